@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF, in this container only.
+
+TEST INFRASTRUCTURE -- run by hand (`python oracle/gen_golden.py`) where /root/reference exists;
+its outputs (small .npz files of inputs + expected outputs) are committed, the reference is not.
+
+How the reference is made to run on a GPU-less host:
+  * its CUDA kernel bodies are compiled for the host by oracle/ref_shim/build_ref.sh into
+    oracle/_ref/libsoftras_ref.so; a tiny in-memory module with the pybind names
+    (cuda/soft_rasterize_cuda.cpp:141-144) forwards torch CPU tensors to it via ctypes;
+  * the SoftRas Python stack (external/SoftRas/soft_renderer) and the UMR wrappers
+    (nnutils/{smr,loss_utils,geom_utils,chamfer_python,scops_utils}.py) are imported UNMODIFIED
+    from /root/reference; absent third-party modules that they import but never use on this
+    path (cv2, torchvision, neural_renderer, skimage, scipy.misc) are registered as empty stubs;
+  * `.cuda()` is patched to identity and `affine_grid`/`grid_sample` defaults to the torch-1.1.0
+    behaviour the reference pins (requirements.txt:8) = align_corners=True.
+Nothing is written under /root/reference (bytecode writing is disabled first).
+"""
+import sys
+sys.dont_write_bytecode = True
+import ctypes
+import importlib.util
+import os
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from umr_amd.mesh import create_sphere  # noqa: E402  (input construction only)
+
+_Fp = ctypes.POINTER(ctypes.c_float)
+
+
+def _p(t):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    return ctypes.cast(t.data_ptr(), _Fp)
+
+
+def install_reference():
+    lib = ctypes.CDLL(os.path.join(HERE, "_ref", "libsoftras_ref.so"))
+
+    def forward_soft_rasterize(faces, textures, faces_info, aggrs_info, grid, p2f_info, p2f_sum, soft_colors,
+                               image_size, near, far, eps, sigma_val, func_id_dist, dist_eps, gamma_val,
+                               func_id_rgb, func_id_alpha, texture_sample_type, double_side):
+        n, f = faces.shape[:2]
+        lib.ref_forward_soft_rasterize(
+            _p(faces), _p(textures), _p(faces_info), _p(aggrs_info), _p(grid), _p(p2f_info), _p(p2f_sum),
+            _p(soft_colors), n, f, int(image_size), int(textures.shape[2]), ctypes.c_float(near),
+            ctypes.c_float(far), ctypes.c_float(eps), ctypes.c_float(sigma_val), int(func_id_dist),
+            ctypes.c_float(dist_eps), ctypes.c_float(gamma_val), int(func_id_rgb), int(func_id_alpha),
+            int(texture_sample_type), int(bool(double_side)))
+        return faces_info, aggrs_info, p2f_info, p2f_sum, soft_colors
+
+    def backward_soft_rasterize(faces, textures, soft_colors, faces_info, aggrs_info, grad_faces, grad_textures,
+                                grad_soft_colors, image_size, near, far, eps, sigma_val, func_id_dist, dist_eps,
+                                gamma_val, func_id_rgb, func_id_alpha, texture_sample_type, double_side):
+        n, f = faces.shape[:2]
+        lib.ref_backward_soft_rasterize(
+            _p(faces), _p(textures), _p(soft_colors), _p(faces_info), _p(aggrs_info), _p(grad_faces),
+            _p(grad_textures), _p(grad_soft_colors), n, f, int(image_size), int(textures.shape[2]),
+            ctypes.c_float(near), ctypes.c_float(far), ctypes.c_float(eps), ctypes.c_float(sigma_val),
+            int(func_id_dist), ctypes.c_float(dist_eps), ctypes.c_float(gamma_val), int(func_id_rgb),
+            int(func_id_alpha), int(texture_sample_type), int(bool(double_side)))
+        return grad_faces, grad_textures
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    cuda_pkg = stub("soft_renderer.cuda")
+    cuda_pkg.__path__ = []
+    stub("soft_renderer.cuda.soft_rasterize", forward_soft_rasterize=forward_soft_rasterize,
+         backward_soft_rasterize=backward_soft_rasterize)
+    for n in ("load_textures", "create_texture_image", "voxelization"):
+        stub("soft_renderer.cuda." + n)
+    sk = stub("skimage"); sk.__path__ = []
+    stub("skimage.io", imread=None, imsave=None)
+    stub("cv2")
+    stub("neural_renderer")
+    tv = stub("torchvision"); tv.__path__ = []
+    stub("torchvision.utils")
+    import scipy
+    scipy.misc = stub("scipy.misc")
+
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    _ag, _gs = F.affine_grid, F.grid_sample
+    F.affine_grid = lambda theta, size, align_corners=True: _ag(theta, size, align_corners=align_corners)
+    F.grid_sample = lambda i, g, mode='bilinear', padding_mode='zeros', align_corners=True: \
+        _gs(i, g, mode=mode, padding_mode=padding_mode, align_corners=align_corners)
+    torch.nn.functional.affine_grid, torch.nn.functional.grid_sample = F.affine_grid, F.grid_sample
+
+    sys.path.insert(0, os.path.join(REF, "external", "SoftRas"))
+    umr = types.ModuleType("UMR"); umr.__path__ = [REF]; sys.modules["UMR"] = umr
+    for sub in ("nnutils", "utils"):
+        m = types.ModuleType("UMR." + sub); m.__path__ = [os.path.join(REF, sub)]; sys.modules["UMR." + sub] = m
+    import soft_renderer as sr
+    from UMR.nnutils import smr, loss_utils, geom_utils, chamfer_python, scops_utils
+    spec = importlib.util.spec_from_file_location(
+        "ps_util", os.path.join(REF, "external", "PerceptualSimilarity", "util", "util.py"))
+    return lib, sr, smr, loss_utils, geom_utils, chamfer_python, scops_utils, spec
+
+
+def scene(n_meshes, subdiv, seed, scale=(0.6, 0.9)):
+    """Seeded synthetic scene: perturbed icosphere + random cameras."""
+    g = torch.Generator().manual_seed(seed)
+    v, f = create_sphere(subdiv)
+    verts = torch.from_numpy(v).float()[None].repeat(n_meshes, 1, 1)
+    verts = verts + 0.05 * torch.randn(verts.shape, generator=g)
+    faces = torch.from_numpy(f).long()[None].repeat(n_meshes, 1, 1)
+    s = scale[0] + (scale[1] - scale[0]) * torch.rand(n_meshes, 1, generator=g)
+    t = -0.1 + 0.2 * torch.rand(n_meshes, 2, generator=g)
+    q = torch.randn(n_meshes, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    return verts, faces, torch.cat([s, t, q], 1), g
+
+
+def np_(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    lib, sr, smr, loss_utils, geom_utils, chamfer_python, scops_utils, ps_spec = install_reference()
+    sys.path.insert(0, ROOT)
+    from oracle import softras  # only for its ctypes helper on the ref .so
+
+    # (i) kernel-level: faces in screen space straight into the reference kernels -------------------------
+    for tag, ts, rgb in (("softmax_ts36", 36, 1), ("softmax_ts1", 1, 1), ("hard_ts1", 1, 0), ("hard_ts4", 4, 0)):
+        verts, faces, cams, g = scene(2, 1, seed=11)
+        proj = geom_utils.orthographic_proj_withz(verts, cams, offset_z=5.)
+        proj[:, :, 1] *= -1
+        proj[:, :, 2] += 2.732
+        fv = sr.functional.face_vertices(proj, faces.int()).contiguous()
+        tex = torch.rand(2, faces.shape[1], ts, 3, generator=g)
+        IS = 64
+        cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(np.log(1. / 1e-10 - 1.)),
+                   gamma_val=1e-4, func_id_rgb=rgb, double_side=True)
+        o = softras.raster_forward(np_(fv), np_(tex), IS, background=(0.1, 0.2, 0.3), backend="ref", **cfg)
+        gsc = torch.randn(2, 4, IS, IS, generator=g)
+        gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"],
+                                         o["aggrs_info"], np_(gsc), IS, backend="ref", **cfg)
+        np.savez_compressed(os.path.join(OUT, "raster_%s.npz" % tag), faces=o["faces"], textures=o["textures"],
+                            image_size=IS, background=np.float32([0.1, 0.2, 0.3]), func_id_rgb=rgb,
+                            faces_info=o["faces_info"], aggrs_info=o["aggrs_info"], p2f_info=o["p2f_info"],
+                            p2f_sum=o["p2f_sum"], soft_colors=o["soft_colors"], grad_soft_colors=np_(gsc),
+                            grad_faces=gf, grad_textures=gt, **{k: v for k, v in cfg.items() if k != "func_id_rgb"})
+        print("raster_%s" % tag, "alpha mean %.4f" % o["soft_colors"][:, 3].mean(), "|gf| %.3e" % np.abs(gf).sum())
+
+    # (ii) nnutils.smr.SoftRenderer.forward end to end (both light settings, with and without textures) ---
+    for tag, ambient_only, with_tex, rtype in (("mask_default_light", False, False, "softmax"),
+                                               ("tex_ambient", True, True, "softmax"),
+                                               ("tex_default_light", False, True, "softmax"),
+                                               ("hard_default_light", False, False, "hard")):
+        verts, faces, cams, g = scene(2, 1, seed=23)
+        verts.requires_grad_(True); cams.requires_grad_(True)
+        tex = torch.rand(2, faces.shape[1], 36, 3, generator=g).requires_grad_(True) if with_tex else None
+        r = smr.SoftRenderer(32, rtype)
+        if ambient_only:
+            r.ambient_light_only()
+        imgs, p2f, aggr = r.forward(verts, faces, cams, tex) if with_tex else r.forward(verts, faces, cams)
+        gi = torch.randn(imgs.shape, generator=g)
+        imgs.backward(gi)
+        d = dict(verts=np_(verts), faces=np_(faces), cams=np_(cams), img_size=32, render_type=rtype,
+                 ambient_only=ambient_only, imgs=np_(imgs), p2f=np_(p2f), aggr=np_(aggr), grad_imgs=np_(gi),
+                 grad_verts=np_(verts.grad), grad_cams=np_(cams.grad),
+                 proj_points=np_(r.project_points(verts, cams)))
+        if with_tex:
+            d.update(textures=np_(tex), grad_textures=np_(tex.grad))
+        np.savez_compressed(os.path.join(OUT, "smr_%s.npz" % tag), **d)
+        print("smr_%s" % tag, "img mean %.4f" % imgs.mean().item())
+
+    # (iii) losses around the renderer ----------------------------------------------------------------------
+    K = 2
+    verts, faces, cams, g = scene(2, 1, seed=31)
+    cams_h = torch.stack([scene(2, 1, seed=40 + k)[2] for k in range(K)], 1).requires_grad_(True)  # [B,K,7]
+    verts.requires_grad_(True)
+    probs = torch.softmax(torch.randn(2, K, generator=g), 1).requires_grad_(True)
+    masks_gt = (torch.rand(2, 32, 32, generator=g) > 0.5).float()
+    mml = loss_utils.MultiMaskLoss(32, "softmax", K)
+    loss, mask_all = mml.forward(verts, faces, cams_h, probs, masks_gt)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "loss_multimask.npz"), verts=np_(verts), faces=np_(faces),
+                        cams_all_hypo=np_(cams_h), cam_probs=np_(probs), masks_gt=np_(masks_gt), loss=np_(loss),
+                        mask_all_hypo=np_(mask_all), grad_verts=np_(verts.grad), grad_cams=np_(cams_h.grad),
+                        grad_probs=np_(probs.grad), image_size=32, num_hypo_cams=K)
+    print("loss_multimask %.6f" % loss.item())
+
+    p = torch.rand(3, 16, 16, generator=g).requires_grad_(True)
+    t = (torch.rand(3, 16, 16, generator=g) > 0.4).float()
+    l1 = loss_utils.neg_iou_loss(p, t); l2 = loss_utils.neg_iou_loss(p, t, avg=False)
+    (l1 + (l2 * torch.tensor([1., 2., 3.])).sum()).backward()
+    np.savez_compressed(os.path.join(OUT, "loss_neg_iou.npz"), predict=np_(p), target=np_(t), loss_avg=np_(l1),
+                        loss_per=np_(l2), grad_predict=np_(p.grad))
+
+    B, Fn, T = 2, 80, 6
+    flow = (torch.rand(B, Fn, T, T, 2, generator=g) * 2.4 - 1.2).requires_grad_(True)  # some out of range
+    images = torch.rand(B, 3, 24, 24, generator=g).requires_grad_(True)
+    dts = torch.rand(B, 1, 24, 24, generator=g)
+    tex = geom_utils.sample_textures(flow, images)
+    gtex = torch.randn(tex.shape, generator=g)
+    tex.backward(gtex)
+    gflow_tex, gimg = flow.grad.clone(), images.grad.clone()
+    flow.grad = None
+    dtl = loss_utils.texture_dt_loss(flow, dts)
+    dtl.backward()
+    np.savez_compressed(os.path.join(OUT, "loss_texture_sampling.npz"), flow=np_(flow), images=np_(images),
+                        dts=np_(dts), tex=np_(tex), grad_tex=np_(gtex), grad_flow_from_tex=np_(gflow_tex),
+                        grad_images=np_(gimg), dt_loss=np_(dtl), grad_flow_from_dt=np_(flow.grad))
+
+    # TexCycle on real renderer outputs: softmax p2f (train_s1.py:217-226) and hard face-id plane
+    verts, faces, cams, g = scene(2, 1, seed=57)
+    texr = smr.SoftRenderer(32, "softmax"); texr.ambient_light_only()
+    _, p2f_soft, _ = texr.forward(verts, faces, cams, torch.rand(2, 80, 36, 3, generator=g))
+    _, p2f_hard, aggr_hard = smr.SoftRenderer(32, "hard").forward(verts, faces, cams)
+    ids = aggr_hard[:, 1].reshape(2, -1)
+    flow = (torch.rand(2, 80, 6, 6, 2, generator=g) * 2 - 1).requires_grad_(True)
+    tc = loss_utils.TexCycle()
+    lc, avg10 = tc.forward(flow, p2f_soft.detach(), ids.detach())
+    lc.backward()
+    lc_hard, _ = tc.forward(flow, p2f_hard.detach(), ids.detach())
+    np.savez_compressed(os.path.join(OUT, "loss_texcycle.npz"), verts=np_(verts), faces=np_(faces), cams=np_(cams),
+                        flow=np_(flow), p2f_soft=np_(p2f_soft), p2f_hard=np_(p2f_hard), face_ids=np_(ids),
+                        loss=np_(lc), loss_hard_target=np_(lc_hard), grad_flow=np_(flow.grad), avg_flow10=np_(avg10))
+    print("loss_texcycle %.6f hard-p2f abs sum %.3e ids min %d" % (lc.item(), p2f_hard.abs().sum().item(), int(ids.min())))
+
+    dv = torch.randn(2, 30, 3, generator=g).requires_grad_(True)
+    (loss_utils.deform_l2reg(dv) + 2 * loss_utils.sym_reg(dv)).backward()
+    np.savez_compressed(os.path.join(OUT, "loss_small_regs.npz"), v=np_(dv), deform=np_(loss_utils.deform_l2reg(dv)),
+                        sym=np_(loss_utils.sym_reg(dv)), grad_v=np_(dv.grad))
+
+    # (iv) chamfer ------------------------------------------------------------------------------------------
+    ch = {}
+    for i, (b, n, m, d) in enumerate(((3, 17, 10, 2), (2, 40, 30, 2), (1, 700, 42, 2), (2, 9, 13, 3))):
+        a = torch.randn(b, n, d, generator=g).requires_grad_(True)
+        bb = torch.randn(b, m, d, generator=g).requires_grad_(True)
+        d1, d2, i1, i2 = chamfer_python.distChamfer(a, bb)
+        (d1.sum() + 0.5 * d2.sum()).backward()
+        ch.update({"a%d" % i: np_(a), "b%d" % i: np_(bb), "d1_%d" % i: np_(d1), "d2_%d" % i: np_(d2),
+                   "i1_%d" % i: np_(i1), "i2_%d" % i: np_(i2), "ga%d" % i: np_(a.grad), "gb%d" % i: np_(bb.grad)})
+    np.savez_compressed(os.path.join(OUT, "chamfer.npz"), n_cases=4, **ch)
+
+    # (v) mesh regularisers on icosphere(1) -----------------------------------------------------------------
+    v, f = create_sphere(1)
+    vt, ft = torch.from_numpy(v).float(), torch.from_numpy(f).int()
+    lap, flat = sr.LaplacianLoss(vt, ft), sr.FlattenLoss(ft)
+    x = (vt[None].repeat(2, 1, 1) + 0.1 * torch.randn(2, 42, 3, generator=g)).requires_grad_(True)
+    ll, fl = lap(x), flat(x)
+    (ll.sum() + fl.sum()).backward()
+    np.savez_compressed(os.path.join(OUT, "mesh_regs.npz"), verts0=v.astype(np.float32), faces=f, x=np_(x),
+                        laplacian=np_(ll), flatten=np_(fl), grad_x=np_(x.grad), lap_matrix=np_(lap.laplacian))
+
+    # (vi) SCOPS centroids + PNet cosine head ---------------------------------------------------------------
+    pm = torch.softmax(torch.randn(2, 5, 24, 24, generator=g), 1).requires_grad_(True)
+    cen = scops_utils.batch_get_centers(pm[:, 1:])
+    cen.backward(torch.ones_like(cen))
+    ps_util_src = open(ps_spec.origin).read()
+    ns = {"torch": torch, "np": np}
+    # only the two pure-torch helpers are needed; the module's top-level imports (matplotlib, skimage...) are absent
+    start = ps_util_src.index("def normalize_tensor"); end = ps_util_src.index("# Converts a Tensor into a Numpy array")
+    exec(compile(ps_util_src[start:end], ps_spec.origin, "exec"), ns)
+    f0 = [torch.randn(2, c, s, s, generator=g) for c, s in ((8, 7), (16, 5))]
+    f1 = [torch.randn(2, c, s, s, generator=g) for c, s in ((8, 7), (16, 5))]
+    val = sum((1. - ns["cos_sim"](a, b)) for a, b in zip(f0, f1))
+    np.savez_compressed(os.path.join(OUT, "parts_and_cossim.npz"), part_maps=np_(pm), centers=np_(cen),
+                        grad_part_maps=np_(pm.grad), f0_0=np_(f0[0]), f0_1=np_(f0[1]), f1_0=np_(f1[0]),
+                        f1_1=np_(f1[1]), cos_dist=np_(val))
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""ctypes front-end for the CPU raster oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Nothing under umr_amd/ does (tests/test_no_oracle_in_product.py enforces it).
+
+Two back-ends with one calling convention (that of the reference binding,
+external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda.cpp:62-138):
+  * "port"  -> oracle/liboracle.so        (oracle/softras_oracle.c, our C restatement)
+  * "ref"   -> oracle/_ref/libsoftras_ref.so  (the reference's own kernel bodies compiled
+               for the host by oracle/ref_shim/build_ref.sh; exists only where it was built)
+
+``soft_rasterize`` below restates the reference's autograd wrapper
+(functional/soft_rasterize.py:9-125) on CPU tensors so that the whole render-and-compare
+path can be differentiated on the host for parity tests.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_F = ctypes.POINTER(ctypes.c_float)
+_libs = {}
+
+
+def _ptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_F)
+
+
+def have_backend(name):
+    path = {"port": os.path.join(_HERE, "liboracle.so"),
+            "ref": os.path.join(_HERE, "_ref", "libsoftras_ref.so")}[name]
+    return os.path.exists(path)
+
+
+def _lib(name):
+    if name not in _libs:
+        path = {"port": os.path.join(_HERE, "liboracle.so"),
+                "ref": os.path.join(_HERE, "_ref", "libsoftras_ref.so")}[name]
+        if not os.path.exists(path):
+            raise RuntimeError("oracle backend %r not built (%s); run `make -C oracle`" % (name, path))
+        _libs[name] = ctypes.CDLL(path)
+    return _libs[name]
+
+
+def max_threads():
+    lib = _lib("port")
+    lib.oracle_max_threads.restype = ctypes.c_int
+    return int(lib.oracle_max_threads())
+
+
+def raster_forward(faces, textures, image_size, background=(0, 0, 0), near=1.0, far=100.0, eps=1e-3,
+                   sigma_val=1e-5, dist_eps_log=None, gamma_val=1e-4, func_id_rgb=1, double_side=True,
+                   backend="port", n_threads=1, func_id_dist=2, func_id_alpha=2, texture_sample_type=0):
+    """Innermost level.  faces [N,F,9|3x3] f32, textures [N,F,TS,3] f32 (numpy).
+    ``dist_eps_log`` is the value the binding receives, log(1/dist_eps - 1).
+    Returns dict(faces_info, aggrs_info, p2f_info, p2f_sum, soft_colors) (raw, un-normalised p2f)."""
+    faces = np.ascontiguousarray(faces, np.float32).reshape(faces.shape[0], faces.shape[1], 9)
+    textures = np.ascontiguousarray(textures, np.float32)
+    n, f = faces.shape[:2]
+    ts = textures.shape[2]
+    IS = int(image_size)
+    faces_info = np.zeros((n, f, 27), np.float32)
+    aggrs_info = np.zeros((n, 2, IS, IS), np.float32)
+    p2f_info = np.zeros((n, f, 2), np.float32)
+    p2f_sum = np.zeros((n, f, 2), np.float32)
+    soft_colors = np.ones((n, 4, IS, IS), np.float32)
+    for k in range(3):
+        soft_colors[:, k] *= np.float32(background[k])
+    grid = standard_grid(IS)
+    args = [_ptr(faces), _ptr(textures), _ptr(faces_info), _ptr(aggrs_info), _ptr(grid), _ptr(p2f_info),
+            _ptr(p2f_sum), _ptr(soft_colors), ctypes.c_int(n), ctypes.c_int(f), ctypes.c_int(IS),
+            ctypes.c_int(ts), ctypes.c_float(near), ctypes.c_float(far), ctypes.c_float(eps),
+            ctypes.c_float(sigma_val), ctypes.c_int(func_id_dist), ctypes.c_float(dist_eps_log),
+            ctypes.c_float(gamma_val), ctypes.c_int(func_id_rgb), ctypes.c_int(func_id_alpha),
+            ctypes.c_int(texture_sample_type), ctypes.c_int(1 if double_side else 0)]
+    lib = _lib(backend)
+    if backend == "port":
+        rc = lib.oracle_raster_forward(*args, ctypes.c_int(n_threads))
+    else:
+        rc = lib.ref_forward_soft_rasterize(*args)
+    if rc != 0:
+        raise RuntimeError("oracle forward rc=%d" % rc)
+    return dict(faces=faces, textures=textures, faces_info=faces_info, aggrs_info=aggrs_info,
+                p2f_info=p2f_info, p2f_sum=p2f_sum, soft_colors=soft_colors)
+
+
+def raster_backward(faces, textures, soft_colors, faces_info, aggrs_info, grad_soft_colors, image_size,
+                    near=1.0, far=100.0, eps=1e-3, sigma_val=1e-5, dist_eps_log=None, gamma_val=1e-4,
+                    func_id_rgb=1, double_side=True, backend="port", n_threads=1, func_id_dist=2,
+                    func_id_alpha=2, texture_sample_type=0):
+    faces = np.ascontiguousarray(faces, np.float32).reshape(faces.shape[0], faces.shape[1], 9)
+    textures = np.ascontiguousarray(textures, np.float32)
+    n, f = faces.shape[:2]
+    ts = textures.shape[2]
+    IS = int(image_size)
+    grad_faces = np.zeros((n, f, 9), np.float32)
+    grad_textures = np.zeros((n, f, ts, 3), np.float32)
+    g = np.ascontiguousarray(grad_soft_colors, np.float32)
+    sc = np.ascontiguousarray(soft_colors, np.float32)
+    fi = np.ascontiguousarray(faces_info, np.float32)
+    ag = np.ascontiguousarray(aggrs_info, np.float32)
+    args = [_ptr(faces), _ptr(textures), _ptr(sc), _ptr(fi), _ptr(ag), _ptr(grad_faces), _ptr(grad_textures),
+            _ptr(g), ctypes.c_int(n), ctypes.c_int(f), ctypes.c_int(IS), ctypes.c_int(ts),
+            ctypes.c_float(near), ctypes.c_float(far), ctypes.c_float(eps), ctypes.c_float(sigma_val),
+            ctypes.c_int(func_id_dist), ctypes.c_float(dist_eps_log), ctypes.c_float(gamma_val),
+            ctypes.c_int(func_id_rgb), ctypes.c_int(func_id_alpha), ctypes.c_int(texture_sample_type),
+            ctypes.c_int(1 if double_side else 0)]
+    lib = _lib(backend)
+    if backend == "port":
+        rc = lib.oracle_raster_backward(*args, ctypes.c_int(n_threads))
+    else:
+        rc = lib.ref_backward_soft_rasterize(*args)
+    if rc != 0:
+        raise RuntimeError("oracle backward rc=%d" % rc)
+    return grad_faces, grad_textures
+
+
+def standard_grid(image_size):
+    """The `grid` argument the reference builds (functional/soft_rasterize.py:57-62):
+    affine_grid(identity) under torch 1.1.0 semantics (requirements.txt:8), i.e. what
+    torch>=1.3 calls align_corners=True: coordinates linspace(-1, 1, IS)."""
+    theta = torch.tensor([[1, 0, 0], [0, 1, 0]], dtype=torch.float)
+    g = torch.nn.functional.affine_grid(theta.unsqueeze(0), (1, 1, image_size, image_size), align_corners=True)
+    return np.ascontiguousarray(g.view(image_size, image_size, 2).numpy(), np.float32)
+
+
+class _SoftRasterizeCPU(torch.autograd.Function):
+    """functional/soft_rasterize.py:9-108 on CPU tensors, kernels = the C oracle."""
+
+    @staticmethod
+    def forward(ctx, face_vertices, textures, image_size, background_color, near, far, fill_back, eps,
+                sigma_val, dist_eps, gamma_val, aggr_func_rgb, backend, n_threads):
+        ctx.cfg = dict(image_size=image_size, near=near, far=far, eps=eps, sigma_val=sigma_val,
+                       dist_eps_log=float(np.log(1. / dist_eps - 1.)), gamma_val=gamma_val,
+                       func_id_rgb={"hard": 0, "softmax": 1}[aggr_func_rgb], double_side=fill_back,
+                       backend=backend, n_threads=n_threads)
+        out = raster_forward(face_vertices.detach().numpy(), textures.detach().numpy(),
+                             background=background_color, **ctx.cfg)
+        ctx.saved = out
+        p2f = torch.from_numpy(out["p2f_info"]) / torch.from_numpy(out["p2f_sum"]).clamp_min(1e-12)  # :73
+        return torch.from_numpy(out["soft_colors"].copy()), p2f, torch.from_numpy(out["aggrs_info"].copy())
+
+    @staticmethod
+    def backward(ctx, grad_soft_colors, grad_p2f=None, grad_aggr=None):
+        o = ctx.saved
+        cfg = dict(ctx.cfg)
+        gf, gt = raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                 grad_soft_colors.contiguous().numpy(), **cfg)
+        n, f = gf.shape[:2]
+        return (torch.from_numpy(gf).view(n, f, 3, 3), torch.from_numpy(gt)) + (None,) * 12
+
+
+def soft_rasterize(face_vertices, textures, image_size=256, background_color=(0, 0, 0), near=1, far=100,
+                   fill_back=True, eps=1e-3, sigma_val=1e-5, dist_eps=1e-4, gamma_val=1e-4,
+                   aggr_func_rgb="softmax", backend="port", n_threads=1):
+    """Middle level: functional/soft_rasterize.py:111-125 (euclidean / prod / surface only)."""
+    return _SoftRasterizeCPU.apply(face_vertices, textures, image_size, list(background_color), float(near),
+                                   float(far), bool(fill_back), float(eps), float(sigma_val), float(dist_eps),
+                                   float(gamma_val), aggr_func_rgb, backend, n_threads)

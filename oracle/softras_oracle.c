@@ -1,0 +1,420 @@
+/*
+ * softras_oracle.c -- CPU restatement of the reference soft rasterizer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under umr_amd/ may import, link or call
+ * this file; it exists so tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check / time the reference ALGORITHM on host cores.
+ *
+ * What it restates (all paths relative to /root/reference):
+ *   external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda_kernel.cu
+ *     :223-282  per-face preprocessing        -> oracle_face_info()
+ *     :63-152   euclidean pixel->triangle d   -> p2f_euclid()
+ *     :54-59    barycentric clip              -> bary_clip()
+ *     :180-195  surface texel lookup          -> texel_index()
+ *     :286-476  per-pixel forward aggregation -> oracle_raster_forward()
+ *     :480-656  per-pixel analytic backward   -> oracle_raster_backward()
+ *
+ * Work complexity is the reference's: one work item per pixel, a serial loop
+ * over ALL faces in index order, no binning.  The reference instantiates its
+ * templates with scalar_t=float but writes many constants as double literals
+ * (1., 2., 1e-5 ...), which promotes individual sub-expressions to double
+ * before rounding back to float.  This file reproduces that promotion
+ * pattern expression by expression (see the "dbl:" comments) and must be
+ * compiled with -ffp-contract=off.
+ *
+ * Scope: the modes UMR instantiates (nnutils/smr.py:53-66) -- dist_func
+ * euclidean (func_id_dist=2), alpha 'prod' (func_id_alpha=2), rgb 'softmax'
+ * (1) or 'hard' (0), texture_type 'surface' (0).  Other ids return -1.
+ *
+ * Pinning: validated against the reference's own kernel bodies compiled for
+ * the host (oracle/ref_shim -> oracle/_ref/libsoftras_ref.so) and against
+ * tests/golden/raster_*.npz generated from them (oracle/gen_golden.py).
+ *
+ * Defined deviations from the reference (both are undefined behaviour there):
+ *  - backward_sample_texture (:199-218) returns an uninitialised local for
+ *    non-selected texels; here they contribute exactly 0.
+ *  - the outside-triangle branch can leave v0=-1 when no w<=0 although some
+ *    w>=1 (only reachable through rounding); the reference then indexes
+ *    face_sym[-3..] and t[-1].  Here that (pixel, face) pair is skipped.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define FI_STRIDE 27 /* faces_info row: inv[9] sym[9] obt[3] unused[6] (:236-238) */
+
+/* ---- :223-282 ------------------------------------------------------------ */
+void oracle_face_info(const float *faces, float *faces_info, int n_meshes, int n_faces) {
+    const long total = (long)n_meshes * n_faces;
+    for (long i = 0; i < total; ++i) {
+        const float *f = faces + i * 9;
+        float *inv = faces_info + i * FI_STRIDE;
+        float *sym = inv + 9;
+        float *obt = inv + 18;
+        const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
+        /* adjugate of [[x0,x1,x2],[y0,y1,y2],[1,1,1]] (:251-254) */
+        const float adj[9] = {
+            y1 - y2, x2 - x1, x1 * y2 - x2 * y1,
+            y2 - y0, x0 - x2, x2 * y0 - x0 * y2,
+            y0 - y1, x1 - x0, x0 * y1 - x1 * y0};
+        float det = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0); /* :255-258 */
+        /* dbl: max/min against the double literal 1e-10, rounded to float (:259) */
+        det = det > 0 ? (float)fmax((double)det, 1e-10) : (float)fmin((double)det, -1e-10);
+        for (int k = 0; k < 9; ++k) inv[k] = adj[k] / det;
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k)
+                sym[j * 3 + k] = f[j * 3] * f[k * 3] + f[j * 3 + 1] * f[k * 3 + 1] + 1; /* :267-269 */
+        for (int k = 0; k < 9; ++k) obt[k] = 0.f; /* caller zero-fills in the reference */
+        const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+        for (int k = 0; k < 3; ++k) { /* first obtuse corner only (:273-281) */
+            const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            if ((px[k1] - px[k]) * (px[k2] - px[k]) + (py[k1] - py[k]) * (py[k2] - py[k]) < 0) {
+                obt[k] = 1.f;
+                break;
+            }
+        }
+    }
+}
+
+/* ---- :33-38 -------------------------------------------------------------- */
+static inline int outside_bbox(float x, float y, const float *f, float thr) {
+    const float xmax = fmaxf(fmaxf(f[0], f[3]), f[6]), xmin = fminf(fminf(f[0], f[3]), f[6]);
+    const float ymax = fmaxf(fmaxf(f[1], f[4]), f[7]), ymin = fminf(fminf(f[1], f[4]), f[7]);
+    return x > xmax + thr || x < xmin - thr || y > ymax + thr || y < ymin - thr;
+}
+
+/* ---- :54-59 -------------------------------------------------------------- */
+static inline void bary_clip(float *w) {
+    /* dbl: clamp bounds 1-1e-5 and 1e-5 are doubles */
+    for (int k = 0; k < 3; ++k) w[k] = (float)fmax(fmin((double)w[k], 1 - 1e-5), 1e-5);
+    const float s = (float)fmax((double)(w[0] + w[1] + w[2]), 1e-5);
+    for (int k = 0; k < 3; ++k) w[k] /= s;
+}
+
+/* ---- :180-189 (surface sampling): index of the texel hit by clipped w ----- */
+static inline int texel_index(const float *w, int R) {
+    const int wx = (int)(w[0] * R);
+    const int wy = (int)(w[1] * R);
+    if ((w[0] + w[1]) * R - wx - wy <= 1) return wy * R + wx;
+    return (R - 1 - wy) * R + (R - 1 - wx);
+}
+
+/* ---- :63-152 --------------------------------------------------------------
+ * Returns 0 on success, 1 for the v0=-1 degenerate (see header).  t receives
+ * (closest-point barycentric) - w; (dx,dy) the vector pixel->closest point. */
+static inline int p2f_euclid(float *sign, float *dx, float *dy, const float *w, float *t,
+                             const float *f, const float *fi, float xp, float yp) {
+    const float *sym = fi + 9;
+    const float *obt = fi + 18;
+    t[0] = t[1] = t[2] = 0.f;
+    if (w[0] > 0 && w[1] > 0 && w[2] > 0 && w[0] < 1 && w[1] < 1 && w[2] < 1) {
+        float best = 100000000.f, bx = 0.f, by = 0.f;
+        for (int k = 0; k < 3; ++k) { /* closest of the three edge lines, parameter NOT clamped */
+            const int v0 = k, v1 = (k + 1) % 3, v2 = (k + 2) % 3;
+            float a[3], tt[3];
+            for (int j = 0; j < 3; ++j) a[j] = sym[3 * v0 + j] - sym[3 * v1 + j];
+            tt[v0] = (w[0] * a[0] + w[1] * a[1] + w[2] * a[2] - a[v1]) / (a[v0] - a[v1]);
+            tt[v1] = 1 - tt[v0];
+            tt[v2] = 0;
+            for (int j = 0; j < 3; ++j) tt[j] -= w[j];
+            const float ex = tt[0] * f[0] + tt[1] * f[3] + tt[2] * f[6];
+            const float ey = tt[0] * f[1] + tt[1] * f[4] + tt[2] * f[7];
+            const float d = ex * ex + ey * ey;
+            if (d < best) {
+                best = d; bx = ex; by = ey;
+                t[0] = tt[0]; t[1] = tt[1]; t[2] = tt[2];
+            }
+        }
+        *dx = bx; *dy = by; *sign = 1.f;
+        return 0;
+    }
+    int v0 = -1;
+    if (w[1] <= 0 && w[2] <= 0) {
+        v0 = 0;
+        if (obt[0] == 1 && (xp - f[0]) * (f[6] - f[0]) + (yp - f[1]) * (f[7] - f[1]) > 0) v0 = 2;
+    } else if (w[2] <= 0 && w[0] <= 0) {
+        v0 = 1;
+        if (obt[1] == 1 && (xp - f[3]) * (f[0] - f[3]) + (yp - f[4]) * (f[1] - f[4]) > 0) v0 = 0;
+    } else if (w[0] <= 0 && w[1] <= 0) {
+        v0 = 2;
+        if (obt[2] == 1 && (xp - f[6]) * (f[3] - f[6]) + (yp - f[7]) * (f[4] - f[7]) > 0) v0 = 1;
+    } else if (w[0] <= 0) v0 = 1;
+    else if (w[1] <= 0) v0 = 2;
+    else if (w[2] <= 0) v0 = 0;
+    if (v0 < 0) return 1;
+    const int v1 = (v0 + 1) % 3, v2 = (v0 + 2) % 3;
+    float a[3];
+    for (int j = 0; j < 3; ++j) a[j] = sym[3 * v0 + j] - sym[3 * v1 + j];
+    t[v0] = (w[0] * a[0] + w[1] * a[1] + w[2] * a[2] - a[v1]) / (a[v0] - a[v1]);
+    t[v1] = 1 - t[v0];
+    t[v2] = 0;
+    for (int k = 0; k < 3; ++k) {
+        t[k] = (float)fmin(fmax((double)t[k], 0.), 1.); /* dbl: clamp (:143) */
+        t[k] -= w[k];
+    }
+    *dx = t[0] * f[0] + t[1] * f[3] + t[2] * f[6];
+    *dy = t[0] * f[1] + t[1] * f[4] + t[2] * f[7];
+    *sign = -1.f;
+    return 0;
+}
+
+static inline int front_facing(const float *f) { /* :42-44 */
+    return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
+}
+
+typedef struct {
+    float near_, far_, eps, sigma, dist_eps, gamma;
+    int rgb_mode, double_side;
+} oracle_params;
+
+static int modes_supported(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type) {
+    return func_id_dist == 2 && func_id_alpha == 2 && texture_sample_type == 0 &&
+           (func_id_rgb == 0 || func_id_rgb == 1);
+}
+
+/* ---- :286-476 --------------------------------------------------------------
+ * Buffers exactly as the reference binding (cuda/soft_rasterize_cuda.cpp:62-82):
+ * caller pre-fills soft_colors (rgb=background, a=1) and zero-fills the rest.
+ * n_threads<=1 reproduces the serial pixel order of the float accumulations
+ * into p2f_info / p2f_sum; otherwise rows are split over OpenMP threads with
+ * per-thread partial sums merged at the end. */
+int oracle_raster_forward(const float *faces, const float *textures, float *faces_info,
+                          float *aggrs_info, const float *grid, float *p2f_info, float *p2f_sum,
+                          float *soft_colors, int n_meshes, int n_faces, int image_size,
+                          int texture_size, float near_, float far_, float eps, float sigma_val,
+                          int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
+                          int func_id_alpha, int texture_sample_type, int double_side,
+                          int n_threads) {
+    if (!modes_supported(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return -1;
+    oracle_face_info(faces, faces_info, n_meshes, n_faces);
+    const int is = image_size, nf = n_faces, ts = texture_size;
+    const int R = (int)sqrt((double)ts); /* :687 */
+    const long npix = (long)is * is;
+    const float threshold = dist_eps * sigma_val; /* :332 */
+    const float thr = sqrtf(threshold);           /* :355 */
+    if (n_threads < 1) n_threads = 1;
+#ifndef _OPENMP
+    n_threads = 1;
+#endif
+    float *partial = NULL;
+    if (n_threads > 1 && func_id_rgb == 1)
+        partial = (float *)calloc((size_t)n_threads * n_meshes * nf * 3, sizeof(float));
+
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) if (n_threads > 1)
+    for (long row = 0; row < (long)n_meshes * is; ++row) {
+        const int bn = (int)(row / is);
+        const int r = (int)(row % is);
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        float *acc = partial ? partial + ((size_t)tid * n_meshes + bn) * nf * 3 : NULL;
+        for (int xi = 0; xi < is; ++xi) {
+            const long pn = (long)r * is + xi;
+            const int yi = is - 1 - r;
+            const float yp = (float)((2. * yi + 1. - is) / is); /* dbl (:325-326) */
+            const float xp = (float)((2. * xi + 1. - is) / is);
+            float col[4] = {1.f, 1.f, 1.f, 1.f}; /* alpha starts at 1 for 'prod' (:335-336) */
+            float ssum = expf(eps / gamma_val);   /* :337 */
+            float smax = eps;
+            for (int k = 0; k < 3; ++k) {
+                const float bg = soft_colors[((long)bn * 4 + k) * npix + pn];
+                col[k] = func_id_rgb == 0 ? bg : bg * ssum; /* :340-345 */
+            }
+            float depth_min = 10000000.f;
+            int face_min = -1;
+            for (int fn = 0; fn < nf; ++fn) {
+                const float *f = faces + ((long)bn * nf + fn) * 9;
+                const float *fi = faces_info + ((long)bn * nf + fn) * FI_STRIDE;
+                const float *tex = textures + ((long)bn * nf + fn) * ts * 3;
+                if (outside_bbox(xp, yp, f, thr)) continue;
+                float w[3], wc[3], t[3], sign, dx, dy;
+                for (int k = 0; k < 3; ++k) w[k] = fi[3 * k] * xp + fi[3 * k + 1] * yp + fi[3 * k + 2];
+                if (p2f_euclid(&sign, &dx, &dy, w, t, f, fi, xp, yp)) continue;
+                const float dis = dx * dx + dy * dy;
+                if (sign < 0 && dis >= threshold) continue; /* :382 */
+                /* dbl: 1./(1.+float) (:383) */
+                const float frag = (float)(1. / (1. + (double)expf(-sign * dis / sigma_val)));
+                col[3] = (float)((double)col[3] * (1. - (double)frag)); /* dbl (:396) */
+                for (int k = 0; k < 3; ++k) wc[k] = w[k];
+                bary_clip(wc);
+                const float zp = (float)(1. / (double)(wc[0] / f[2] + wc[1] / f[5] + wc[2] / f[8])); /* dbl (:403) */
+                if (zp < near_ || zp > far_) continue; /* AFTER alpha (:404) */
+                if (func_id_rgb == 0) { /* :408-416 */
+                    const int inside = w[0] <= 1 && w[0] >= 0 && w[1] <= 1 && w[1] >= 0 && w[2] <= 1 && w[2] >= 0;
+                    if (zp < depth_min && inside && (double_side || front_facing(f))) {
+                        depth_min = zp;
+                        face_min = fn;
+                        const int tix = texel_index(wc, R);
+                        for (int k = 0; k < 3; ++k) col[k] = tex[tix * 3 + k];
+                    }
+                } else if (front_facing(f) || double_side) { /* :417-436 */
+                    const float zn = (far_ - zp) / (far_ - near_);
+                    float rescale = 1.f;
+                    if (zn > smax) {
+                        rescale = expf((smax - zn) / gamma_val);
+                        smax = zn;
+                    }
+                    const float ez = expf((zn - smax) / gamma_val);
+                    ssum = rescale * ssum + ez * frag;
+                    const float wgt = ez * frag;
+                    const float gx = wgt * grid[pn * 2], gy = wgt * grid[pn * 2 + 1];
+                    if (acc) {
+                        acc[fn * 3] += gx; acc[fn * 3 + 1] += gy; acc[fn * 3 + 2] += wgt;
+                    } else {
+                        float *pi = p2f_info + ((long)bn * nf + fn) * 2;
+                        float *ps = p2f_sum + ((long)bn * nf + fn) * 2;
+                        pi[0] += gx; pi[1] += gy; ps[0] += wgt; ps[1] += wgt;
+                    }
+                    const int tix = texel_index(wc, R);
+                    for (int k = 0; k < 3; ++k) col[k] = rescale * col[k] + wgt * tex[tix * 3 + k];
+                }
+            }
+            soft_colors[((long)bn * 4 + 3) * npix + pn] = (float)(1. - (double)col[3]); /* :450 */
+            if (func_id_rgb == 0) {
+                if (face_min != -1)
+                    for (int k = 0; k < 3; ++k) soft_colors[((long)bn * 4 + k) * npix + pn] = col[k];
+                aggrs_info[((long)bn * 2) * npix + pn] = depth_min;
+                aggrs_info[((long)bn * 2 + 1) * npix + pn] = (float)face_min;
+            } else {
+                for (int k = 0; k < 3; ++k) soft_colors[((long)bn * 4 + k) * npix + pn] = col[k] / ssum;
+                aggrs_info[((long)bn * 2) * npix + pn] = ssum;
+                aggrs_info[((long)bn * 2 + 1) * npix + pn] = smax;
+            }
+        }
+    }
+    if (partial) {
+        for (int th = 0; th < n_threads; ++th)
+            for (long i = 0; i < (long)n_meshes * nf; ++i) {
+                const float *a = partial + ((size_t)th * n_meshes * nf + i) * 3;
+                p2f_info[i * 2] += a[0]; p2f_info[i * 2 + 1] += a[1];
+                p2f_sum[i * 2] += a[2];  p2f_sum[i * 2 + 1] += a[2];
+            }
+        free(partial);
+    }
+    return 0;
+}
+
+/* ---- :480-656 --------------------------------------------------------------
+ * grad_faces [N,F,9] and grad_textures [N,F,TS,3] must arrive zero-filled
+ * (functional/soft_rasterize.py:95-96); contributions are ADDED. */
+int oracle_raster_backward(const float *faces, const float *textures, const float *soft_colors,
+                           const float *faces_info, const float *aggrs_info, float *grad_faces,
+                           float *grad_textures, const float *grad_soft_colors, int n_meshes,
+                           int n_faces, int image_size, int texture_size, float near_, float far_,
+                           float eps, float sigma_val, int func_id_dist, float dist_eps,
+                           float gamma_val, int func_id_rgb, int func_id_alpha,
+                           int texture_sample_type, int double_side, int n_threads) {
+    (void)eps;
+    if (!modes_supported(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return -1;
+    const int is = image_size, nf = n_faces, ts = texture_size;
+    const int R = (int)sqrt((double)ts);
+    const long npix = (long)is * is;
+    const float threshold = dist_eps * sigma_val;
+    const float thr = sqrtf(threshold);
+    if (n_threads < 1) n_threads = 1;
+#ifndef _OPENMP
+    n_threads = 1;
+#endif
+    const size_t gf_n = (size_t)n_meshes * nf * 9, gt_n = (size_t)n_meshes * nf * ts * 3;
+    float *pf = NULL, *pt = NULL;
+    if (n_threads > 1) {
+        pf = (float *)calloc(gf_n * n_threads, sizeof(float));
+        pt = (float *)calloc(gt_n * n_threads, sizeof(float));
+    }
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) if (n_threads > 1)
+    for (long row = 0; row < (long)n_meshes * is; ++row) {
+        const int bn = (int)(row / is);
+        const int r = (int)(row % is);
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        float *gF = pf ? pf + gf_n * tid : grad_faces;
+        float *gT = pt ? pt + gt_n * tid : grad_textures;
+        for (int xi = 0; xi < is; ++xi) {
+            const long pn = (long)r * is + xi;
+            const int yi = is - 1 - r;
+            const float yp = (float)((2. * yi + 1 - is) / is);
+            const float xp = (float)((2. * xi + 1 - is) / is);
+            const float ssum = aggrs_info[((long)bn * 2) * npix + pn];
+            const float smax = aggrs_info[((long)bn * 2 + 1) * npix + pn];
+            const float out_a = soft_colors[((long)bn * 4 + 3) * npix + pn];
+            float out_c[3], g[4];
+            for (int k = 0; k < 3; ++k) out_c[k] = soft_colors[((long)bn * 4 + k) * npix + pn];
+            for (int k = 0; k < 4; ++k) g[k] = grad_soft_colors[((long)bn * 4 + k) * npix + pn];
+            for (int fn = 0; fn < nf; ++fn) {
+                const float *f = faces + ((long)bn * nf + fn) * 9;
+                const float *fi = faces_info + ((long)bn * nf + fn) * FI_STRIDE;
+                const float *tex = textures + ((long)bn * nf + fn) * ts * 3;
+                if (outside_bbox(xp, yp, f, thr)) continue;
+                float w[3], w0[3], t[3], sign, dx, dy;
+                for (int k = 0; k < 3; ++k) w[k] = fi[3 * k] * xp + fi[3 * k + 1] * yp + fi[3 * k + 2];
+                if (p2f_euclid(&sign, &dx, &dy, w, t, f, fi, xp, yp)) continue;
+                const float dis = dx * dx + dy * dy;
+                if (sign < 0 && dis >= threshold) continue;
+                const float frag = (float)(1. / (1. + (double)expf(-sign * dis / sigma_val)));
+                float gv[3][3] = {{0}};
+                /* dbl: max(1-frag, 1e-6) is double, so is the quotient and product (:584) */
+                float c_alpha = g[3];
+                c_alpha = (float)((double)c_alpha * ((double)(1 - out_a) / fmax((double)(1 - frag), 1e-6)));
+                float c_xy = 0.f;
+                c_xy += c_alpha;
+                for (int k = 0; k < 3; ++k) w0[k] = w[k];
+                bary_clip(w);
+                const float zp = (float)(1. / (double)(w[0] / f[2] + w[1] / f[5] + w[2] / f[8]));
+                if (zp < near_ || zp > far_) continue; /* drops alpha too (:592) */
+                float *gtex = gT + ((long)bn * nf + fn) * ts * 3;
+                if (func_id_rgb == 0) { /* :595-602 */
+                    if ((float)fn == smax) {
+                        const int tix = texel_index(w, R);
+                        for (int k = 0; k < 3; ++k) gtex[tix * 3 + k] += g[k];
+                    }
+                } else if (front_facing(f) || double_side) { /* :604-628 */
+                    float c_rgb = 0.f;
+                    const float zn = (far_ - zp) / (far_ - near_);
+                    const float p = frag * expf((zn - smax) / gamma_val) / ssum;
+                    const int tix = texel_index(w, R);
+                    for (int k = 0; k < 3; ++k) {
+                        gtex[tix * 3 + k] += p * g[k];
+                        c_rgb += g[k] * (tex[tix * 3 + k] - out_c[k]);
+                    }
+                    c_rgb *= p;
+                    c_xy += c_rgb / frag;
+                    const float c_z = c_rgb / gamma_val / (near_ - far_) * zp * zp;
+                    gv[0][2] = c_z * w[0] / f[2] / f[2];
+                    gv[1][2] = c_z * w[1] / f[5] / f[5];
+                    gv[2][2] = c_z * w[2] / f[8] / f[8];
+                }
+                c_xy *= frag * (1 - frag) / sigma_val; /* :632 */
+                for (int k = 0; k < 3; ++k) {
+                    gv[k][0] = 2 * sign * c_xy * (t[k] + w0[k]) * dx; /* :640 */
+                    gv[k][1] = 2 * sign * c_xy * (t[k] + w0[k]) * dy;
+                }
+                float *gf = gF + ((long)bn * nf + fn) * 9;
+                for (int k = 0; k < 3; ++k)
+                    for (int l = 0; l < 3; ++l) gf[k * 3 + l] += gv[k][l];
+            }
+        }
+    }
+    if (pf) {
+        for (int th = 0; th < n_threads; ++th) {
+            for (size_t i = 0; i < gf_n; ++i) grad_faces[i] += pf[gf_n * th + i];
+            for (size_t i = 0; i < gt_n; ++i) grad_textures[i] += pt[gt_n * th + i];
+        }
+        free(pf);
+        free(pt);
+    }
+    return 0;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

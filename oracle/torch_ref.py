@@ -1,0 +1,350 @@
+"""CPU restatement (torch, fp32) of the reference's Python-level render-and-compare path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/README.md.  Each function cites the reference
+file:line it follows (paths relative to /root/reference).  The rasterizer itself is the C
+oracle (oracle/softras.py); everything around it is restated here with plain torch CPU ops
+so the HIP path can be compared value-for-value and gradient-for-gradient.
+
+torch-version note: the reference pins torch 1.1.0 (requirements.txt:8) where
+``grid_sample`` / ``affine_grid`` behave like today's ``align_corners=True``; every call here
+passes that explicitly.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import softras
+
+
+# --------------------------------------------------------------------------- geometry
+def hamilton_product(qa, qb):
+    """nnutils/geom_utils.py:119-144."""
+    a0, a1, a2, a3 = qa[..., 0], qa[..., 1], qa[..., 2], qa[..., 3]
+    b0, b1, b2, b3 = qb[..., 0], qb[..., 1], qb[..., 2], qb[..., 3]
+    return torch.stack([a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3,
+                        a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                        a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1,
+                        a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0], dim=-1)
+
+
+def quat_rotate(X, q):
+    """nnutils/geom_utils.py:147-165: X' = q (0,X) conj(q), NOT normalising q."""
+    q = q[:, None, :].expand(-1, X.shape[1], -1)
+    q_conj = torch.cat([q[..., :1], -q[..., 1:]], dim=-1)
+    Xq = torch.cat([torch.zeros_like(X[..., :1]), X], dim=-1)
+    return hamilton_product(q, hamilton_product(Xq, q_conj))[..., 1:4]
+
+
+def orthographic_proj_withz(X, cam, offset_z=0.):
+    """nnutils/geom_utils.py:74-91.  cam = [s, tx, ty, qw, qx, qy, qz]."""
+    Xr = quat_rotate(X, cam[:, -4:])
+    proj = cam[:, 0].view(-1, 1, 1) * Xr
+    return torch.cat((proj[..., :2] + cam[:, 1:3].view(-1, 1, 2), proj[..., 2:3] + offset_z), 2)
+
+
+def face_vertices(vertices, faces):
+    """external/SoftRas/soft_renderer/functional/face_vertices.py:4-22."""
+    bs, nv = vertices.shape[:2]
+    idx = faces.long() + (torch.arange(bs) * nv)[:, None, None]
+    return vertices.reshape(bs * nv, 3)[idx]
+
+
+def surface_normals(fv):
+    """external/SoftRas/soft_renderer/mesh.py:111-118."""
+    v10 = fv[:, :, 0] - fv[:, :, 1]
+    v12 = fv[:, :, 2] - fv[:, :, 1]
+    return F.normalize(torch.cross(v12, v10, dim=2), p=2, dim=2, eps=1e-6)
+
+
+def surface_light(fv, intensity_ambient, intensity_directional, direction=(0, 1, 0), color=(1, 1, 1)):
+    """lighting.py:50-57 + functional/ambient_lighting.py:17 + directional_lighting.py:26-27 -> [N,F,3]."""
+    col = torch.tensor(color, dtype=torch.float32)[None, None, :]
+    light = torch.zeros(fv.shape[0], fv.shape[1], 3) + intensity_ambient * col
+    d = torch.tensor(direction, dtype=torch.float32)[None, None, :]
+    cosine = F.relu(torch.sum(surface_normals(fv) * d, dim=2))
+    return light + intensity_directional * (col * cosine[:, :, None])
+
+
+def look_at_ortho(vertices, eye=(0, 0, -2.732), scale=1.0):
+    """transform.py:41-48 -> functional/look_at.py:6-62 (at=0, up=y) + orthogonal.py:4-17."""
+    eye = torch.tensor(eye, dtype=torch.float32)[None, :]
+    at = torch.zeros(1, 3)
+    up = torch.tensor([[0., 1., 0.]])
+    z_axis = F.normalize(at - eye, eps=1e-5)
+    x_axis = F.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = F.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    r = torch.cat((x_axis[:, None], y_axis[:, None], z_axis[:, None]), dim=1)
+    v = torch.matmul(vertices - eye[:, None, :], r.transpose(1, 2))
+    return torch.stack((v[..., 0] * scale, v[..., 1] * scale, v[..., 2]), dim=2)
+
+
+class SoftRenderer(torch.nn.Module):
+    """nnutils/smr.py:49-87 (+ Render :29-44, sr.SoftRenderer renderer.py:48-98, rasterizer.py:42-55)."""
+
+    def __init__(self, img_size=256, render_type='softmax', background_color=(0, 0, 0), sigma_val=1e-5,
+                 gamma_val=1e-4, dist_eps=1e-10, anti_aliasing=True, backend="port", n_threads=1):
+        super().__init__()
+        self.img_size, self.render_type = img_size, render_type
+        self.background_color = list(background_color)
+        self.sigma_val, self.gamma_val, self.dist_eps = sigma_val, gamma_val, dist_eps
+        self.anti_aliasing = anti_aliasing
+        self.intensity_ambient, self.intensity_directional = 0.8, 0.5  # smr.py:63, renderer.py:58-60
+        self.offset_z = 5.
+        self.backend, self.n_threads = backend, n_threads
+
+    def ambient_light_only(self):
+        self.intensity_ambient, self.intensity_directional = 1, 0
+
+    def set_bgcolor(self, color):
+        self.background_color = list(color)
+
+    def project_points(self, verts, cams):
+        return orthographic_proj_withz(verts, cams)[:, :, :2]
+
+    def forward(self, vertices, faces, cams, textures=None):
+        verts = orthographic_proj_withz(vertices, cams, offset_z=self.offset_z)
+        verts = verts * torch.tensor([1., -1., 1.])  # smr.py:36 (in-place on the projected copy)
+        if textures is None:  # mesh.py:46-50
+            textures = torch.ones(verts.shape[0], faces.shape[1], 1, 3)
+        fv = face_vertices(verts, faces)
+        light = surface_light(fv, self.intensity_ambient, self.intensity_directional)
+        textures = textures * light[:, :, None, :]
+        fv = face_vertices(look_at_ortho(verts), faces)
+        size = self.img_size * (2 if self.anti_aliasing else 1)
+        images, p2f, aggr = softras.soft_rasterize(
+            fv, textures, size, self.background_color, 1, 100, True, 1e-3, self.sigma_val, self.dist_eps,
+            self.gamma_val, self.render_type, self.backend, self.n_threads)
+        if self.anti_aliasing:
+            images = F.avg_pool2d(images, kernel_size=2, stride=2)
+        return images, p2f, aggr
+
+
+# --------------------------------------------------------------------------- sampling
+def grid_sample(inp, grid):
+    """torch 1.1.0 F.grid_sample defaults: bilinear, zeros padding, align_corners=True."""
+    return F.grid_sample(inp, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+
+
+def sample_textures(texture_flow, images):
+    """nnutils/geom_utils.py:41-59."""
+    T = texture_flow.size(-2)
+    Fn = texture_flow.size(1)
+    C = images.size(1)
+    samples = grid_sample(images, texture_flow.view(-1, Fn, T * T, 2)).view(-1, C, Fn, T, T)
+    return samples.permute(0, 2, 3, 4, 1)
+
+
+# --------------------------------------------------------------------------- losses
+def neg_iou_loss(predict, target, avg=True):
+    """nnutils/loss_utils.py:41-48."""
+    dims = tuple(range(predict.ndimension())[1:])
+    intersect = (predict * target).sum(dims)
+    union = (predict + target - predict * target).sum(dims) + 1e-6
+    if avg:
+        return 1. - (intersect / union).sum() / intersect.nelement()
+    return 1. - (intersect / union)
+
+
+def texture_dt_loss(texture_flow, dist_transf):
+    """nnutils/loss_utils.py:50-90 (visualisation branch omitted)."""
+    T = texture_flow.size(-2)
+    Fn = texture_flow.size(1)
+    return grid_sample(dist_transf, texture_flow.view(-1, Fn, T * T, 2)).mean()
+
+
+def texture_loss_masks(img_pred, img_gt, mask_gt, mask_pred, avg=True):
+    """nnutils/loss_utils.py:103-116."""
+    mask_gt, mask_pred = mask_gt.unsqueeze(1), mask_pred.unsqueeze(1)
+    if avg:
+        return torch.nn.L1Loss()(img_pred * mask_pred, img_gt * mask_gt)
+    loss = torch.nn.L1Loss(reduction='none')(img_pred * mask_pred, img_gt * mask_gt)
+    return torch.sum(loss, dim=(1, 2, 3)) / (loss.size(1) * loss.size(2) * loss.size(3))
+
+
+def deform_l2reg(V):
+    """nnutils/loss_utils.py:118-123."""
+    return torch.mean(torch.norm(V.view(-1, V.size(2)), p=2, dim=1))
+
+
+def sym_reg(verts):
+    """nnutils/loss_utils.py:125-126."""
+    return torch.mean(torch.abs(verts[:, :, 1]))
+
+
+def tex_cycle(flow, prob, aggr_info):
+    """nnutils/loss_utils.py:152-182.  aggr_info [nb, IS*IS] face ids (float, -1 = background,
+    which python indexing maps to the LAST face -- kept, it is the reference's behaviour)."""
+    nb, nf = flow.shape[:2]
+    avg_flow = torch.mean(flow.view(nb, nf, -1, 2), dim=2)
+    mask = torch.zeros(avg_flow.size())
+    for cnt in range(nb):
+        fids = torch.unique(aggr_info[cnt]).long()
+        mask[cnt, fids, :] = 1
+    return torch.nn.MSELoss()(avg_flow * mask, prob * mask), avg_flow[0, 0:10, :]
+
+
+def dist_chamfer(a, b):
+    """nnutils/chamfer_python.py:43-64."""
+    x, y = a, b
+    bs, nx, _ = x.size()
+    ny = y.size(1)
+    xx = torch.pow(x, 2).sum(2)
+    yy = torch.pow(y, 2).sum(2)
+    zz = torch.bmm(x, y.transpose(2, 1))
+    rx = xx.unsqueeze(1).expand(bs, ny, nx)
+    ry = yy.unsqueeze(1).expand(bs, nx, ny)
+    P = rx.transpose(2, 1) + ry - 2 * zz
+    return torch.min(P, 2)[0], torch.min(P, 1)[0], torch.min(P, 2)[1].int(), torch.min(P, 1)[1].int()
+
+
+def multi_mask_loss(renderer, vs, fs, cams_all_hypo, cam_probs, masks_gt, num_hypo_cams, image_size):
+    """nnutils/loss_utils.py:257-275."""
+    bs = vs.size(0)
+    pred_vs = vs.unsqueeze(1).repeat(1, num_hypo_cams, 1, 1).view(-1, vs.size(1), 3)
+    faces = fs.unsqueeze(1).repeat(1, num_hypo_cams, 1, 1).view(-1, fs.size(1), 3)
+    pred, _, _ = renderer.forward(pred_vs, faces, cams_all_hypo.view(-1, 7))
+    mask_all_hypo = pred[:, 3, :, :]
+    masks = masks_gt.unsqueeze(1).repeat(1, num_hypo_cams, 1, 1).view(-1, image_size, image_size)
+    loss = neg_iou_loss(mask_all_hypo, masks, avg=False)
+    loss = (loss.view(bs, -1) * cam_probs).sum(dim=1)
+    return loss.mean(), mask_all_hypo
+
+
+def corr_loss_chamfer(part_vertex_ids, part_points, verts, cams, weights=(1, 1, 0, 0)):
+    """nnutils/loss_utils.py:223-248.  part_vertex_ids: 4 LongTensors (head, belly, neck, back);
+    part_points: 4 tensors [B, n_i, 2] in the order the forward signature names them."""
+    coords = torch.cat([verts[:, ids, :] for ids in part_vertex_ids], dim=1)
+    vert2d = orthographic_proj_withz(coords, cams)[:, :, :2]
+    nums = np.cumsum([0] + [len(i) for i in part_vertex_ids])
+    cds = []
+    for i in range(4):
+        d1, _, _, _ = dist_chamfer(vert2d[:, nums[i]:nums[i + 1], :], part_points[i])
+        cds.append(d1 * weights[i])
+    loss = torch.mean(torch.cat(cds, dim=1), dim=1)
+    return torch.mean(loss), vert2d
+
+
+class LaplacianLoss(torch.nn.Module):
+    """external/SoftRas/soft_renderer/losses.py:6-37."""
+
+    def __init__(self, vertex, faces, average=False):
+        super().__init__()
+        nv = vertex.size(0)
+        faces = faces.detach().cpu().numpy()
+        lap = np.zeros([nv, nv]).astype(np.float32)
+        for a, b in ((0, 1), (1, 0), (1, 2), (2, 1), (2, 0), (0, 2)):
+            lap[faces[:, a], faces[:, b]] = -1
+        r, c = np.diag_indices(nv)
+        lap[r, c] = -lap.sum(1)
+        for i in range(nv):
+            lap[i, :] /= lap[i, i]
+        self.register_buffer('laplacian', torch.from_numpy(lap))
+        self.average = average
+
+    def forward(self, x):
+        bs = x.size(0)
+        x = torch.matmul(self.laplacian, x)
+        x = x.pow(2).sum(tuple(range(x.ndimension())[1:]))
+        return x.sum() / bs if self.average else x
+
+
+def flatten_edge_quads(faces):
+    """losses.py:44-70: unique edges (v0<v1, python-set order replaced by sorted order -- the loss is
+    a sum over edges so order only changes float summation order) and the two opposite vertices,
+    first and second in FACE order."""
+    faces = np.asarray(faces)
+    edges = sorted(set(tuple(v) for v in np.sort(np.concatenate((faces[:, 0:2], faces[:, 1:3]), axis=0))))
+    # NOTE (reference quirk, losses.py:45): only edges (f0,f1) and (f1,f2) of each face are collected, not
+    # (f2,f0); on a closed manifold every edge still appears because the neighbour lists it.
+    v0s = np.array([e[0] for e in edges], 'int64')
+    v1s = np.array([e[1] for e in edges], 'int64')
+    v2s, v3s = [], []
+    for v0, v1 in zip(v0s, v1s):
+        count = 0
+        for face in faces:
+            if v0 in face and v1 in face:
+                v = face[(face != v0) & (face != v1)]
+                if count == 0:
+                    v2s.append(int(v[0]))
+                    count += 1
+                else:
+                    v3s.append(int(v[0]))
+    return v0s, v1s, np.array(v2s, 'int64'), np.array(v3s, 'int64')
+
+
+class FlattenLoss(torch.nn.Module):
+    """external/SoftRas/soft_renderer/losses.py:39-114."""
+
+    def __init__(self, faces, average=False):
+        super().__init__()
+        v0s, v1s, v2s, v3s = flatten_edge_quads(faces.detach().cpu().numpy())
+        for n, v in (('v0s', v0s), ('v1s', v1s), ('v2s', v2s), ('v3s', v3s)):
+            self.register_buffer(n, torch.from_numpy(v).long())
+        self.average = average
+
+    def forward(self, vertices, eps=1e-6):
+        bs = vertices.size(0)
+        v0s, v1s = vertices[:, self.v0s, :], vertices[:, self.v1s, :]
+        v2s, v3s = vertices[:, self.v2s, :], vertices[:, self.v3s, :]
+
+        def half(b):
+            a = v1s - v0s
+            al2, bl2 = a.pow(2).sum(-1), b.pow(2).sum(-1)
+            al1, bl1 = (al2 + eps).sqrt(), (bl2 + eps).sqrt()
+            ab = (a * b).sum(-1)
+            cos = ab / (al1 * bl1 + eps)
+            sin = (1 - cos.pow(2) + eps).sqrt()
+            c = a * (ab / (al2 + eps))[:, :, None]
+            return b - c, bl1 * sin
+
+        cb1, cb1l1 = half(v2s - v0s)
+        cb2, cb2l1 = half(v3s - v0s)
+        cos = (cb1 * cb2).sum(-1) / (cb1l1 * cb2l1 + eps)
+        loss = (cos + 1).pow(2).sum(tuple(range(cos.ndimension())[1:]))
+        return loss.sum() / bs if self.average else loss
+
+
+def batch_get_centers(pred_softmax, epsilon=1e-3):
+    """nnutils/scops_utils.py:12-54 (self_referenced=False): soft centroid of each part map."""
+    B, C, H, W = pred_softmax.shape
+    # get_coordinate_tensors(h, w) is called as (x_max=h, y_max=w) (:23): x over columns / x_max
+    x_map = torch.from_numpy((np.tile(np.arange(H), (W, 1)) / H * 2 - 1.0).astype(np.float32))
+    y_map = torch.from_numpy((np.tile(np.arange(W), (H, 1)).T / W * 2 - 1.0).astype(np.float32))
+    out = []
+    for b in range(B):
+        cs = []
+        for c in range(C):
+            pm = pred_softmax[b, c] + epsilon
+            pdf = pm / pm.sum()
+            cs.append(torch.stack(((pdf * x_map).sum(), (pdf * y_map).sum()), dim=0).unsqueeze(0))
+        out.append(torch.cat(cs, dim=0).unsqueeze(0))
+    return torch.cat(out, dim=0)
+
+
+def part_matching_core(proj_rgb_means, part_segs, weights=(0, 5.0, 0.0, 0.0, 5.0)):
+    """nnutils/loss_utils.py:399-440 with avg=True, loss_type='mse': everything after the 4 renders.
+    proj_rgb_means: list of 4 tensors [B,1,H,W] (mean over rgb of each part render)."""
+    bs = part_segs.size(0)
+    bg = torch.full_like(proj_rgb_means[0], 0.1)
+    proj = torch.cat([bg] + list(proj_rgb_means), dim=1)
+    centers_proj = batch_get_centers(torch.softmax(proj, dim=1)[:, 1:])
+    centers_parts = batch_get_centers(torch.softmax(part_segs, dim=1)[:, 1:])
+    loss_lmeqv = F.mse_loss(centers_proj, centers_parts)
+    max_proj, _ = torch.max(proj.view(bs, 5, -1), dim=2)
+    max_proj = max_proj.clamp_min(1e-5)
+    max_part, _ = torch.max(part_segs.view(bs, 5, -1), dim=2)
+    max_part = max_part.clamp_min(1e-5)
+    w = torch.tensor(weights).view(1, 5, 1, 1)
+    loss_eqv = torch.mean((proj / max_proj.view(bs, 5, 1, 1) - part_segs / max_part.view(bs, 5, 1, 1)).pow(2) * w)
+    return (loss_eqv + loss_lmeqv) / 4.0
+
+
+def cos_sim_distance(feats0, feats1, eps=1e-10):
+    """external/PerceptualSimilarity/models/networks_basic.py:42-64 + util/util.py:71-83 (PNet head):
+    sum over layers of mean_xy(1 - cos(f0, f1)); features normalised over channels."""
+    val = 0
+    for f0, f1 in zip(feats0, feats1):
+        n0 = f0 / (torch.sqrt(torch.sum(f0 ** 2, dim=1, keepdim=True)) + eps)
+        n1 = f1 / (torch.sqrt(torch.sum(f1 ** 2, dim=1, keepdim=True)) + eps)
+        val = val + (1. - torch.mean(torch.mean(torch.sum(n0 * n1, dim=1), dim=1), dim=1))
+    return val

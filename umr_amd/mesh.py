@@ -1,0 +1,53 @@
+"""Host-side template mesh construction (init-time, numpy).
+
+Mirrors what the reference gets from ``utils/mesh.py:37-41`` (``create_sphere`` ->
+``meshzoo.iso_sphere``; meshzoo 0.4.3 is an un-vendored dependency, so the vertex/face
+ORDER is parity-unpinned -- only the counts are pinned by the reference:
+subdivide 3 -> 642 verts / 1280 faces, 4 -> 2562 / 5120, utils/mesh.py:38-39).
+"""
+import numpy as np
+
+
+def create_sphere(n_subdivide=3):
+    """Unit icosphere: returns (verts [V,3] float64, faces [F,3] int64).
+
+    The base icosahedron uses the (0, +-1, +-phi) cyclic-permutation coordinates, which are
+    mirror symmetric in every coordinate plane, so subdivided vertices come in exact
+    bit-identical +-pairs (needed by the symmetric re-ordering, utils/mesh.py:44-100).
+    """
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0),
+             (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+             (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11),
+             (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9),
+             (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    verts = [np.asarray(v, dtype=np.float64) for v in verts]
+    for _ in range(n_subdivide):
+        cache = {}
+        new_faces = []
+
+        def mid(a, b):
+            key = (a, b) if a < b else (b, a)
+            if key not in cache:
+                # symmetric in (a, b): a+b is commutative in IEEE arithmetic
+                cache[key] = len(verts)
+                verts.append((verts[key[0]] + verts[key[1]]) * 0.5)
+            return cache[key]
+
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            new_faces += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = new_faces
+    v = np.stack(verts)
+    # normalise with a sign-symmetric formula so mirrored vertices stay bit-identical
+    v = v / np.sqrt((v * v).sum(1, keepdims=True))
+    return v, np.asarray(faces, dtype=np.int64)
+
+
+def unique_edges(faces):
+    """Sorted unique undirected edges [E,2] of a triangle mesh."""
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 0)
+    e = np.sort(e, axis=1)
+    return np.unique(e, axis=0)
