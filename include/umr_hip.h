@@ -1,0 +1,188 @@
+/*
+ * umr_hip.h -- C ABI of libumr_hip.so: the MI355X (gfx950) render-and-compare hot path of UMR.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one interface of
+ * the reference (cited per function, paths relative to the reference tree) and is what a maintainer
+ * binds from Python (ctypes) in place of the reference's pybind/CUDA module or
+ * torch op chain.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; fp32 data, int32 indices; every tensor dense, row-major
+ *   - the CALLER owns and pre-allocates every buffer (as the reference binding does,
+ *     functional/soft_rasterize.py:47-55,95-97); nothing is allocated or freed inside
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *     no host synchronisation inside; re-entrant; callable from several host threads
+ *   - return value: 0 = enqueued; UMR_ERR_ARG = rejected arguments / unsupported mode (nothing
+ *     enqueued); UMR_ERR_LAUNCH = hipGetLastError() reported a launch failure (the reference only
+ *     printf()s those, soft_rasterize_cuda_kernel.cu:700-702)
+ *   - scratch memory is passed in by the caller: size from the matching *_workspace_bytes()
+ */
+#ifndef UMR_HIP_H
+#define UMR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMR_OK 0
+#define UMR_ERR_ARG (-1)
+#define UMR_ERR_LAUNCH (-2)
+
+/* library / build identification: returns e.g. "umr_hip 0.1 gfx950" */
+const char *umr_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Soft rasterizer.  Replaces the pybind module soft_renderer.cuda.soft_rasterize
+ *   forward_soft_rasterize   external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda.cpp:62-97
+ *   backward_soft_rasterize  external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda.cpp:100-138
+ * (kernels soft_rasterize_cuda_kernel.cu:223-656).  Same buffers, same scalars, same in-place
+ * contract: soft_colors arrives filled with (background rgb, 1), every other output zero-filled.
+ *
+ *   faces        [N,F,9]   screen-space face vertices (x0,y0,z0,x1,...)          in
+ *   textures     [N,F,TS,3]                                                     in
+ *   faces_info   [N,F,27]  inv(9) sym(9) obt(3) unused(6)                        out (fwd) / unused (bwd)
+ *   aggrs_info   [N,2,IS,IS] softmax: (sum, max); hard: (depth_min, face id|-1)  out (fwd) / in (bwd)
+ *   grid         [IS,IS,2] pixel -> normalised coordinate map (p2f weights)      in  (softmax only)
+ *   p2f_info     [N,F,2], p2f_sum [N,F,2]  raw accumulators (un-normalised)      out (softmax only)
+ *   soft_colors  [N,4,IS,IS]                                                     in/out
+ *   pooled_out   [N,4,IS/2,IS/2] or NULL: fused 2x2 average pool of soft_colors
+ *                (anti-aliasing, rasterizer.py:52-53); requires even IS            out, optional
+ *
+ * Supported modes (the ones nnutils/smr.py:53-66 instantiates): func_id_dist=2 (euclidean),
+ * func_id_alpha=2 (prod), texture_sample_type=0 (surface), func_id_rgb in {0 hard, 1 softmax};
+ * TS must be a perfect square.  Anything else returns UMR_ERR_ARG.
+ * dist_eps is the value the reference binding receives: log(1/eps_dist - 1).
+ *
+ * flags: bit 0 (UMR_RASTER_NO_P2F) skips the p2f_info/p2f_sum accumulation (callers that discard
+ * them, e.g. MultiMaskLoss, nnutils/loss_utils.py:265).
+ * -------------------------------------------------------------------------------------------*/
+#define UMR_RASTER_NO_P2F 1
+
+size_t umr_raster_workspace_bytes(int N, int F);
+
+int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
+                       const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,
+                       float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
+                       float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                       int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                       int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/*   grad_faces    [N,F,9], grad_textures [N,F,TS,3]   zero-filled by the caller; contributions are ADDED
+ *   grad_soft_colors [N,4,IS,IS], or -- when grad_is_pooled != 0 -- the gradient of the 2x2-pooled
+ *                 image [N,4,IS/2,IS/2] (the avg_pool2d backward is fused: each pixel sees g/4)
+ *   need_grad_faces / need_grad_textures: 0 skips that output (pointer may then be NULL); the
+ *                 reference always computes both (functional/soft_rasterize.py:95-106). */
+int umr_raster_backward(const float *faces, const float *textures, const float *soft_colors,
+                        const float *faces_info, const float *aggrs_info, float *grad_faces,
+                        float *grad_textures, const float *grad_soft_colors, int grad_is_pooled,
+                        int need_grad_faces, int need_grad_textures, int N, int F, int TS, int image_size,
+                        float near_, float far_, float eps, float sigma_val, int func_id_dist,
+                        float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                        int texture_sample_type, int double_side, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Camera projection + face gather.  Replaces the torch op chain of one SoftRenderer.forward:
+ *   nnutils/geom_utils.py:74-91,119-165  orthographic_proj_withz / quat_rotate / hamilton_product
+ *   nnutils/smr.py:36                    y flip
+ *   external/SoftRas/soft_renderer/functional/face_vertices.py:4-22   gather
+ *   external/SoftRas/soft_renderer/functional/look_at.py:48-60 + orthogonal.py:13-16
+ *                                        (eye (0,0,eye_z), at 0, up y => z -= eye_z; scale 1)
+ *   verts [N,V,3], cams [N,7] = (s, tx, ty, qw, qx, qy, qz), faces_idx [N,F,3] int32
+ *   face_pre  [N,F,9] or NULL: projected + flipped, BEFORE look_at (what Lighting sees, mesh.py:111-118)
+ *   face_out  [N,F,9]: after look_at/orthogonal -- the rasterizer's `faces`
+ * -------------------------------------------------------------------------------------------*/
+int umr_project_faces_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
+                              float *face_out, int N, int V, int F, float offset_z, float eye_z,
+                              void *stream);
+
+/* backward: grad_face_out [N,F,9] (and optional grad_face_pre, may be NULL) ->
+ *   grad_verts [N,V,3] (ADDED into; caller zero-fills) and grad_cams [N,7] (overwritten).
+ *   workspace: umr_project_workspace_bytes(N, V) bytes. */
+size_t umr_project_workspace_bytes(int N, int V);
+int umr_project_faces_backward(const float *grad_face_out, const float *grad_face_pre, const float *verts,
+                               const float *cams, const int *faces_idx, float *grad_verts, float *grad_cams,
+                               int N, int V, int F, void *workspace, size_t workspace_bytes, void *stream);
+
+/* vertices only, no flip, no look_at:
+ *   out_dim 2: SoftRenderer.project_points / orthographic_proj (nnutils/smr.py:76-78, geom_utils.py:60-72)
+ *              out [N,V,2] = (s R(q) X)[:2] + t
+ *   out_dim 3: orthographic_proj_withz (geom_utils.py:74-91): out [N,V,3], z = s (R X)_z + offset_z
+ * backward: grad_verts [N,V,3] ADDED into (may be NULL), grad_cams [N,7] overwritten. */
+int umr_project_points_forward(const float *verts, const float *cams, float *out, int N, int V, int out_dim,
+                               float offset_z, void *stream);
+int umr_project_points_backward(const float *grad_out, const float *verts, const float *cams, float *grad_verts,
+                                float *grad_cams, int N, int V, int out_dim, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Silhouette IoU.  Replaces nnutils/loss_utils.py:41-48 (neg_iou_loss, avg=False form):
+ *   loss[n] = 1 - sum(p*t) / (sum(p + t - p*t) + 1e-6)      predict/target [N,P], loss [N]
+ * predict may be a strided channel view: element (n,i) at predict[n*predict_stride + i].
+ * backward: grad_predict (same striding, ADDED into) = grad_loss[n] * d loss[n] / d p.
+ * sums [N,2] = (intersect, union+1e-6) is written by forward and read by backward.
+ * -------------------------------------------------------------------------------------------*/
+int umr_neg_iou_forward(const float *predict, long predict_stride, const float *target, float *loss,
+                        float *sums, int N, long P, void *stream);
+int umr_neg_iou_backward(const float *predict, long predict_stride, const float *target, const float *sums,
+                         const float *grad_loss, float *grad_predict, long grad_stride, int N, long P,
+                         void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chamfer distance.  Replaces nnutils/chamfer_python.py:43-64 (distChamfer) without the [B,n,m]
+ * matrix:  P_ij = |a_i|^2 + |b_j|^2 - 2 a_i.b_j  (same expansion as the reference, so values agree
+ * to rounding); dist1[i] = min_j, dist2[j] = min_i, idx int32, first index wins ties.
+ *   a [B,n,D], b [B,m,D], D in {2,3}
+ * backward: grad_a, grad_b overwritten with the gradient of (g1 . dist1 + g2 . dist2).
+ * -------------------------------------------------------------------------------------------*/
+int umr_chamfer_forward(const float *a, const float *b, float *dist1, float *dist2, int *idx1, int *idx2,
+                        int B, int n, int m, int D, void *stream);
+int umr_chamfer_backward(const float *a, const float *b, const int *idx1, const int *idx2, const float *g1,
+                         const float *g2, float *grad_a, float *grad_b, int B, int n, int m, int D,
+                         void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Texture sampling.  Replaces F.grid_sample as called by nnutils/geom_utils.py:41-59
+ * (sample_textures) and nnutils/loss_utils.py:60-64 (texture_dt_loss): bilinear, zero padding,
+ * torch-1.1.0 coordinate convention (= align_corners=True).
+ *   image [B,C,H,W], grid [B,P,2] (x,y in [-1,1]) -> out [B,P,C]  (channel-LAST: the layout
+ *   sample_textures permutes to, geom_utils.py:59)
+ * backward: grad_out [B,P,C] -> grad_grid [B,P,2] (overwritten, may be NULL),
+ *           grad_image [B,C,H,W] (ADDED into, may be NULL)
+ * -------------------------------------------------------------------------------------------*/
+int umr_grid_sample_forward(const float *image, const float *grid, float *out, int B, int C, int H, int W,
+                            long P, void *stream);
+int umr_grid_sample_backward(const float *image, const float *grid, const float *grad_out, float *grad_grid,
+                             float *grad_image, int B, int C, int H, int W, long P, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mesh regularisers.  Replace external/SoftRas/soft_renderer/losses.py
+ *   LaplacianLoss.forward :29-37 -- sum_v |x_v - mean_{u in nbr(v)} x_u|^2 per mesh, from a CSR
+ *     neighbour list instead of the dense row-normalised [V,V] matrix (identical rows: the
+ *     reference's matrix has 1 on the diagonal and -1/deg on neighbours)
+ *   FlattenLoss.forward :72-114   -- sum_edges (cos_dihedral + 1)^2, eps = 1e-6 guards kept
+ *   x [B,V,3]; nbr_off [V+1], nbr_idx [nnz] int32;  quads [E,4] int32 = (v0,v1,v2,v3)
+ *   loss [B]; backward ADDS grad_loss[b] * dloss/dx into grad_x [B,V,3].
+ * -------------------------------------------------------------------------------------------*/
+int umr_laplacian_forward(const float *x, const int *nbr_off, const int *nbr_idx, float *lap, float *loss,
+                          int B, int V, void *stream);
+int umr_laplacian_backward(const float *lap, const int *nbr_off, const int *nbr_idx, const float *grad_loss,
+                           float *grad_x, int B, int V, void *stream);
+int umr_flatten_forward(const float *x, const int *quads, float *loss, int B, int V, int E, void *stream);
+int umr_flatten_backward(const float *x, const int *quads, const float *grad_loss, float *grad_x, int B, int V,
+                         int E, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Texture-cycle visibility mask.  Replaces the per-sample torch.unique + CPU mask + H2D loop of
+ * nnutils/loss_utils.py:173-179 (TexCycle.forward):
+ *   face_ids [B,P] float (hard renderer's aggrs_info[:,1], -1 = background) -> mask [B,F] (0/1)
+ *   id -1 marks the LAST face (python negative indexing -- reference behaviour, kept).
+ *   mask must arrive zero-filled.
+ * -------------------------------------------------------------------------------------------*/
+int umr_visible_face_mask(const float *face_ids, float *mask, int B, long P, int F, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMR_HIP_H */

@@ -1,0 +1,38 @@
+"""Shared test helpers: seeded synthetic scenes and tolerant comparisons."""
+import numpy as np
+import torch
+
+from umr_amd.mesh import create_sphere
+
+
+def scene(n_meshes, subdiv, seed, scale=(0.6, 0.9)):
+    """Perturbed icosphere + random cameras.  Must stay identical to oracle/gen_golden.py:scene()."""
+    g = torch.Generator().manual_seed(seed)
+    v, f = create_sphere(subdiv)
+    verts = torch.from_numpy(v).float()[None].repeat(n_meshes, 1, 1)
+    verts = verts + 0.05 * torch.randn(verts.shape, generator=g)
+    faces = torch.from_numpy(f).long()[None].repeat(n_meshes, 1, 1)
+    s = scale[0] + (scale[1] - scale[0]) * torch.rand(n_meshes, 1, generator=g)
+    t = -0.1 + 0.2 * torch.rand(n_meshes, 2, generator=g)
+    q = torch.randn(n_meshes, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    return verts, faces, torch.cat([s, t, q], 1), g
+
+
+def assert_close_frac(got, ref, atol, rtol=0.0, frac=0.999, max_outlier=None, name=""):
+    """>= `frac` of the elements within atol + rtol*|ref|; the rest (isolated branch flips: texel index,
+    closest-edge selection, threshold rejects flip on 1-ulp differences) bounded by `max_outlier`."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.isfinite(got).all(), name + ": non-finite values"
+    err = np.abs(got - ref)
+    ok = err <= atol + rtol * np.abs(ref)
+    f = ok.mean() if ok.size else 1.0
+    assert f >= frac, "%s: only %.5f within tol (max err %.3e, atol %.1e rtol %.1e)" % (name, f, err.max(), atol, rtol)
+    if max_outlier is not None and err.size:
+        assert err.max() <= max_outlier, "%s: outlier %.3e > %.3e" % (name, err.max(), max_outlier)
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()

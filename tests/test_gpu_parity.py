@@ -1,0 +1,293 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against (a) golden vectors produced by the reference itself and (b) the CPU oracle on seeded inputs.
+
+Tolerance: north_star asks for renders within 1e-4 of the reference; written out at every check.
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import scene, assert_close_frac, t2n
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RASTER = ["raster_softmax_ts36.npz", "raster_softmax_ts1.npz", "raster_hard_ts1.npz", "raster_hard_ts4.npz"]
+
+
+def _raw_raster(g, flags=0, pooled=False):
+    """Call umr_raster_forward / umr_raster_backward directly (innermost drop-in level)."""
+    from umr_amd import _lib
+    from umr_amd.functional import standard_grid
+    L = _lib.lib()
+    p = _lib.ptr
+    faces = torch.from_numpy(g["faces"]).to(DEV)
+    tex = torch.from_numpy(g["textures"]).to(DEV)
+    N, F = faces.shape[:2]
+    TS = tex.shape[2]
+    IS = int(g["image_size"])
+    faces_info = torch.zeros(N, F, 27, device=DEV)
+    aggrs = torch.zeros(N, 2, IS, IS, device=DEV)
+    p2f_info = torch.zeros(N, F, 2, device=DEV)
+    p2f_sum = torch.zeros(N, F, 2, device=DEV)
+    sc = torch.ones(N, 4, IS, IS, device=DEV)
+    for k in range(3):
+        sc[:, k] *= float(g["background"][k])
+    pool = torch.empty(N, 4, IS // 2, IS // 2, device=DEV) if pooled else None
+    grid = standard_grid(IS, torch.device(DEV))
+    wsb = L.umr_raster_workspace_bytes(N, F)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    scal = (float(g["near"]), float(g["far"]), float(g["eps"]), float(g["sigma_val"]), 2, float(g["dist_eps_log"]),
+            float(g["gamma_val"]), int(g["func_id_rgb"]), 2, 0, int(bool(g["double_side"])))
+    st = _lib.stream_ptr(torch.device(DEV))
+    rc = L.umr_raster_forward(p(faces), p(tex), p(faces_info), p(aggrs), p(grid), p(p2f_info), p(p2f_sum), p(sc),
+                              p(pool), N, F, TS, IS, *scal, flags, p(ws), wsb, st)
+    assert rc == 0
+    gsc = torch.from_numpy(g["grad_soft_colors"]).to(DEV)
+    gf = torch.zeros(N, F, 9, device=DEV)
+    gt = torch.zeros_like(tex)
+    rc = L.umr_raster_backward(p(faces), p(tex), p(sc), p(faces_info), p(aggrs), p(gf), p(gt), p(gsc), 0, 1, 1, N, F,
+                               TS, IS, *scal, p(ws), wsb, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return dict(faces_info=faces_info, aggrs_info=aggrs, p2f_info=p2f_info, p2f_sum=p2f_sum, soft_colors=sc,
+                pooled=pool, grad_faces=gf, grad_textures=gt)
+
+
+@pytest.mark.parametrize("name", RASTER)
+def test_raster_cabi_vs_reference_golden(name):
+    g = load_golden(name)
+    o = _raw_raster(g)
+    # preprocessing is pure fp32 IEEE arithmetic in the reference's order -> bit exact
+    np.testing.assert_array_equal(t2n(o["faces_info"]), g["faces_info"])
+    # 1e-4 = north_star render tolerance
+    assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=0.999, max_outlier=0.6, name="soft_colors")
+    if int(g["func_id_rgb"]) == 1:
+        assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=1e-3, frac=0.999, name="aggrs")
+        scale = np.abs(g["p2f_sum"]).max()
+        assert_close_frac(t2n(o["p2f_sum"]), g["p2f_sum"], atol=1e-4 * scale, rtol=1e-3, frac=0.995, name="p2f_sum")
+        assert_close_frac(t2n(o["p2f_info"]), g["p2f_info"], atol=1e-4 * scale, rtol=1e-3, frac=0.995, name="p2f_info")
+    else:
+        ids_ok = (t2n(o["aggrs_info"])[:, 1] == g["aggrs_info"][:, 1]).mean()
+        assert ids_ok >= 0.999, ids_ok   # face-id plane: integer work, bit exact up to isolated depth ties
+        assert_close_frac(t2n(o["aggrs_info"])[:, 0], g["aggrs_info"][:, 0], atol=0, rtol=1e-5, frac=0.999, name="depth")
+    sf = np.abs(g["grad_faces"]).max()
+    assert_close_frac(t2n(o["grad_faces"]), g["grad_faces"], atol=1e-4 * sf, rtol=2e-3, frac=0.99, name="grad_faces")
+    st = max(np.abs(g["grad_textures"]).max(), 1e-12)
+    assert_close_frac(t2n(o["grad_textures"]), g["grad_textures"], atol=1e-4 * st, rtol=2e-3, frac=0.99, name="grad_textures")
+
+
+def test_raster_flags_and_fused_pool():
+    g = load_golden("raster_softmax_ts36.npz")
+    a = _raw_raster(g)
+    b = _raw_raster(g, flags=1)          # UMR_RASTER_NO_P2F
+    assert torch.equal(a["soft_colors"], b["soft_colors"])
+    assert float(b["p2f_sum"].abs().sum()) == 0.0
+    c = _raw_raster(g, pooled=True)
+    ref = torch.nn.functional.avg_pool2d(c["soft_colors"], 2, 2)
+    assert float((c["pooled"] - ref).abs().max()) <= 1e-6
+
+
+def test_raster_rejects_unsupported_modes():
+    from umr_amd import _lib
+    L = _lib.lib()
+    t = torch.zeros(64, device=DEV)
+    wsb = L.umr_raster_workspace_bytes(1, 1)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    p = _lib.ptr
+    base = [p(t), p(t), p(t), p(t), p(t), p(t), p(t), p(t), None, 1, 1, 1, 2, 1., 100., 1e-3, 1e-5]
+    tail = [1e-4, 1, 2, 0, 1, 0, p(ws), wsb, None]
+    assert L.umr_raster_forward(*base, 1, 23.0, *tail) == -1          # barycentric distance: unsupported
+    assert L.umr_raster_forward(*base, 2, 23.0, 1e-4, 1, 1, 0, 1, 0, p(ws), wsb, None) == -1  # alpha 'sum'
+    assert L.umr_raster_forward(*base[:9], 1, 1, 2, 2, 1., 100., 1e-3, 1e-5, 2, 23.0, *tail) == -1  # TS not square
+
+
+@pytest.mark.parametrize("name", ["smr_mask_default_light.npz", "smr_tex_ambient.npz", "smr_tex_default_light.npz",
+                                  "smr_hard_default_light.npz"])
+def test_smr_softrenderer_vs_reference_golden(name):
+    from umr_amd.smr import SoftRenderer
+    g = load_golden(name)
+    verts = torch.from_numpy(g["verts"]).to(DEV).requires_grad_(True)
+    cams = torch.from_numpy(g["cams"]).to(DEV).requires_grad_(True)
+    faces = torch.from_numpy(g["faces"]).to(DEV)
+    tex = torch.from_numpy(g["textures"]).to(DEV).requires_grad_(True) if "textures" in g else None
+    r = SoftRenderer(int(g["img_size"]), str(g["render_type"]))
+    if bool(g["ambient_only"]):
+        r.ambient_light_only()
+    imgs, p2f, aggr = r.forward(verts, faces, cams, tex)
+    assert imgs.shape == g["imgs"].shape and aggr.shape == g["aggr"].shape
+    assert_close_frac(t2n(imgs), g["imgs"], atol=1e-4, frac=0.999, max_outlier=0.3, name="imgs")   # 1e-4: north_star
+    assert_close_frac(t2n(p2f), g["p2f"], atol=2e-3, rtol=1e-3, frac=0.99, name="p2f")
+    np.testing.assert_allclose(t2n(r.project_points(verts, cams)), g["proj_points"], atol=2e-6)
+    imgs.backward(torch.from_numpy(g["grad_imgs"]).to(DEV))
+    for got, key in ((verts.grad, "grad_verts"), (cams.grad, "grad_cams")):
+        s = max(np.abs(g[key]).max(), 1e-12)
+        assert_close_frac(t2n(got), g[key], atol=2e-4 * s, rtol=5e-3, frac=0.98, name=key)
+    if tex is not None:
+        s = np.abs(g["grad_textures"]).max()
+        assert_close_frac(t2n(tex.grad), g["grad_textures"], atol=1e-4 * s, rtol=2e-3, frac=0.99, name="grad_textures")
+
+
+@pytest.mark.parametrize("ts,rgb", [(36, "softmax"), (1, "softmax"), (1, "hard")])
+def test_full_size_vs_oracle(oracle_built, ts, rgb):
+    """BASELINE config size: 642-vert / 1280-face mesh at IS=512, against the C oracle on the host cores."""
+    from oracle import softras
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(2, 3, seed=5)
+    from oracle import torch_ref
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).contiguous()
+    tex = torch.rand(2, 1280, ts, 3, generator=gen)
+    gsc = torch.randn(2, 4, 512, 512, generator=gen)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4,
+               func_id_rgb={"hard": 0, "softmax": 1}[rgb], double_side=True)
+    nt = softras.max_threads()
+    o = softras.raster_forward(fv.numpy(), tex.numpy(), 512, backend="port", n_threads=nt, **cfg)
+    gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                     gsc.numpy(), 512, backend="port", n_threads=nt, **cfg)
+    fvd = fv.to(DEV).requires_grad_(True)
+    texd = tex.to(DEV).requires_grad_(True)
+    sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 512, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4,
+                                      rgb, 'prod', 'surface')
+    sc.backward(gsc.to(DEV))
+    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.999, max_outlier=1.0, name="soft_colors")  # north_star 1e-4
+    if rgb == "softmax":
+        p2f_ref = o["p2f_info"] / np.maximum(o["p2f_sum"], 1e-12)
+        assert_close_frac(t2n(p2f), p2f_ref, atol=2e-3, frac=0.99, name="p2f")
+    else:
+        assert (t2n(aggr)[:, 1] == o["aggrs_info"][:, 1]).mean() >= 0.9995
+    sf = np.abs(gf).max()
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * sf, rtol=5e-3, frac=0.99, name="grad_faces")
+    st = max(np.abs(gt).max(), 1e-12)
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * st, rtol=5e-3, frac=0.99, name="grad_textures")
+
+
+def test_backward_is_linear_in_upstream_gradient():
+    """Size-independent property at full size: the analytic backward is linear in grad_soft_colors."""
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(2, 3, seed=9)
+    from umr_amd.functional import ProjectFacesFunction
+    _, fv = ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    tex = torch.rand(2, 1280, 36, 3, generator=gen).to(DEV)
+    g1 = torch.randn(2, 4, 512, 512, generator=gen).to(DEV)
+    g2 = torch.randn(2, 4, 512, 512, generator=gen).to(DEV)
+
+    def grads(g):
+        f = fv.detach().clone().requires_grad_(True)
+        t = tex.clone().requires_grad_(True)
+        sc, _, _ = UF.soft_rasterize(f, t, 512, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
+        sc.backward(g)
+        return f.grad, t.grad
+    a, b, c = grads(g1), grads(g2), grads(g1 + 2 * g2)
+    for i in range(2):
+        ref = a[i] + 2 * b[i]
+        s = float(ref.abs().max())
+        assert float((c[i] - ref).abs().max()) <= 2e-4 * s
+
+
+def test_losses_vs_reference_goldens():
+    from umr_amd import loss_utils as LU, geom_utils as GU
+    from umr_amd.chamfer_python import distChamfer
+    g = load_golden("loss_multimask.npz")
+    verts = torch.from_numpy(g["verts"]).to(DEV).requires_grad_(True)
+    cams = torch.from_numpy(g["cams_all_hypo"]).to(DEV).requires_grad_(True)
+    probs = torch.from_numpy(g["cam_probs"]).to(DEV).requires_grad_(True)
+    mml = LU.MultiMaskLoss(int(g["image_size"]), "softmax", int(g["num_hypo_cams"]))
+    loss, masks = mml.forward(verts, torch.from_numpy(g["faces"]).to(DEV), cams, probs,
+                              torch.from_numpy(g["masks_gt"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert_close_frac(t2n(masks), g["mask_all_hypo"], atol=1e-4, frac=0.999, name="masks")
+    loss.backward()
+    for got, key in ((verts.grad, "grad_verts"), (cams.grad, "grad_cams"), (probs.grad, "grad_probs")):
+        s = np.abs(g[key]).max()
+        assert_close_frac(t2n(got), g[key], atol=2e-4 * s, rtol=5e-3, frac=0.98, name=key)
+
+    g = load_golden("loss_neg_iou.npz")
+    p = torch.from_numpy(g["predict"]).to(DEV).requires_grad_(True)
+    t = torch.from_numpy(g["target"]).to(DEV)
+    l1, l2 = LU.neg_iou_loss(p, t), LU.neg_iou_loss(p, t, avg=False)
+    (l1 + (l2 * torch.tensor([1., 2., 3.], device=DEV)).sum()).backward()
+    np.testing.assert_allclose(l1.item(), g["loss_avg"], atol=1e-6)
+    np.testing.assert_allclose(t2n(l2), g["loss_per"], atol=1e-6)
+    np.testing.assert_allclose(t2n(p.grad), g["grad_predict"], atol=1e-7, rtol=1e-4)
+
+    g = load_golden("loss_texture_sampling.npz")
+    flow = torch.from_numpy(g["flow"]).to(DEV).requires_grad_(True)
+    images = torch.from_numpy(g["images"]).to(DEV).requires_grad_(True)
+    tex = GU.sample_textures(flow, images)
+    np.testing.assert_allclose(t2n(tex), g["tex"], atol=2e-6)
+    tex.backward(torch.from_numpy(g["grad_tex"]).to(DEV))
+    np.testing.assert_allclose(t2n(flow.grad), g["grad_flow_from_tex"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(t2n(images.grad), g["grad_images"], atol=1e-5, rtol=1e-5)
+    flow.grad = None
+    dt = LU.texture_dt_loss(flow, torch.from_numpy(g["dts"]).to(DEV))
+    dt.backward()
+    np.testing.assert_allclose(dt.item(), g["dt_loss"], atol=1e-6)
+    np.testing.assert_allclose(t2n(flow.grad), g["grad_flow_from_dt"], atol=1e-8, rtol=1e-3)
+
+    g = load_golden("loss_texcycle.npz")
+    flow = torch.from_numpy(g["flow"]).to(DEV).requires_grad_(True)
+    l, avg10 = LU.TexCycle()(flow, torch.from_numpy(g["p2f_soft"]).to(DEV), torch.from_numpy(g["face_ids"]).to(DEV))
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["loss"], atol=1e-7)
+    np.testing.assert_allclose(t2n(flow.grad), g["grad_flow"], atol=1e-9, rtol=1e-4)
+    np.testing.assert_allclose(t2n(avg10), g["avg_flow10"], atol=1e-6)
+
+    g = load_golden("chamfer.npz")
+    for i in range(int(g["n_cases"])):
+        a = torch.from_numpy(g["a%d" % i]).to(DEV).requires_grad_(True)
+        b = torch.from_numpy(g["b%d" % i]).to(DEV).requires_grad_(True)
+        d1, d2, i1, i2 = distChamfer(a, b)
+        np.testing.assert_allclose(t2n(d1), g["d1_%d" % i], atol=2e-6)
+        np.testing.assert_allclose(t2n(d2), g["d2_%d" % i], atol=2e-6)
+        assert i1.dtype == torch.int32
+        assert (t2n(i1) == g["i1_%d" % i]).mean() > 0.995 and (t2n(i2) == g["i2_%d" % i]).mean() > 0.995
+        (d1.sum() + 0.5 * d2.sum()).backward()
+        np.testing.assert_allclose(t2n(a.grad), g["ga%d" % i], atol=2e-5)
+        np.testing.assert_allclose(t2n(b.grad), g["gb%d" % i], atol=2e-5)
+
+    g = load_golden("mesh_regs.npz")
+    vt, ft = torch.from_numpy(g["verts0"]), torch.from_numpy(g["faces"]).int()
+    lap, flat = LU.LaplacianLoss(vt, ft).to(DEV), LU.FlattenLoss(ft).to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    ll, fl = lap(x), flat(x)
+    np.testing.assert_allclose(t2n(ll), g["laplacian"], rtol=1e-5)
+    np.testing.assert_allclose(t2n(fl), g["flatten"], rtol=1e-4)
+    (ll.sum() + fl.sum()).backward()
+    np.testing.assert_allclose(t2n(x.grad), g["grad_x"], rtol=2e-3, atol=2e-4)
+
+
+def test_projection_gradients_vs_torch_autograd():
+    from oracle import torch_ref
+    from umr_amd import geom_utils as GU
+    verts, faces, cams, gen = scene(3, 1, seed=77)
+    gz = torch.randn(3, 42, 3, generator=gen)
+    v0, c0 = verts.clone().requires_grad_(True), cams.clone().requires_grad_(True)
+    ref = torch_ref.orthographic_proj_withz(v0, c0, 5.0)
+    ref.backward(gz)
+    v1, c1 = verts.to(DEV).requires_grad_(True), cams.to(DEV).requires_grad_(True)
+    out = GU.orthographic_proj_withz(v1, c1, 5.0)
+    out.backward(gz.to(DEV))
+    np.testing.assert_allclose(t2n(out), ref.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(t2n(v1.grad), v0.grad.numpy(), atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(t2n(c1.grad), c0.grad.numpy(), atol=1e-4, rtol=1e-4)
+
+
+def test_empty_scene_and_offscreen_mesh():
+    """Edge cases: a mesh entirely off screen renders pure background with zero gradients; ragged
+    image sizes (not a multiple of the 32x16 block) are handled."""
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(1, 1, seed=3)
+    from umr_amd.functional import ProjectFacesFunction
+    _, fv = ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    off = (fv + torch.tensor([5.0, 0, 0], device=DEV)).detach().requires_grad_(True)
+    tex = torch.rand(1, 80, 1, 3, device=DEV)
+    sc, p2f, aggr = UF.soft_rasterize(off, tex, 50, [0.25, 0.5, 0.75], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
+    assert sc.shape == (1, 4, 50, 50)
+    assert float(sc[:, 3].abs().max()) == 0.0
+    np.testing.assert_allclose(t2n(sc[0, :3].mean((1, 2))), [0.25, 0.5, 0.75], atol=1e-6)
+    sc.sum().backward()
+    assert float(off.grad.abs().max()) == 0.0

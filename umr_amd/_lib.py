@@ -1,0 +1,83 @@
+"""ctypes binding of libumr_hip.so (include/umr_hip.h).  No fallback: if the library is missing or a
+call is rejected this raises -- the product path never routes through a CPU implementation."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libumr_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_long
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+# name -> argtypes, exactly the prototypes of include/umr_hip.h
+SIGNATURES = {
+    "umr_raster_workspace_bytes": ([_I, _I], _Z),
+    "umr_raster_forward": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I, _P, _Z, _P], _I),
+    "umr_raster_backward": ([_P] * 8 + [_I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P, _Z, _P], _I),
+    "umr_project_faces_forward": ([_P] * 5 + [_I, _I, _I, _F, _F, _P], _I),
+    "umr_project_workspace_bytes": ([_I, _I], _Z),
+    "umr_project_faces_backward": ([_P] * 7 + [_I, _I, _I, _P, _Z, _P], _I),
+    "umr_project_points_forward": ([_P] * 3 + [_I, _I, _I, _F, _P], _I),
+    "umr_project_points_backward": ([_P] * 5 + [_I, _I, _I, _P], _I),
+    "umr_neg_iou_forward": ([_P, _L, _P, _P, _P, _I, _L, _P], _I),
+    "umr_neg_iou_backward": ([_P, _L, _P, _P, _P, _P, _L, _I, _L, _P], _I),
+    "umr_chamfer_forward": ([_P] * 6 + [_I, _I, _I, _I, _P], _I),
+    "umr_chamfer_backward": ([_P] * 8 + [_I, _I, _I, _I, _P], _I),
+    "umr_grid_sample_forward": ([_P] * 3 + [_I, _I, _I, _I, _L, _P], _I),
+    "umr_grid_sample_backward": ([_P] * 5 + [_I, _I, _I, _I, _L, _P], _I),
+    "umr_laplacian_forward": ([_P] * 5 + [_I, _I, _P], _I),
+    "umr_laplacian_backward": ([_P] * 5 + [_I, _I, _P], _I),
+    "umr_flatten_forward": ([_P] * 3 + [_I, _I, _I, _P], _I),
+    "umr_flatten_backward": ([_P] * 4 + [_I, _I, _I, _P], _I),
+    "umr_visible_face_mask": ([_P, _P, _I, _L, _I, _P], _I),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libumr_hip.so once.  Raises if it has not been built (python -m umr_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "umr_amd: %s is missing -- build it with `python -m umr_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        h.umr_version.restype = ctypes.c_char_p
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = h
+    return _lib
+
+
+def version():
+    return lib().umr_version().decode()
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be CUDA (ROCm) and contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("umr_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("umr_amd: %s failed with status %d (%s)" % (
+            what, rc, {-1: "rejected arguments / unsupported mode", -2: "kernel launch error"}.get(rc, "?")))

@@ -1,0 +1,45 @@
+"""Build libumr_hip.so (hipcc, gfx950 only) in-tree: umr_amd/lib/libumr_hip.so.
+
+`python -m umr_amd.build` or umr_amd.build.build().  The .so is git-ignored but travels with the
+gpurun snapshot, so the GPU box uses the prebuilt library (hipcc is present there too).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libumr_hip.so")
+SOURCES = ["raster.hip", "geometry.hip", "losses.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+         "-munsafe-fp-atomics",   # native global_atomic_add_f32 instead of CAS loops
+         "-ffp-contract=off",     # branch-deciding expressions round like the reference's float code
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "umr_common.h"),
+                                                      os.path.join(HERE, "..", "include", "umr_hip.h"),
+                                                      os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, extra_flags=()):
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print("[umr_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

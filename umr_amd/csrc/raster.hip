@@ -1,0 +1,637 @@
+// raster.hip -- soft rasterizer forward / backward for MI355X (gfx950, wave64).
+//
+// Behaviour follows the reference kernels
+//   external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda_kernel.cu:223-282 (face preprocessing),
+//   :286-476 (forward), :480-656 (backward)
+// but the execution plan is CDNA4-native rather than "one thread per pixel looping over all faces":
+//
+//   * a 512-thread workgroup owns a 32x16 pixel block; each of its 8 wavefronts owns one 8x8 tile
+//     (lane = pixel), so a face's per-wave data is wave-uniform and is fetched with scalar loads;
+//   * faces are binned per block IN the kernel: the block scans the compact [N,F] bbox array
+//     (coalesced float4 loads), ballots, and appends surviving face ids to an LDS list in
+//     ASCENDING index order (the forward's online soft-max and the p2f weights depend on visit
+//     order, reference :421-430);  each wave then filters the LDS list against its own 8x8 tile
+//     with one lane per candidate face + ballot and walks the set bits;
+//   * per-(wave, face) partial sums (p2f accumulators in forward, the 9 vertex gradients in
+//     backward) are reduced across the wavefront before touching memory: one atomic per
+//     (tile, face, component) instead of the reference's one per (pixel, face, component).
+//
+// Numerics: fp32 throughout, IEEE division, no FMA contraction (-ffp-contract=off) so that the
+// branch-deciding quantities (barycentrics, distances, depth) round like the reference's
+// scalar_t=float code; the reference's stray double sub-expressions are evaluated in float
+// (differences <= 1 ulp, covered by the 1e-4 parity tolerance).
+#include "umr_common.h"
+
+#define REC 40         // floats per preprocessed face record
+#define LIST_CAP 2048  // LDS face list capacity (faces are processed in super-chunks of this many)
+#define BLK_W 32
+#define BLK_H 16
+#define BLK_THREADS 512
+
+namespace {
+
+struct RasterArgs {
+    const float4 *bbox;   // [N*F] (xlo, xhi, ylo, yhi) = bbox dilated by sqrt(threshold)
+    const float *rec;     // [N*F*REC]
+    const float *textures;
+    const float *grid;
+    float *aggrs;
+    float *p2f_info;
+    float *p2f_sum;
+    float *soft_colors;
+    float *pooled;
+    // backward only
+    const float *grad_colors;
+    float *grad_faces;
+    float *grad_textures;
+    int N, F, IS, TS, R;
+    float near_, far_, eps, sigma, threshold, gamma;
+    int double_side, with_p2f, grad_pooled, need_gf, need_gt;
+    int tiles_x, tiles_y;
+};
+
+// ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
+__global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
+                             float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float *f = faces + (size_t)i * 9;
+    const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
+    float adj[9] = {y1 - y2, x2 - x1, x1 * y2 - x2 * y1,
+                    y2 - y0, x0 - x2, x2 * y0 - x0 * y2,
+                    y0 - y1, x1 - x0, x0 * y1 - x1 * y0};
+    float det = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+    det = det > 0 ? fmaxf(det, 1e-10f) : fminf(det, -1e-10f);
+    float inv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv[k] = adj[k] / det;
+    const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+    float sym[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sym[j * 3 + k] = px[j] * px[k] + py[j] * py[k] + 1.f;
+    int obt = -1;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {  // first obtuse corner wins (:273-281)
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        if ((px[k1] - px[k]) * (px[k2] - px[k]) + (py[k1] - py[k]) * (py[k2] - py[k]) < 0) obt = k;
+    }
+    if (faces_info) {
+        float *fi = faces_info + (size_t)i * 27;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { fi[k] = inv[k]; fi[9 + k] = sym[k]; }
+        fi[18] = obt == 0 ? 1.f : 0.f; fi[19] = obt == 1 ? 1.f : 0.f; fi[20] = obt == 2 ? 1.f : 0.f;
+    }
+    const float xlo = fminf(fminf(x0, x1), x2) - thr, xhi = fmaxf(fmaxf(x0, x1), x2) + thr;
+    const float ylo = fminf(fminf(y0, y1), y2) - thr, yhi = fmaxf(fmaxf(y0, y1), y2) + thr;
+    bbox[i] = make_float4(xlo, xhi, ylo, yhi);
+    float *r = rec + (size_t)i * REC;
+    r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi;
+    r[4] = x0; r[5] = y0; r[6] = z0; r[7] = x1; r[8] = y1; r[9] = z1; r[10] = x2; r[11] = y2; r[12] = z2;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[13 + k] = inv[k];
+    // edge e = (e, e+1 mod 3): a_e[j] = sym[e][j] - sym[e+1][j] (:82-84), den_e = a_e[e] - a_e[e+1] (:86)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int e1 = (e + 1) % 3;
+        float a[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { a[j] = sym[3 * e + j] - sym[3 * e1 + j]; r[22 + 3 * e + j] = a[j]; }
+        r[31 + e] = a[e] - a[e1];
+    }
+    r[34] = __int_as_float(obt);
+    // (f7-f1)*(f3-f0) < (f4-f1)*(f6-f0)  (:42-44)
+    r[35] = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1.f : 0.f;
+    r[36] = r[37] = r[38] = r[39] = 0.f;
+}
+
+__device__ __forceinline__ float ndc_coord(int i, int IS) {  // (2i + 1 - IS) / IS, evaluated in double (:325-326)
+    return (float)((2.0 * i + 1.0 - IS) / IS);
+}
+
+struct Face {  // wave-uniform
+    float xlo, xhi, ylo, yhi;
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+    float inv[9];
+    float a[9];
+    float den[3];
+    int obt;
+    int front;
+};
+
+// The record address is wave-uniform (face id comes from v_readlane); reading it through the constant
+// address space makes the backend emit s_load_dwordx* (scalar cache, SGPR operands) instead of 64-lane
+// broadcast vector loads.  Safe: the records are written by k_face_setup in an EARLIER launch.
+typedef const __attribute__((address_space(4))) float cfloat_t;
+
+__device__ __forceinline__ void load_face(Face &fc, const float *rg) {
+    cfloat_t *r = (cfloat_t *)rg;
+    fc.xlo = r[0]; fc.xhi = r[1]; fc.ylo = r[2]; fc.yhi = r[3];
+    fc.x0 = r[4]; fc.y0 = r[5]; fc.z0 = r[6]; fc.x1 = r[7]; fc.y1 = r[8]; fc.z1 = r[9];
+    fc.x2 = r[10]; fc.y2 = r[11]; fc.z2 = r[12];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { fc.inv[k] = r[13 + k]; fc.a[k] = r[22 + k]; }
+    fc.den[0] = r[31]; fc.den[1] = r[32]; fc.den[2] = r[33];
+    fc.obt = __float_as_int(r[34]);
+    fc.front = r[35] != 0.f;
+}
+
+struct Pair {  // per-lane result of the pixel/face geometry
+    float w0, w1, w2;   // unclipped barycentrics
+    float t0, t1, t2;   // (closest-point barycentric) - w
+    float dx, dy, sign, frag;
+};
+
+// bbox reject (:355), barycentric (:25-29), euclidean distance (:63-152), threshold reject (:382),
+// sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
+__device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, float yp, float threshold,
+                                          float sigma) {
+    if (xp > fc.xhi || xp < fc.xlo || yp > fc.yhi || yp < fc.ylo) return false;
+    const float w0 = fc.inv[0] * xp + fc.inv[1] * yp + fc.inv[2];
+    const float w1 = fc.inv[3] * xp + fc.inv[4] * yp + fc.inv[5];
+    const float w2 = fc.inv[6] * xp + fc.inv[7] * yp + fc.inv[8];
+    p.w0 = w0; p.w1 = w1; p.w2 = w2;
+    // line parameter of the projection on each edge line: tq_e = tau for edge (e, e+1)
+    const float tq0 = (w0 * fc.a[0] + w1 * fc.a[1] + w2 * fc.a[2] - fc.a[1]) / fc.den[0];
+    const float tq1 = (w0 * fc.a[3] + w1 * fc.a[4] + w2 * fc.a[5] - fc.a[5]) / fc.den[1];
+    const float tq2 = (w0 * fc.a[6] + w1 * fc.a[7] + w2 * fc.a[8] - fc.a[6]) / fc.den[2];
+    float t0, t1, t2, dx, dy, sign;
+    if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
+        float best = 100000000.f;
+        dx = 0.f; dy = 0.f; t0 = t1 = t2 = 0.f;
+        {   // edge (0,1): beta = (tq0, 1 - tq0, 0), unclamped (:78-107)
+            const float u0 = tq0 - w0, u1 = (1 - tq0) - w1, u2 = 0 - w2;
+            const float ex = u0 * fc.x0 + u1 * fc.x1 + u2 * fc.x2, ey = u0 * fc.y0 + u1 * fc.y1 + u2 * fc.y2;
+            const float d = ex * ex + ey * ey;
+            if (d < best) { best = d; dx = ex; dy = ey; t0 = u0; t1 = u1; t2 = u2; }
+        }
+        {   // edge (1,2): beta = (0, tq1, 1 - tq1)
+            const float u0 = 0 - w0, u1 = tq1 - w1, u2 = (1 - tq1) - w2;
+            const float ex = u0 * fc.x0 + u1 * fc.x1 + u2 * fc.x2, ey = u0 * fc.y0 + u1 * fc.y1 + u2 * fc.y2;
+            const float d = ex * ex + ey * ey;
+            if (d < best) { best = d; dx = ex; dy = ey; t0 = u0; t1 = u1; t2 = u2; }
+        }
+        {   // edge (2,0): beta = (1 - tq2, 0, tq2)
+            const float u0 = (1 - tq2) - w0, u1 = 0 - w1, u2 = tq2 - w2;
+            const float ex = u0 * fc.x0 + u1 * fc.x1 + u2 * fc.x2, ey = u0 * fc.y0 + u1 * fc.y1 + u2 * fc.y2;
+            const float d = ex * ex + ey * ey;
+            if (d < best) { best = d; dx = ex; dy = ey; t0 = u0; t1 = u1; t2 = u2; }
+        }
+        sign = 1.f;
+    } else {
+        int v0 = -1;  // region selection (:112-126)
+        if (w1 <= 0 && w2 <= 0) {
+            v0 = 0;
+            if (fc.obt == 0 && (xp - fc.x0) * (fc.x2 - fc.x0) + (yp - fc.y0) * (fc.y2 - fc.y0) > 0) v0 = 2;
+        } else if (w2 <= 0 && w0 <= 0) {
+            v0 = 1;
+            if (fc.obt == 1 && (xp - fc.x1) * (fc.x0 - fc.x1) + (yp - fc.y1) * (fc.y0 - fc.y1) > 0) v0 = 0;
+        } else if (w0 <= 0 && w1 <= 0) {
+            v0 = 2;
+            if (fc.obt == 2 && (xp - fc.x2) * (fc.x1 - fc.x2) + (yp - fc.y2) * (fc.y1 - fc.y2) > 0) v0 = 1;
+        } else if (w0 <= 0) v0 = 1;
+        else if (w1 <= 0) v0 = 2;
+        else if (w2 <= 0) v0 = 0;
+        if (v0 < 0) return false;  // reference UB (index -1); defined here and in the oracle as "skip"
+        const float tv = v0 == 0 ? tq0 : (v0 == 1 ? tq1 : tq2);
+        const float c0 = fminf(fmaxf(tv, 0.f), 1.f);        // beta_{v0}
+        const float c1 = fminf(fmaxf(1 - tv, 0.f), 1.f);    // beta_{v0+1}
+        const float b0 = v0 == 0 ? c0 : (v0 == 1 ? 0.f : c1);
+        const float b1 = v0 == 0 ? c1 : (v0 == 1 ? c0 : 0.f);
+        const float b2 = v0 == 0 ? 0.f : (v0 == 1 ? c1 : c0);
+        t0 = b0 - w0; t1 = b1 - w1; t2 = b2 - w2;
+        dx = t0 * fc.x0 + t1 * fc.x1 + t2 * fc.x2;
+        dy = t0 * fc.y0 + t1 * fc.y1 + t2 * fc.y2;
+        sign = -1.f;
+    }
+    const float dis = dx * dx + dy * dy;
+    if (sign < 0 && dis >= threshold) return false;
+    p.t0 = t0; p.t1 = t1; p.t2 = t2; p.dx = dx; p.dy = dy; p.sign = sign;
+    p.frag = 1.f / (1.f + __expf(-sign * dis / sigma));
+    return true;
+}
+
+// barycentric_clip (:54-59) + perspective-correct depth (:403)
+__device__ __forceinline__ float clip_depth(float &c0, float &c1, float &c2, const Pair &p, const Face &fc) {
+    c0 = fmaxf(fminf(p.w0, 1.f - 1e-5f), 1e-5f);
+    c1 = fmaxf(fminf(p.w1, 1.f - 1e-5f), 1e-5f);
+    c2 = fmaxf(fminf(p.w2, 1.f - 1e-5f), 1e-5f);
+    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+    c0 /= s; c1 /= s; c2 /= s;
+    return 1.f / (c0 / fc.z0 + c1 / fc.z1 + c2 / fc.z2);
+}
+
+__device__ __forceinline__ int texel_index(float c0, float c1, int R) {  // :180-189
+    const int wx = (int)(c0 * R), wy = (int)(c1 * R);
+    if ((c0 + c1) * R - wx - wy <= 1) return wy * R + wx;
+    return (R - 1 - wy) * R + (R - 1 - wx);
+}
+
+// XCD-aware work mapping: hardware places workgroup b on XCD b % 8; give each XCD a contiguous
+// run of (mesh, tile) work items so one mesh's face records stay in one L2.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+    return (total % 8 == 0) ? (b % 8) * (total / 8) + b / 8 : b;
+}
+
+struct Tile {
+    int n, lane, wave, xi, row;
+    bool valid, wave_on;
+    float xp, yp;
+    float bxlo, bxhi, bylo, byhi;  // block bounds (pixel centres)
+    float wxlo, wxhi, wylo, wyhi;  // wave tile bounds
+};
+
+__device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
+    const int total = A.N * A.tiles_x * A.tiles_y;
+    int wid = xcd_remap(blockIdx.x, total);
+    const int bx = wid % A.tiles_x; wid /= A.tiles_x;
+    const int by = wid % A.tiles_y;
+    t.n = wid / A.tiles_y;
+    t.lane = threadIdx.x & 63;
+    t.wave = threadIdx.x >> 6;
+    const int IS = A.IS;
+    const int px0 = bx * BLK_W + (t.wave & 3) * 8, py0 = by * BLK_H + (t.wave >> 2) * 8;
+    t.xi = px0 + (t.lane & 7);
+    t.row = py0 + (t.lane >> 3);
+    t.valid = t.xi < IS && t.row < IS;
+    t.wave_on = px0 < IS && py0 < IS;
+    t.xp = ndc_coord(t.xi, IS);
+    t.yp = ndc_coord(IS - 1 - t.row, IS);
+    t.bxlo = ndc_coord(bx * BLK_W, IS);
+    t.bxhi = ndc_coord(min(bx * BLK_W + BLK_W - 1, IS - 1), IS);
+    t.byhi = ndc_coord(IS - 1 - by * BLK_H, IS);
+    t.bylo = ndc_coord(IS - 1 - min(by * BLK_H + BLK_H - 1, IS - 1), IS);
+    t.wxlo = ndc_coord(px0, IS);
+    t.wxhi = ndc_coord(min(px0 + 7, IS - 1), IS);
+    t.wyhi = ndc_coord(IS - 1 - py0, IS);
+    t.wylo = ndc_coord(IS - 1 - min(py0 + 7, IS - 1), IS);
+}
+
+// Block-level binning of faces [f0, f1) into the LDS list, ascending order.  Returns the count.
+__device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4 *__restrict__ bbox_n, int f0,
+                                          int f1, const Tile &t) {
+    int count = 0;
+    for (int c = f0; c < f1; c += BLK_THREADS) {
+        const int f = c + (int)threadIdx.x;
+        bool pass = false;
+        if (f < f1) {
+            const float4 bb = bbox_n[f];
+            // same predicate as the per-pixel reject, applied to the block's extreme pixel centres
+            pass = !(t.bxlo > bb.y || t.bxhi < bb.x || t.bylo > bb.w || t.byhi < bb.z);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (t.lane == 0) s_wcnt[t.wave] = __popcll(m);
+        __syncthreads();
+        int base = count, tot = 0;
+#pragma unroll
+        for (int w = 0; w < BLK_THREADS / 64; ++w) {
+            const int cw = s_wcnt[w];
+            if (w < t.wave) base += cw;
+            tot += cw;
+        }
+        if (pass) s_list[base + __popcll(m & ((1ull << t.lane) - 1ull))] = f;
+        count += tot;
+        __syncthreads();
+    }
+    return count;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int RGB>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437)
+__global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs A) {
+    __shared__ int s_list[LIST_CAP];
+    __shared__ int s_wcnt[BLK_THREADS / 64];
+    Tile t;
+    tile_setup(t, A);
+    const int F = A.F, IS = A.IS;
+    const size_t npix = (size_t)IS * IS;
+    const size_t pn = (size_t)t.row * IS + t.xi;
+    const float4 *__restrict__ bbox_n = A.bbox + (size_t)t.n * F;
+    const float *__restrict__ rec_n = A.rec + (size_t)t.n * F * REC;
+    const float *__restrict__ tex_n = A.textures + (size_t)t.n * F * A.TS * 3;
+
+    float alpha = 1.f;
+    float ssum = __expf(A.eps / A.gamma), smax = A.eps;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, gx = 0.f, gy = 0.f;
+    float depth_min = 10000000.f;
+    int face_min = -1;
+    if (t.valid) {
+        float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
+        c0 = sc[0]; c1 = sc[npix]; c2 = sc[2 * npix];
+        if (RGB == 1) {
+            c0 *= ssum; c1 *= ssum; c2 *= ssum;
+            if (A.with_p2f) { gx = A.grid[pn * 2]; gy = A.grid[pn * 2 + 1]; }
+        }
+    }
+
+    for (int f0 = 0; f0 < F; f0 += LIST_CAP) {
+        const int f1 = min(F, f0 + LIST_CAP);
+        if (f0 > 0) __syncthreads();
+        const int count = build_list(s_list, s_wcnt, bbox_n, f0, f1, t);
+        if (!t.wave_on) continue;
+        for (int base = 0; base < count; base += 64) {
+            const int li = base + t.lane;
+            const int fcand = li < count ? s_list[li] : -1;
+            bool hit = false;
+            if (fcand >= 0) {
+                const float4 bb = bbox_n[fcand];
+                hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int f = __builtin_amdgcn_readlane(fcand, b);
+                Face fc;
+                load_face(fc, rec_n + (size_t)f * REC);
+                float wgt = 0.f;  // this lane's p2f weight for face f
+                Pair p;
+                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.sigma)) {
+                    alpha *= 1.f - p.frag;  // 'prod' alpha (:396), BEFORE the depth-range test
+                    float q0, q1, q2;
+                    const float zp = clip_depth(q0, q1, q2, p, fc);
+                    if (!(zp < A.near_ || zp > A.far_)) {
+                        if (RGB == 0) {
+                            const bool inside = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
+                            if (zp < depth_min && inside && (A.double_side || fc.front)) {
+                                depth_min = zp;
+                                face_min = f;
+                                const float *tx = tex_n + ((size_t)f * A.TS + texel_index(q0, q1, A.R)) * 3;
+                                c0 = tx[0]; c1 = tx[1]; c2 = tx[2];
+                            }
+                        } else if (fc.front || A.double_side) {
+                            const float zn = (A.far_ - zp) / (A.far_ - A.near_);
+                            float rescale = 1.f;
+                            if (zn > smax) {
+                                rescale = __expf((smax - zn) / A.gamma);
+                                smax = zn;
+                            }
+                            const float ez = __expf((zn - smax) / A.gamma);
+                            ssum = rescale * ssum + ez * p.frag;
+                            wgt = ez * p.frag;
+                            const float *tx = tex_n + ((size_t)f * A.TS + texel_index(q0, q1, A.R)) * 3;
+                            c0 = rescale * c0 + wgt * tx[0];
+                            c1 = rescale * c1 + wgt * tx[1];
+                            c2 = rescale * c2 + wgt * tx[2];
+                        }
+                    }
+                }
+                if (RGB == 1 && A.with_p2f) {  // :427-430, reduced over the 8x8 tile first
+                    if (__any(wgt != 0.f)) {
+                        const float sx = wave_sum(wgt * gx), sy = wave_sum(wgt * gy), sw = wave_sum(wgt);
+                        if (t.lane < 4) {
+                            const size_t o = ((size_t)t.n * F + f) * 2;
+                            float *dst = t.lane < 2 ? A.p2f_info + o + t.lane : A.p2f_sum + o + (t.lane - 2);
+                            atomicAdd(dst, t.lane == 0 ? sx : (t.lane == 1 ? sy : sw));
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (!t.wave_on) return;
+    // epilogue (:442-475)
+    float o0, o1, o2;
+    const float o3 = 1.f - alpha;
+    if (RGB == 0) { o0 = c0; o1 = c1; o2 = c2; }
+    else { o0 = c0 / ssum; o1 = c1 / ssum; o2 = c2 / ssum; }
+    if (t.valid) {
+        float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
+        if (RGB == 1 || face_min != -1) { sc[0] = o0; sc[npix] = o1; sc[2 * npix] = o2; }
+        sc[3 * npix] = o3;
+        float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
+        ag[0] = RGB == 0 ? depth_min : ssum;
+        ag[npix] = RGB == 0 ? (float)face_min : smax;
+    }
+    if (A.pooled) {  // fused anti-aliasing 2x2 average (rasterizer.py:52-53); IS is even here
+        float v[4] = {o0, o1, o2, o3};
+        const int H = IS >> 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = v[k] + __shfl_xor(v[k], 1, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (t.valid && !(t.lane & 1) && !(t.lane & 8))
+                A.pooled[(((size_t)t.n * 4 + k) * H + (t.row >> 1)) * H + (t.xi >> 1)] = 0.25f * s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int RGB>
+__global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArgs A) {
+    __shared__ int s_list[LIST_CAP];
+    __shared__ int s_wcnt[BLK_THREADS / 64];
+    Tile t;
+    tile_setup(t, A);
+    const int F = A.F, IS = A.IS, TS = A.TS;
+    const size_t npix = (size_t)IS * IS;
+    const size_t pn = (size_t)t.row * IS + t.xi;
+    const float4 *__restrict__ bbox_n = A.bbox + (size_t)t.n * F;
+    const float *__restrict__ rec_n = A.rec + (size_t)t.n * F * REC;
+    const float *__restrict__ tex_n = A.textures + (size_t)t.n * F * TS * 3;
+
+    float ssum = 1.f, smax = 0.f, oc0 = 0.f, oc1 = 0.f, oc2 = 0.f, oa = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (t.valid) {
+        const float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
+        ssum = ag[0]; smax = ag[npix];
+        const float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
+        oc0 = sc[0]; oc1 = sc[npix]; oc2 = sc[2 * npix]; oa = sc[3 * npix];
+        if (A.grad_pooled) {  // avg_pool2d backward fused: every pixel of a 2x2 cell sees g/4
+            const int H = IS >> 1;
+            const float *gp = A.grad_colors + ((size_t)t.n * 4 * H + (t.row >> 1)) * H + (t.xi >> 1);
+            const size_t hp = (size_t)H * H;
+            g0 = 0.25f * gp[0]; g1 = 0.25f * gp[hp]; g2 = 0.25f * gp[2 * hp]; g3 = 0.25f * gp[3 * hp];
+        } else {
+            const float *gp = A.grad_colors + (size_t)t.n * 4 * npix + pn;
+            g0 = gp[0]; g1 = gp[npix]; g2 = gp[2 * npix]; g3 = gp[3 * npix];
+        }
+    }
+
+    for (int f0 = 0; f0 < F; f0 += LIST_CAP) {
+        const int f1 = min(F, f0 + LIST_CAP);
+        if (f0 > 0) __syncthreads();
+        const int count = build_list(s_list, s_wcnt, bbox_n, f0, f1, t);
+        if (!t.wave_on) continue;
+        for (int base = 0; base < count; base += 64) {
+            const int li = base + t.lane;
+            const int fcand = li < count ? s_list[li] : -1;
+            bool hit = false;
+            if (fcand >= 0) {
+                const float4 bb = bbox_n[fcand];
+                hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int f = __builtin_amdgcn_readlane(fcand, b);
+                Face fc;
+                load_face(fc, rec_n + (size_t)f * REC);
+                float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // texture gradient of this lane (at texel tix)
+                int tix = 0;
+                bool contrib = false;
+                Pair p;
+                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.sigma)) {
+                    float c_xy = g3 * ((1.f - oa) / fmaxf(1.f - p.frag, 1e-6f));  // :584
+                    float q0, q1, q2;
+                    const float zp = clip_depth(q0, q1, q2, p, fc);
+                    if (!(zp < A.near_ || zp > A.far_)) {  // :592 -- drops the alpha term as well
+                        contrib = true;
+                        if (RGB == 0) {
+                            if ((float)f == smax) {  // :596
+                                tix = texel_index(q0, q1, A.R);
+                                gt0 = g0; gt1 = g1; gt2 = g2;
+                            }
+                        } else if (fc.front || A.double_side) {
+                            const float zn = (A.far_ - zp) / (A.far_ - A.near_);
+                            const float ps = p.frag * __expf((zn - smax) / A.gamma) / ssum;  // :608
+                            tix = texel_index(q0, q1, A.R);
+                            const float *tx = tex_n + ((size_t)f * TS + tix) * 3;
+                            gt0 = ps * g0; gt1 = ps * g1; gt2 = ps * g2;
+                            float c_rgb = g0 * (tx[0] - oc0);
+                            c_rgb += g1 * (tx[1] - oc1);
+                            c_rgb += g2 * (tx[2] - oc2);
+                            c_rgb *= ps;
+                            c_xy += c_rgb / p.frag;
+                            const float c_z = c_rgb / A.gamma / (A.near_ - A.far_) * zp * zp;  // :624
+                            gv[2] = c_z * q0 / fc.z0 / fc.z0;
+                            gv[5] = c_z * q1 / fc.z1 / fc.z1;
+                            gv[8] = c_z * q2 / fc.z2 / fc.z2;
+                        }
+                        c_xy *= p.frag * (1.f - p.frag) / A.sigma;  // :632
+                        const float k2 = 2.f * p.sign * c_xy;        // :640
+                        const float b0 = k2 * (p.t0 + p.w0), b1 = k2 * (p.t1 + p.w1), b2 = k2 * (p.t2 + p.w2);
+                        gv[0] = b0 * p.dx; gv[1] = b0 * p.dy;
+                        gv[3] = b1 * p.dx; gv[4] = b1 * p.dy;
+                        gv[6] = b2 * p.dx; gv[7] = b2 * p.dy;
+                    }
+                }
+                if (!__any(contrib)) continue;
+                if (A.need_gf) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float s = wave_sum(gv[k]);
+                        if (t.lane == k) mine = s;
+                    }
+                    if (t.lane < 9) atomicAdd(A.grad_faces + ((size_t)t.n * F + f) * 9 + t.lane, mine);
+                }
+                if (A.need_gt) {
+                    float *gtf = A.grad_textures + ((size_t)t.n * F + f) * TS * 3;
+                    if (TS == 1) {
+                        const float s0 = wave_sum(gt0), s1 = wave_sum(gt1), s2 = wave_sum(gt2);
+                        if (t.lane < 3) atomicAdd(gtf + t.lane, t.lane == 0 ? s0 : (t.lane == 1 ? s1 : s2));
+                    } else if (gt0 != 0.f || gt1 != 0.f || gt2 != 0.f) {
+                        atomicAdd(gtf + tix * 3 + 0, gt0);
+                        atomicAdd(gtf + tix * 3 + 1, gt1);
+                        atomicAdd(gtf + tix * 3 + 2, gt2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int TS, int *R) {
+    if (func_id_dist != 2 || func_id_alpha != 2 || texture_sample_type != 0) return false;
+    if (func_id_rgb != 0 && func_id_rgb != 1) return false;
+    int r = 1;
+    while (r * r < TS) ++r;
+    if (r * r != TS) return false;
+    *R = r;
+    return true;
+}
+
+size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+const char *umr_version(void) { return "umr_hip 0.1 gfx950"; }
+
+size_t umr_raster_workspace_bytes(int N, int F) {
+    if (N <= 0 || F <= 0) return 0;
+    return ws_bbox_bytes(N, F) + (size_t)N * F * REC * sizeof(float);
+}
+
+int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
+                       const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,
+                       float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
+                       float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                       int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                       int flags, void *workspace, size_t workspace_bytes, void *stream) {
+    int R = 0;
+    if (!faces || !textures || !aggrs_info || !soft_colors || !workspace) return UMR_ERR_ARG;
+    if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
+    if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
+    if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
+    const int with_p2f = func_id_rgb == 1 && !(flags & UMR_RASTER_NO_P2F);
+    if (with_p2f && (!grid || !p2f_info || !p2f_sum)) return UMR_ERR_ARG;
+    if (pooled_out && (image_size & 1)) return UMR_ERR_ARG;
+    if ((long long)N * ((image_size + BLK_W - 1) / BLK_W) * ((image_size + BLK_H - 1) / BLK_H) > 0x7fffffffLL)
+        return UMR_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    RasterArgs A = {};
+    A.bbox = (const float4 *)workspace;
+    A.rec = (const float *)((char *)workspace + ws_bbox_bytes(N, F));
+    A.textures = textures; A.grid = grid; A.aggrs = aggrs_info; A.p2f_info = p2f_info; A.p2f_sum = p2f_sum;
+    A.soft_colors = soft_colors; A.pooled = pooled_out;
+    A.N = N; A.F = F; A.IS = image_size; A.TS = TS; A.R = R;
+    A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
+    A.threshold = dist_eps * sigma_val;  // :332
+    A.gamma = gamma_val; A.double_side = double_side; A.with_p2f = with_p2f;
+    A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
+    A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
+    const int total = N * F;
+    k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
+                                                      sqrtf(A.threshold));
+    const int blocks = N * A.tiles_x * A.tiles_y;
+    if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
+    else k_raster_forward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+    return umr_launch_status();
+}
+
+int umr_raster_backward(const float *faces, const float *textures, const float *soft_colors,
+                        const float *faces_info, const float *aggrs_info, float *grad_faces,
+                        float *grad_textures, const float *grad_soft_colors, int grad_is_pooled,
+                        int need_grad_faces, int need_grad_textures, int N, int F, int TS, int image_size,
+                        float near_, float far_, float eps, float sigma_val, int func_id_dist,
+                        float dist_eps, float gamma_val, int func_id_rgb, int func_id_alpha,
+                        int texture_sample_type, int double_side, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+    (void)faces_info;  // recomputed into the workspace (bit-identical: same kernel, same input)
+    int R = 0;
+    if (!faces || !textures || !soft_colors || !aggrs_info || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
+    if ((need_grad_faces && !grad_faces) || (need_grad_textures && !grad_textures)) return UMR_ERR_ARG;
+    if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
+    if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
+    if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
+    if (grad_is_pooled && (image_size & 1)) return UMR_ERR_ARG;
+    if (!need_grad_faces && !need_grad_textures) return UMR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    RasterArgs A = {};
+    A.bbox = (const float4 *)workspace;
+    A.rec = (const float *)((char *)workspace + ws_bbox_bytes(N, F));
+    A.textures = textures; A.aggrs = (float *)aggrs_info; A.soft_colors = (float *)soft_colors;
+    A.grad_colors = grad_soft_colors; A.grad_faces = grad_faces; A.grad_textures = grad_textures;
+    A.N = N; A.F = F; A.IS = image_size; A.TS = TS; A.R = R;
+    A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
+    A.threshold = dist_eps * sigma_val;
+    A.gamma = gamma_val; A.double_side = double_side;
+    A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
+    A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
+    A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
+    const int total = N * F;
+    k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
+                                                      sqrtf(A.threshold));
+    const int blocks = N * A.tiles_x * A.tiles_y;
+    if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
+    else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+    return umr_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+"""torch.autograd front-ends over the C ABI (include/umr_hip.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and autograd
+bookkeeping.  All arithmetic happens in libumr_hip.so; there is no CPU or eager-torch fallback.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ptr
+
+_FUNC_DIST = {'hard': 0, 'barycentric': 1, 'euclidean': 2}
+_FUNC_RGB = {'hard': 0, 'softmax': 1}
+_FUNC_ALPHA = {'hard': 0, 'sum': 1, 'prod': 2}
+_FUNC_SAMPLE = {'surface': 0, 'vertex': 1}
+
+_grid_cache = {}
+
+
+def standard_grid(image_size, device):
+    """The `grid` the reference builds every call (functional/soft_rasterize.py:57-62): identity
+    affine_grid under torch-1.1.0 semantics (= align_corners=True).  Cached per (size, device)."""
+    key = (int(image_size), str(device))
+    g = _grid_cache.get(key)
+    if g is None:
+        theta = torch.tensor([[1, 0, 0], [0, 1, 0]], dtype=torch.float)
+        g = torch.nn.functional.affine_grid(theta.unsqueeze(0), (1, 1, image_size, image_size), align_corners=True)
+        g = g.view(image_size, image_size, 2).contiguous().to(device)
+        _grid_cache[key] = g
+    return g
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class SoftRasterizeFunction(Function):
+    """Drop-in for external/SoftRas/soft_renderer/functional/soft_rasterize.py:9-108.
+
+    Extra (trailing) arguments drive the fused MI355X paths and default to the reference behaviour:
+      pool:       also return/consume the 2x2 average-pooled image (anti-aliasing fused into the kernels;
+                  the first output is then [N,4,IS/2,IS/2] and its gradient is consumed at that size)
+      need_p2f:   False skips the p2f accumulators (returned as zeros)
+    """
+
+    @staticmethod
+    def forward(ctx, face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
+                fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+                gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
+                pool=False, need_p2f=True):
+        L = _lib.lib()
+        dev = face_vertices.device
+        fv = _f32c(face_vertices)
+        tex = _f32c(textures)
+        N, F = fv.shape[:2]
+        TS = tex.shape[2]
+        IS = int(image_size)
+        ctx.cfg = (IS, float(near), float(far), float(eps), float(sigma_val), _FUNC_DIST[dist_func],
+                   float(math.log(1. / dist_eps - 1.)), float(gamma_val), _FUNC_RGB[aggr_func_rgb],
+                   _FUNC_ALPHA[aggr_func_alpha], _FUNC_SAMPLE[texture_type], 1 if fill_back else 0)
+        ctx.pool = bool(pool)
+        faces_info = torch.zeros(N, F, 27, device=dev, dtype=torch.float32)
+        aggrs_info = torch.zeros(N, 2, IS, IS, device=dev, dtype=torch.float32)
+        p2f_info = torch.zeros(N, F, 2, device=dev, dtype=torch.float32)
+        p2f_sum = torch.zeros(N, F, 2, device=dev, dtype=torch.float32)
+        soft_colors = torch.ones(N, 4, IS, IS, device=dev, dtype=torch.float32)
+        for k in range(3):
+            if background_color[k] != 1:
+                soft_colors[:, k].mul_(float(background_color[k]))
+        pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
+        grid = standard_grid(IS, dev) if (need_p2f and ctx.cfg[8] == 1) else None
+        ws_bytes = L.umr_raster_workspace_bytes(N, F)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
+        rc = L.umr_raster_forward(ptr(fv), ptr(tex), ptr(faces_info), ptr(aggrs_info), ptr(grid), ptr(p2f_info),
+                                  ptr(p2f_sum), ptr(soft_colors), ptr(pooled), N, F, TS, IS_, near_, far_, eps_,
+                                  sig, fd, de, gam, frgb, fal, fsm, ds, 0 if need_p2f else 1, ptr(ws), ws_bytes,
+                                  _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_raster_forward")
+        p2f = p2f_info / p2f_sum.clamp_min(1e-12)  # functional/soft_rasterize.py:73
+        ctx.save_for_backward(fv, tex, soft_colors, aggrs_info)
+        ctx.fv_shape = face_vertices.shape
+        ctx.mark_non_differentiable(p2f, aggrs_info)
+        return (pooled if pool else soft_colors), p2f, aggrs_info
+
+    @staticmethod
+    def backward(ctx, grad_soft_colors, grad_p2f_info=None, grad_aggrs_info=None):
+        L = _lib.lib()
+        fv, tex, soft_colors, aggrs_info = ctx.saved_tensors
+        dev = fv.device
+        N, F = fv.shape[:2]
+        TS = tex.shape[2]
+        need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32) if need_gf else None
+        grad_textures = torch.zeros_like(tex) if need_gt else None
+        g = grad_soft_colors.to(torch.float32).contiguous()
+        ws_bytes = L.umr_raster_workspace_bytes(N, F)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
+        rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
+                                   ptr(grad_textures), ptr(g), 1 if ctx.pool else 0, 1 if need_gf else 0,
+                                   1 if need_gt else 0, N, F, TS, IS_, near_, far_, eps_, sig, fd, de, gam, frgb,
+                                   fal, fsm, ds, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_raster_backward")
+        gf = grad_faces.view(ctx.fv_shape) if need_gf else None
+        return (gf, grad_textures) + (None,) * 15
+
+
+def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
+                   fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+                   gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
+                   pool=False, need_p2f=True):
+    """Same signature and return as soft_renderer.functional.soft_rasterize
+    (functional/soft_rasterize.py:111-125): (soft_colors [N,4,IS,IS], p2f_info [N,F,2], aggrs_info)."""
+    if not face_vertices.is_cuda:
+        # the reference's guard (:117-118) is dead code; ours is real
+        raise TypeError('Rasterize module supports only GPU (ROCm) tensors')
+    return SoftRasterizeFunction.apply(face_vertices, textures, image_size, background_color, near, far,
+                                       fill_back, eps, sigma_val, dist_func, dist_eps, gamma_val,
+                                       aggr_func_rgb, aggr_func_alpha, texture_type, pool, need_p2f)
+
+
+class ProjectFacesFunction(Function):
+    """verts [N,V,3], cams [N,7], faces [N,F,3] int32 -> (face_pre [N,F,3,3], face_out [N,F,3,3]).
+    Fuses geom_utils.orthographic_proj_withz + smr.Render's y flip + face_vertices + LookAt/orthogonal."""
+
+    @staticmethod
+    def forward(ctx, verts, cams, faces_idx, offset_z, eye_z, want_pre):
+        L = _lib.lib()
+        dev = verts.device
+        v, c = _f32c(verts), _f32c(cams)
+        N, V = v.shape[:2]
+        F = faces_idx.shape[1]
+        face_out = torch.empty(N, F, 3, 3, device=dev, dtype=torch.float32)
+        face_pre = torch.empty(N, F, 3, 3, device=dev, dtype=torch.float32) if want_pre else None
+        rc = L.umr_project_faces_forward(ptr(v), ptr(c), ptr(faces_idx), ptr(face_pre), ptr(face_out), N, V, F,
+                                         float(offset_z), float(eye_z), _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_project_faces_forward")
+        ctx.save_for_backward(v, c, faces_idx)
+        ctx.want_pre = want_pre
+        if want_pre:
+            return face_pre, face_out
+        return face_out.new_empty(0), face_out
+
+    @staticmethod
+    def backward(ctx, g_pre, g_out):
+        L = _lib.lib()
+        v, c, faces_idx = ctx.saved_tensors
+        dev = v.device
+        N, V = v.shape[:2]
+        F = faces_idx.shape[1]
+        g_out = g_out.to(torch.float32).contiguous()
+        g_pre = g_pre.to(torch.float32).contiguous() if (ctx.want_pre and g_pre is not None) else None
+        grad_verts = torch.zeros_like(v) if ctx.needs_input_grad[0] else None
+        grad_cams = torch.empty_like(c)
+        ws_bytes = L.umr_project_workspace_bytes(N, V)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        rc = L.umr_project_faces_backward(ptr(g_out), ptr(g_pre), ptr(v), ptr(c), ptr(faces_idx), ptr(grad_verts),
+                                          ptr(grad_cams), N, V, F, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_project_faces_backward")
+        return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+class ProjectPointsFunction(Function):
+    """verts [N,V,3], cams [N,7] -> [N,V,out_dim] (2: xy; 3: xy + z with offset_z).  No y flip."""
+
+    @staticmethod
+    def forward(ctx, verts, cams, out_dim=2, offset_z=0.0):
+        L = _lib.lib()
+        v, c = _f32c(verts), _f32c(cams)
+        N, V = v.shape[:2]
+        out = torch.empty(N, V, out_dim, device=v.device, dtype=torch.float32)
+        _lib.check(L.umr_project_points_forward(ptr(v), ptr(c), ptr(out), N, V, int(out_dim), float(offset_z),
+                                                _lib.stream_ptr(v.device)), "umr_project_points_forward")
+        ctx.save_for_backward(v, c)
+        ctx.out_dim = int(out_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        v, c = ctx.saved_tensors
+        N, V = v.shape[:2]
+        g = g.to(torch.float32).contiguous()
+        grad_verts = torch.zeros_like(v) if ctx.needs_input_grad[0] else None
+        grad_cams = torch.empty_like(c)
+        _lib.check(L.umr_project_points_backward(ptr(g), ptr(v), ptr(c), ptr(grad_verts), ptr(grad_cams), N, V,
+                                                 ctx.out_dim, _lib.stream_ptr(v.device)),
+                   "umr_project_points_backward")
+        return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None
+
+
+class NegIoUFunction(Function):
+    """loss[n] = 1 - sum(p t) / (sum(p + t - p t) + 1e-6)   (nnutils/loss_utils.py:41-48, avg=False)."""
+
+    @staticmethod
+    def forward(ctx, predict, target):
+        L = _lib.lib()
+        p = _f32c(predict).view(predict.shape[0], -1)
+        t = _f32c(target).view(target.shape[0], -1)
+        N, P = p.shape
+        loss = torch.empty(N, device=p.device, dtype=torch.float32)
+        sums = torch.empty(N, 2, device=p.device, dtype=torch.float32)
+        _lib.check(L.umr_neg_iou_forward(ptr(p), P, ptr(t), ptr(loss), ptr(sums), N, P, _lib.stream_ptr(p.device)),
+                   "umr_neg_iou_forward")
+        ctx.save_for_backward(p, t, sums)
+        ctx.shape = predict.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        p, t, sums = ctx.saved_tensors
+        N, P = p.shape
+        gp = torch.zeros_like(p)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(L.umr_neg_iou_backward(ptr(p), P, ptr(t), ptr(sums), ptr(g), ptr(gp), P, N, P,
+                                          _lib.stream_ptr(p.device)), "umr_neg_iou_backward")
+        return gp.view(ctx.shape), None
+
+
+class ChamferFunction(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        L = _lib.lib()
+        a_, b_ = _f32c(a), _f32c(b)
+        B, n, D = a_.shape
+        m = b_.shape[1]
+        dev = a_.device
+        d1 = torch.empty(B, n, device=dev, dtype=torch.float32)
+        d2 = torch.empty(B, m, device=dev, dtype=torch.float32)
+        i1 = torch.empty(B, n, device=dev, dtype=torch.int32)
+        i2 = torch.empty(B, m, device=dev, dtype=torch.int32)
+        _lib.check(L.umr_chamfer_forward(ptr(a_), ptr(b_), ptr(d1), ptr(d2), ptr(i1), ptr(i2), B, n, m, D,
+                                         _lib.stream_ptr(dev)), "umr_chamfer_forward")
+        ctx.save_for_backward(a_, b_, i1, i2)
+        ctx.mark_non_differentiable(i1, i2)
+        return d1, d2, i1, i2
+
+    @staticmethod
+    def backward(ctx, g1, g2, _gi1, _gi2):
+        L = _lib.lib()
+        a_, b_, i1, i2 = ctx.saved_tensors
+        B, n, D = a_.shape
+        m = b_.shape[1]
+        g1 = (g1 if g1 is not None else torch.zeros(B, n, device=a_.device)).to(torch.float32).contiguous()
+        g2 = (g2 if g2 is not None else torch.zeros(B, m, device=a_.device)).to(torch.float32).contiguous()
+        ga, gb = torch.empty_like(a_), torch.empty_like(b_)
+        _lib.check(L.umr_chamfer_backward(ptr(a_), ptr(b_), ptr(i1), ptr(i2), ptr(g1), ptr(g2), ptr(ga), ptr(gb),
+                                          B, n, m, D, _lib.stream_ptr(a_.device)), "umr_chamfer_backward")
+        return ga, gb
+
+
+class GridSampleCLFunction(Function):
+    """image [B,C,H,W], grid [B,P,2] -> out [B,P,C]; bilinear / zeros / align_corners=True."""
+
+    @staticmethod
+    def forward(ctx, image, grid):
+        L = _lib.lib()
+        img, g = _f32c(image), _f32c(grid)
+        B, C, H, W = img.shape
+        P = g.shape[1]
+        out = torch.empty(B, P, C, device=img.device, dtype=torch.float32)
+        _lib.check(L.umr_grid_sample_forward(ptr(img), ptr(g), ptr(out), B, C, H, W, P, _lib.stream_ptr(img.device)),
+                   "umr_grid_sample_forward")
+        ctx.save_for_backward(img, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.lib()
+        img, g = ctx.saved_tensors
+        B, C, H, W = img.shape
+        P = g.shape[1]
+        go = go.to(torch.float32).contiguous()
+        gi = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        gg = torch.empty_like(g) if ctx.needs_input_grad[1] else None
+        _lib.check(L.umr_grid_sample_backward(ptr(img), ptr(g), ptr(go), ptr(gg), ptr(gi), B, C, H, W, P,
+                                              _lib.stream_ptr(img.device)), "umr_grid_sample_backward")
+        return gi, gg
+
+
+class LaplacianFunction(Function):
+    @staticmethod
+    def forward(ctx, x, nbr_off, nbr_idx):
+        L = _lib.lib()
+        x_ = _f32c(x)
+        B, V = x_.shape[:2]
+        lap = torch.empty_like(x_)
+        loss = torch.empty(B, device=x_.device, dtype=torch.float32)
+        _lib.check(L.umr_laplacian_forward(ptr(x_), ptr(nbr_off), ptr(nbr_idx), ptr(lap), ptr(loss), B, V,
+                                           _lib.stream_ptr(x_.device)), "umr_laplacian_forward")
+        ctx.save_for_backward(lap, nbr_off, nbr_idx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        lap, nbr_off, nbr_idx = ctx.saved_tensors
+        B, V = lap.shape[:2]
+        gx = torch.zeros_like(lap)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(L.umr_laplacian_backward(ptr(lap), ptr(nbr_off), ptr(nbr_idx), ptr(g), ptr(gx), B, V,
+                                            _lib.stream_ptr(lap.device)), "umr_laplacian_backward")
+        return gx, None, None
+
+
+class FlattenFunction(Function):
+    @staticmethod
+    def forward(ctx, x, quads):
+        L = _lib.lib()
+        x_ = _f32c(x)
+        B, V = x_.shape[:2]
+        E = quads.shape[0]
+        loss = torch.empty(B, device=x_.device, dtype=torch.float32)
+        _lib.check(L.umr_flatten_forward(ptr(x_), ptr(quads), ptr(loss), B, V, E, _lib.stream_ptr(x_.device)),
+                   "umr_flatten_forward")
+        ctx.save_for_backward(x_, quads)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x_, quads = ctx.saved_tensors
+        B, V = x_.shape[:2]
+        gx = torch.zeros_like(x_)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(L.umr_flatten_backward(ptr(x_), ptr(quads), ptr(g), ptr(gx), B, V, quads.shape[0],
+                                          _lib.stream_ptr(x_.device)), "umr_flatten_backward")
+        return gx, None
+
+
+def visible_face_mask(face_ids, num_faces):
+    """face_ids [B,P] float (hard renderer face-id plane) -> [B,F] 0/1 mask (loss_utils.py:173-179)."""
+    L = _lib.lib()
+    ids = _f32c(face_ids)
+    B, P = ids.shape
+    mask = torch.zeros(B, num_faces, device=ids.device, dtype=torch.float32)
+    _lib.check(L.umr_visible_face_mask(ptr(ids), ptr(mask), B, P, num_faces, _lib.stream_ptr(ids.device)),
+               "umr_visible_face_mask")
+    return mask

@@ -1,0 +1,81 @@
+"""nnutils.smr.SoftRenderer on MI355X.
+
+Same constructor, methods and return values as the reference wrapper (nnutils/smr.py:49-87, which
+drives external/SoftRas sr.SoftRenderer: renderer.py:48-98, lighting.py:50-57, transform.py:41-48,
+rasterizer.py:42-55), so loss code written against the reference runs unchanged:
+
+    imgs [N,4,H,H], p2f [N,F,2], aggr [N,2,2H,2H] = SoftRenderer(H, 'softmax')(verts, faces, cams, textures)
+
+Execution: one projection+gather kernel, (torch elementwise lighting only when a directional light is
+on), one face-setup + one tiled raster kernel with the 2x2 anti-aliasing pool fused; backward is the
+mirror image.  No CPU path.
+"""
+import torch
+
+from . import functional as UF
+
+
+class SoftRenderer(torch.nn.Module):
+    def __init__(self, img_size=256, render_type='softmax', background_color=[0, 0, 0], sigma_val=1e-5,
+                 gamma_val=1e-4, dist_eps=1e-10, anti_aliasing=True):
+        super(SoftRenderer, self).__init__()
+        self.img_size = img_size
+        self.render_type = render_type
+        self.background_color = list(background_color)
+        self.sigma_val, self.gamma_val, self.dist_eps = sigma_val, gamma_val, dist_eps
+        self.anti_aliasing = anti_aliasing
+        # sr.SoftRenderer defaults (renderer.py:58-60) with smr.py:63's brighter ambient
+        self.light_intensity_ambient = 0.8
+        self.light_intensity_directional = 0.5
+        self.light_color = [1., 1., 1.]
+        self.light_direction = [0., 1., 0.]
+        self.eye_z = -2.732          # smr.py:60
+        self.offset_z = 5.           # smr.py:66
+        self.near, self.far, self.eps = 1., 100., 1e-3   # renderer.py:48-49
+        self.need_p2f = True         # set False to skip the p2f accumulators (callers that discard them)
+
+    def ambient_light_only(self):
+        """smr.py:68-71."""
+        self.light_intensity_ambient = 1
+        self.light_intensity_directional = 0
+
+    def set_bgcolor(self, color):
+        """smr.py:73-74."""
+        self.background_color = list(color)
+
+    def project_points(self, verts, cams):
+        """smr.py:76-78 -> [N,V,2]."""
+        return UF.ProjectPointsFunction.apply(verts, cams, 2, 0.0)
+
+    def _light(self, face_pre):
+        """lighting.py:50-57 (surface mode): ambient + directional * relu(n.d) per face -> [N,F,3]."""
+        col = face_pre.new_tensor(self.light_color)[None, None, :]
+        light = self.light_intensity_ambient * col
+        if self.light_intensity_directional != 0:
+            v10 = face_pre[:, :, 0] - face_pre[:, :, 1]
+            v12 = face_pre[:, :, 2] - face_pre[:, :, 1]
+            n = torch.nn.functional.normalize(torch.cross(v12, v10, dim=2), p=2, dim=2, eps=1e-6)
+            d = face_pre.new_tensor(self.light_direction)[None, None, :]
+            cosine = torch.relu(torch.sum(n * d, dim=2))
+            light = light + self.light_intensity_directional * (col * cosine[:, :, None])
+        return light
+
+    def forward(self, vertices, faces, cams, textures=None):
+        """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
+        textures None | [N,F,TS,3]."""
+        faces = faces.int().contiguous()                                  # smr.py:81
+        directional = self.light_intensity_directional != 0
+        face_pre, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z,
+                                                           directional)
+        N, F = faces.shape[:2]
+        if textures is None:                                              # mesh.py:46-50
+            textures = torch.ones(N, F, 1, 3, dtype=torch.float32, device=vertices.device)
+        if directional:
+            textures = textures * self._light(face_pre)[:, :, None, :]
+        elif self.light_intensity_ambient != 1 or any(c != 1 for c in self.light_color):
+            textures = textures * (self.light_intensity_ambient * textures.new_tensor(self.light_color))
+        size = self.img_size * (2 if self.anti_aliasing else 1)          # rasterizer.py:43
+        return UF.soft_rasterize(face_out, textures, size, self.background_color, self.near, self.far, True,
+                                 self.eps, self.sigma_val, 'euclidean', self.dist_eps, self.gamma_val,
+                                 self.render_type, 'prod', 'surface', pool=self.anti_aliasing,
+                                 need_p2f=self.need_p2f)
