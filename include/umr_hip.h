@@ -33,6 +33,14 @@ extern "C" {
 /* library / build identification: returns e.g. "umr_hip 0.1 gfx950" */
 const char *umr_version(void);
 
+/* Optional kernel timing for benchmarks.  While enabled, every raster main-kernel launch is bracketed by
+ * library-owned HIP events recorded on the launch stream.  umr_profile_collect(which) waits for the
+ * recorded events of `which` (0 = k_raster_forward, 1 = k_raster_backward), returns their summed
+ * duration, the launch count and the summed ALGORITHMIC bytes (SURVEY.md section 8d formulas), and
+ * forgets them. */
+int umr_profile_enable(int on);
+int umr_profile_collect(int which, double *total_ms, long *launches, double *total_bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * Soft rasterizer.  Replaces the pybind module soft_renderer.cuda.soft_rasterize
  *   forward_soft_rasterize   external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda.cpp:62-97

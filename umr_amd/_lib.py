@@ -16,6 +16,9 @@ _Z = ctypes.c_size_t
 
 # name -> argtypes, exactly the prototypes of include/umr_hip.h
 SIGNATURES = {
+    "umr_profile_enable": ([_I], _I),
+    "umr_profile_collect": ([_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),
+                             ctypes.POINTER(ctypes.c_double)], _I),
     "umr_raster_workspace_bytes": ([_I, _I], _Z),
     "umr_raster_forward": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I, _P, _Z, _P], _I),
     "umr_raster_backward": ([_P] * 8 + [_I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P, _Z, _P], _I),
@@ -81,3 +84,14 @@ def check(rc, what):
     if rc != 0:
         raise RuntimeError("umr_amd: %s failed with status %d (%s)" % (
             what, rc, {-1: "rejected arguments / unsupported mode", -2: "kernel launch error"}.get(rc, "?")))
+
+
+def profile_enable(on=True):
+    check(lib().umr_profile_enable(1 if on else 0), "umr_profile_enable")
+
+
+def profile_collect(which):
+    """-> (total_ms, launches, algorithmic_bytes) of the raster forward (0) / backward (1) main kernel."""
+    ms, n, b = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+    check(lib().umr_profile_collect(which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)), "umr_profile_collect")
+    return ms.value, n.value, b.value

@@ -21,6 +21,8 @@
 // scalar_t=float code; the reference's stray double sub-expressions are evaluated in float
 // (differences <= 1 ulp, covered by the 1e-4 parity tolerance).
 #include "umr_common.h"
+#include <mutex>
+#include <vector>
 
 #define REC 40         // floats per preprocessed face record
 #define LIST_CAP 2048  // LDS face list capacity (faces are processed in super-chunks of this many)
@@ -547,11 +549,54 @@ bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_
 
 size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 255) & ~(size_t)255; }
 
+// ---- optional per-kernel timing with library-owned HIP events (umr_profile_*) -------------------
+struct ProfRec { hipEvent_t e0, e1; double bytes; int which; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+
+struct ProfScope {  // brackets exactly one kernel launch on `st`
+    bool on; hipEvent_t e0, e1; hipStream_t st; int which; double bytes;
+    ProfScope(hipStream_t s, int w, double b) : on(g_prof_on), st(s), which(w), bytes(b) {
+        if (on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(e1, st);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof.push_back({e0, e1, bytes, which});
+        }
+    }
+};
+
 }  // namespace
 
 extern "C" {
 
 const char *umr_version(void) { return "umr_hip 0.1 gfx950"; }
+
+int umr_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return UMR_OK;
+}
+
+int umr_profile_collect(int which, double *total_ms, long *launches, double *total_bytes) {
+    if (!total_ms || !launches || !total_bytes) return UMR_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    *total_ms = 0.0; *launches = 0; *total_bytes = 0.0;
+    std::vector<ProfRec> keep;
+    for (const ProfRec &r : g_prof) {
+        if (r.which != which) { keep.push_back(r); continue; }
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            *total_ms += ms; *launches += 1; *total_bytes += r.bytes;
+        }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    g_prof.swap(keep);
+    return UMR_OK;
+}
 
 size_t umr_raster_workspace_bytes(int N, int F) {
     if (N <= 0 || F <= 0) return 0;
@@ -590,8 +635,12 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold));
     const int blocks = N * A.tiles_x * A.tiles_y;
-    if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
-    else k_raster_forward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+    {
+        // algorithmic bytes of one forward launch: 24 IS^2 + F (36 + 12 TS + 16) per mesh
+        ProfScope ps(st, 0, (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
+        if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
+        else k_raster_forward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+    }
     return umr_launch_status();
 }
 
@@ -629,8 +678,14 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold));
     const int blocks = N * A.tiles_x * A.tiles_y;
-    if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
-    else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+    {
+        // algorithmic bytes of one backward launch: per mesh (40 | 28 when the gradient
+        // arrives 2x2-pooled: 4 instead of 16 B/pixel) IS^2 + F (180 + 24 TS)
+        const double px = grad_is_pooled ? 28.0 : 40.0;
+        ProfScope ps(st, 1, (double)N * (px * image_size * image_size + (double)F * (180.0 + 24.0 * TS)));
+        if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
+        else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+    }
     return umr_launch_status();
 }
 

@@ -1,0 +1,121 @@
+"""The render-and-compare part of one UMR training step, as a module.
+
+Mirrors `ShapenetTrainer.forward` of the reference from the point where the network outputs exist
+(experiments/train_s1.py:177-265): the op sequence, detaches and loss weights are the reference's;
+every render / sampling / reduction on the way is a HIP kernel (umr_amd/csrc).  Per image this is
+4 raster forwards (mask :199, texture :217, hard :223, GAN view :235) and 3 raster backwards.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import geom_utils, loss_utils
+from .smr import SoftRenderer
+
+
+class S1Weights:
+    """experiments/train_s1.py:46-56 defaults."""
+    mask_loss_wt = 3.0
+    gan_loss_wt = 1.0
+    triangle_reg_wt = 0.15
+    flatten_reg_wt = 0.0004
+    deform_reg_wt = 5.0
+    ori_reg_wt = 0.4
+    tex_loss_wt = 3.0
+    tex_dt_loss_wt = 3.0
+    tex_cycle_loss_wt = 0.5
+
+
+def rotate_cam_y(cam, angle_deg):
+    """geom_utils.rotate_cam (nnutils/geom_utils.py:167-193) for axis=[0,1,0] without the per-sample
+    numpy / cv2.Rodrigues / host round trip: new_q = q_y(angle) (x) q, on device.
+    cam [B,7] = [s,tx,ty,qw,qx,qy,qz]; angle_deg [B]."""
+    half = angle_deg.to(cam.dtype) * (math.pi / 360.0)
+    rw, ry = torch.cos(half), torch.sin(half)
+    qw, qx, qy, qz = cam[:, 3], cam[:, 4], cam[:, 5], cam[:, 6]
+    # (rw, 0, ry, 0) (x) (qw, qx, qy, qz)
+    nw = rw * qw - ry * qy
+    nx = rw * qx + ry * qz
+    ny = rw * qy + ry * qw
+    nz = rw * qz - ry * qx
+    q = torch.stack([nw, nx, ny, nz], 1)
+    # quaternion_from_matrix(isprecise=True) returns the w>=0 representative of a unit quaternion
+    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    q = torch.where(q[:, :1] < 0, -q, q)
+    return torch.cat([cam[:, :3], q], 1)
+
+
+class RenderCompareS1(nn.Module):
+    """train_s1 render-and-compare: forward(outputs, batch) -> (total_loss, dict of terms).
+
+    outputs: pred_vs [B,V,3], delta_v [B,V',3], cam [B,7], tex_flow [B,F,T,T,2]
+    batch:   imgs [B,3,H,H], masks [B,H,H], dts_barrier [B,1,H,H], gan_angles [B] (degrees)
+    texture_loss: callable(img_pred, img_gt, mask_gt, mask_pred) -> scalar (PerceptualTextureLoss in the
+                  reference, train_s1.py:150); default = loss_utils.texture_loss_masks (L1).
+    discriminator: optional nn.Module taking [2B,1,H,H] masks (train_s1.py:243).
+    """
+
+    def __init__(self, template_verts, faces, image_size=256, renderer_type="softmax", weights=None,
+                 texture_loss=None, discriminator=None, epoch=0):
+        super().__init__()
+        self.w = weights or S1Weights()
+        self.image_size = image_size
+        self.register_buffer("faces", faces.long())
+        self.renderer = SoftRenderer(image_size, renderer_type)            # train_s1.py:105
+        self.dis_renderer = SoftRenderer(image_size, renderer_type)        # :106
+        self.hard_renderer = SoftRenderer(image_size, "hard")              # :107
+        self.tex_renderer = SoftRenderer(image_size, renderer_type)        # :109-110
+        self.tex_renderer.ambient_light_only()
+        # outputs nobody reads are not computed: only tex_renderer's p2f is consumed (:226)
+        self.renderer.need_p2f = False
+        self.dis_renderer.need_p2f = False
+        self.laplacian_loss_fn = loss_utils.LaplacianLoss(template_verts, faces)   # :141
+        self.flatten_loss_fn = loss_utils.FlattenLoss(faces)                       # :142
+        self.texture_cycle_fn = loss_utils.TexCycle()
+        self.texture_loss = texture_loss or loss_utils.texture_loss_masks
+        self.discriminator = discriminator
+        self.epoch = epoch
+
+    def forward(self, outputs, batch):
+        w = self.w
+        pred_vs, delta_v, proj_cam, tex_flow = outputs["pred_vs"], outputs["delta_v"], outputs["cam"], outputs["tex_flow"]
+        imgs, masks, dts = batch["imgs"], batch["masks"], batch["dts_barrier"]
+        B = pred_vs.shape[0]
+        faces = self.faces[None].expand(B, -1, -1)
+        terms = {}
+        # shape losses (:199-206)
+        pred_seen, _, _ = self.renderer(pred_vs, faces, proj_cam)
+        mask_pred_seen = pred_seen[:, 3]
+        terms["mask"] = loss_utils.neg_iou_loss(mask_pred_seen, masks)
+        terms["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
+        terms["flatten"] = self.flatten_loss_fn(pred_vs).mean()
+        terms["deform"] = loss_utils.deform_l2reg(delta_v)
+        terms["ori"] = loss_utils.sym_reg(pred_vs)
+        # texture losses (:209-230)
+        tex = geom_utils.sample_textures(tex_flow, imgs)
+        bs, fs = tex.shape[:2]
+        tex = tex.reshape(bs, fs, -1, 3)
+        texture_rgba, p2f_info, _ = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex)
+        texture_pred = texture_rgba[:, 0:3]
+        terms["tex"] = self.texture_loss(texture_pred, imgs, masks, mask_pred_seen)
+        terms["tex_dt"] = loss_utils.texture_dt_loss(tex_flow, dts)
+        _, _, aggr_info = self.hard_renderer(pred_vs.detach(), faces, proj_cam.detach())
+        aggr_ids = aggr_info[:, 1].reshape(bs, -1)
+        tex_cycle, _ = self.texture_cycle_fn(tex_flow, p2f_info.detach(), aggr_ids.detach())
+        terms["tex_cycle"] = tex_cycle
+        # unseen-view render for the adversarial term (:232-245)
+        random_cams = rotate_cam_y(proj_cam.detach(), batch["gan_angles"])
+        pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, random_cams)
+        if self.discriminator is not None:
+            pred = torch.cat((pred_seen.detach(), pred_unseen))
+            labels = torch.cat((torch.ones(B, device=pred.device), torch.zeros(B, device=pred.device)))
+            gan_preds = self.discriminator(pred[:, 3].unsqueeze(1))
+            terms["gan"] = nn.functional.binary_cross_entropy_with_logits(gan_preds.view(-1), labels)
+        else:  # keep the render + its backward in the step even without a discriminator network
+            terms["gan"] = pred_unseen[:, 3].mean()
+        total = terms["mask"] * w.mask_loss_wt + terms["triangle"] * w.triangle_reg_wt \
+            + terms["flatten"] * w.flatten_reg_wt + terms["ori"] * w.ori_reg_wt + terms["deform"] * w.deform_reg_wt \
+            + terms["tex"] * w.tex_loss_wt + terms["tex_dt"] * w.tex_dt_loss_wt \
+            + terms["tex_cycle"] * w.tex_cycle_loss_wt + terms["gan"] * w.gan_loss_wt
+        return total, terms
