@@ -39,6 +39,9 @@ const char *umr_version(void);
  * duration, the launch count and the summed ALGORITHMIC bytes (SURVEY.md section 8d formulas), and
  * forgets them. */
 int umr_profile_enable(int on);
+/* A/B switches for benchmarking kernel variants ("bwd_pixel_major": 1 selects the tile-binned
+ * pixel-major backward with global atomics instead of the default face-major one). */
+int umr_debug_set(const char *key, int value);
 int umr_profile_collect(int which, double *total_ms, long *launches, double *total_bytes);
 
 /* ---------------------------------------------------------------------------------------------

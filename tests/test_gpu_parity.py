@@ -311,3 +311,48 @@ def test_train_s1_step_vs_oracle(oracle_built):
         r = out_c[k].grad.numpy()
         s = np.abs(r).max()
         assert_close_frac(t2n(out_g[k].grad), r, atol=3e-4 * s, rtol=5e-3, frac=0.98, name="grad_" + k)
+
+
+@pytest.mark.parametrize("name", RASTER)
+def test_backward_variants_agree(name):
+    """Face-major (default) and pixel-major (tile-binned, atomics) backward kernels: same gradients."""
+    from umr_amd import _lib
+    g = load_golden(name)
+    try:
+        _lib.debug_set("bwd_pixel_major", 1)
+        a = _raw_raster(g)
+    finally:
+        _lib.debug_set("bwd_pixel_major", 0)
+    b = _raw_raster(g)
+    for k in ("grad_faces", "grad_textures"):
+        s = max(float(a[k].abs().max()), 1e-12)
+        assert float((a[k] - b[k]).abs().max()) <= 1e-4 * s, k
+    sf = np.abs(g["grad_faces"]).max()
+    assert_close_frac(t2n(a["grad_faces"]), g["grad_faces"], atol=1e-4 * sf, rtol=2e-3, frac=0.99, name="pm grad_faces")
+
+
+def test_face_major_backward_non_pow2_and_determinism():
+    """IS not a power of two exercises the fp64 pixel-centre path; face-major results are run-to-run identical."""
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(2, 2, seed=21)
+    _, fv = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    tex = torch.rand(2, 320, 4, 3, generator=gen).to(DEV)
+    g = torch.randn(2, 4, 100, 100, generator=gen).to(DEV)
+
+    def run():
+        f = fv.detach().clone().requires_grad_(True)
+        t = tex.clone().requires_grad_(True)
+        sc, _, _ = UF.soft_rasterize(f, t, 100, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
+        sc.backward(g)
+        return sc.detach(), f.grad, t.grad
+    a, b = run(), run()
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    from oracle import softras
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4,
+               func_id_rgb=1, double_side=True)
+    o = softras.raster_forward(t2n(fv), t2n(tex), 100, n_threads=4, **cfg)
+    gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                     t2n(g), 100, n_threads=4, **cfg)
+    assert_close_frac(t2n(a[0]), o["soft_colors"], atol=1e-4, frac=0.999, name="soft_colors")
+    assert_close_frac(t2n(a[1]).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
+    assert_close_frac(t2n(a[2]), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="gt")

@@ -17,6 +17,7 @@ _Z = ctypes.c_size_t
 # name -> argtypes, exactly the prototypes of include/umr_hip.h
 SIGNATURES = {
     "umr_profile_enable": ([_I], _I),
+    "umr_debug_set": ([ctypes.c_char_p, _I], _I),
     "umr_profile_collect": ([_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),
                              ctypes.POINTER(ctypes.c_double)], _I),
     "umr_raster_workspace_bytes": ([_I, _I], _Z),
@@ -95,3 +96,7 @@ def profile_collect(which):
     ms, n, b = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
     check(lib().umr_profile_collect(which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)), "umr_profile_collect")
     return ms.value, n.value, b.value
+
+
+def debug_set(key, value):
+    check(lib().umr_debug_set(key.encode(), int(value)), "umr_debug_set(%s)" % key)

@@ -22,15 +22,25 @@
 // (differences <= 1 ulp, covered by the 1e-4 parity tolerance).
 #include "umr_common.h"
 #include <mutex>
+#include <string>
 #include <vector>
 
-#define REC 40         // floats per preprocessed face record
+#define REC 64         // floats per preprocessed face record
 #define LIST_CAP 2048  // LDS face list capacity (faces are processed in super-chunks of this many)
 #define BLK_W 32
 #define BLK_H 16
 #define BLK_THREADS 512
 
 namespace {
+
+// Record layout (floats) written by k_face_setup: 256 bytes per face.
+//   [0,32)  wave-uniform part, fetched with 2 x s_load_dwordx16 into SGPRs
+//   [32,56) three 32-byte edge blocks {a0, a1, a2, a[v1], den, RN(1/den), -, -}; a lane reads ONLY the block
+//           of its nearest edge (per-lane address, 2 x global_load_dwordx4, L1-resident)
+enum { R_XLO = 0, R_XHI = 1, R_YLO = 2, R_YHI = 3, R_X0 = 4, R_Y0 = 5, R_X1 = 6, R_Y1 = 7, R_X2 = 8, R_Y2 = 9,
+       R_Z0 = 10, R_Z1 = 11, R_Z2 = 12, R_RZ0 = 13, R_RZ1 = 14, R_RZ2 = 15,
+       R_INV = 16, R_K0 = 25, R_K1 = 26, R_K2 = 27, R_FLAGS = 28, R_FRONT = 29, R_OX = 30, R_OY = 31,
+       R_EDGE = 32 };
 
 struct RasterArgs {
     const float4 *bbox;   // [N*F] (xlo, xhi, ylo, yhi) = bbox dilated by sqrt(threshold)
@@ -48,6 +58,9 @@ struct RasterArgs {
     float *grad_textures;
     int N, F, IS, TS, R;
     float near_, far_, eps, sigma, threshold, gamma;
+    float nis;        // -1/sigma
+    float r_range;    // RN(1/(far-near))
+    float inv_gamma;
     int double_side, with_p2f, grad_pooled, need_gf, need_gt;
     int tiles_x, tiles_y;
 };
@@ -88,143 +101,182 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     const float xlo = fminf(fminf(x0, x1), x2) - thr, xhi = fmaxf(fmaxf(x0, x1), x2) + thr;
     const float ylo = fminf(fminf(y0, y1), y2) - thr, yhi = fmaxf(fmaxf(y0, y1), y2) + thr;
     bbox[i] = make_float4(xlo, xhi, ylo, yhi);
+    // ---- packed record: three 64-byte lines, fetched by the raster kernels with 3 x s_load_dwordx16 ----
     float *r = rec + (size_t)i * REC;
-    r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi;
-    r[4] = x0; r[5] = y0; r[6] = z0; r[7] = x1; r[8] = y1; r[9] = z1; r[10] = x2; r[11] = y2; r[12] = z2;
+    r[R_XLO] = xlo; r[R_XHI] = xhi; r[R_YLO] = ylo; r[R_YHI] = yhi;
+    r[R_X0] = x0; r[R_Y0] = y0; r[R_X1] = x1; r[R_Y1] = y1; r[R_X2] = x2; r[R_Y2] = y2;
+    r[R_Z0] = z0; r[R_Z1] = z1; r[R_Z2] = z2;
+    r[R_RZ0] = 1.f / z0; r[R_RZ1] = 1.f / z1; r[R_RZ2] = 1.f / z2;  // correctly rounded (Markstein division)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) r[13 + k] = inv[k];
-    // edge e = (e, e+1 mod 3): a_e[j] = sym[e][j] - sym[e+1][j] (:82-84), den_e = a_e[e] - a_e[e+1] (:86)
+    for (int k = 0; k < 9; ++k) r[R_INV + k] = inv[k];
+    // squared height of corner c over its opposite edge: inside the triangle the squared distance to that
+    // edge's line is w_c^2 K_c -- used only to PICK the nearest edge (:99), the distance itself is then
+    // evaluated with the reference's own formula
+    const float det_raw = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int a = (c + 1) % 3, b = (c + 2) % 3;
+        const float ex = px[a] - px[b], ey = py[a] - py[b];
+        r[R_K0 + c] = det_raw * det_raw / fmaxf(ex * ex + ey * ey, 1e-30f);
+    }
+    // depth chain may use reciprocal-multiply division only when every z is an ordinary positive number
+    const bool sane = z0 > 1e-20f && z1 > 1e-20f && z2 > 1e-20f && z0 < 1e20f && z1 < 1e20f && z2 < 1e20f;
+    r[R_FLAGS] = __int_as_float((obt + 1) | (sane ? 0 : 4));  // bits 0-1: obtuse corner + 1 (0 = none); bit 2: slow
+    r[R_FRONT] = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1.f : 0.f;  // :42-44
+    // vector of the obtuse-corner override test (:116,:119,:122): corner k -> p_{k+2} - p_k
+    const int ob = obt < 0 ? 0 : obt;
+    r[R_OX] = px[(ob + 2) % 3] - px[ob];
+    r[R_OY] = py[(ob + 2) % 3] - py[ob];
+    // edge e = (e, e+1): a_e[j] = sym[e][j] - sym[e+1][j] (:82-84,:133-135); den_e = a_e[e] - a_e[e+1]
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         const int e1 = (e + 1) % 3;
         float a[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { a[j] = sym[3 * e + j] - sym[3 * e1 + j]; r[22 + 3 * e + j] = a[j]; }
-        r[31 + e] = a[e] - a[e1];
+        for (int j = 0; j < 3; ++j) a[j] = sym[3 * e + j] - sym[3 * e1 + j];
+        const float den = a[e] - a[e1];
+        float *eb = r + R_EDGE + 8 * e;
+        eb[0] = a[0]; eb[1] = a[1]; eb[2] = a[2]; eb[3] = a[e1];
+        eb[4] = den; eb[5] = 1.f / den; eb[6] = 0.f; eb[7] = 0.f;
     }
-    r[34] = __int_as_float(obt);
-    // (f7-f1)*(f3-f0) < (f4-f1)*(f6-f0)  (:42-44)
-    r[35] = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1.f : 0.f;
-    r[36] = r[37] = r[38] = r[39] = 0.f;
+#pragma unroll
+    for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
 }
 
 __device__ __forceinline__ float ndc_coord(int i, int IS) {  // (2i + 1 - IS) / IS, evaluated in double (:325-326)
     return (float)((2.0 * i + 1.0 - IS) / IS);
 }
 
-struct Face {  // wave-uniform
-    float xlo, xhi, ylo, yhi;
-    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
-    float inv[9];
-    float a[9];
-    float den[3];
-    int obt;
-    int front;
+// Same value without fp64 when IS is a power of two (every BASELINE config): 2i+1-IS is an exact small
+// integer and the division is an exponent shift, so float arithmetic is exact -- provably identical bits.
+__device__ __forceinline__ float ndc_coord_fast(int i, int IS, float inv_is, bool pow2) {
+    return pow2 ? (float)(2 * i + 1 - IS) * inv_is : ndc_coord(i, IS);
+}
+
+// The record address is wave-uniform (face id comes from v_readlane / the wave id); reading it through the
+// constant address space makes the backend emit s_load_dwordx16 (scalar cache, SGPR operands) instead of
+// 64-lane broadcast vector loads.  Three explicit 64-byte vector loads issue back to back and are waited for
+// once.  Safe: the records are written by k_face_setup in an EARLIER launch.
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) v16f cv16f_t;
+
+struct Face {  // wave-uniform: 32 SGPRs + the record's address
+    v16f qa, qb;
+    const float4 *edges;  // three 32-byte edge blocks (global memory, read per lane)
+    template <int I> __device__ __forceinline__ float g() const {
+        if constexpr (I < 16) return qa[I];
+        else return qb[I - 16];
+    }
+    __device__ __forceinline__ int obt() const { return (__float_as_int(g<R_FLAGS>()) & 3) - 1; }
+    __device__ __forceinline__ bool front() const { return g<R_FRONT>() != 0.f; }
+    __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
 };
 
-// The record address is wave-uniform (face id comes from v_readlane); reading it through the constant
-// address space makes the backend emit s_load_dwordx* (scalar cache, SGPR operands) instead of 64-lane
-// broadcast vector loads.  Safe: the records are written by k_face_setup in an EARLIER launch.
-typedef const __attribute__((address_space(4))) float cfloat_t;
-
 __device__ __forceinline__ void load_face(Face &fc, const float *rg) {
-    cfloat_t *r = (cfloat_t *)rg;
-    fc.xlo = r[0]; fc.xhi = r[1]; fc.ylo = r[2]; fc.yhi = r[3];
-    fc.x0 = r[4]; fc.y0 = r[5]; fc.z0 = r[6]; fc.x1 = r[7]; fc.y1 = r[8]; fc.z1 = r[9];
-    fc.x2 = r[10]; fc.y2 = r[11]; fc.z2 = r[12];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { fc.inv[k] = r[13 + k]; fc.a[k] = r[22 + k]; }
-    fc.den[0] = r[31]; fc.den[1] = r[32]; fc.den[2] = r[33];
-    fc.obt = __float_as_int(r[34]);
-    fc.front = r[35] != 0.f;
+    cv16f_t *r = (cv16f_t *)rg;
+    fc.qa = r[0]; fc.qb = r[1];
+    fc.edges = (const float4 *)(rg + R_EDGE);
 }
 
 struct Pair {  // per-lane result of the pixel/face geometry
     float w0, w1, w2;   // unclipped barycentrics
-    float t0, t1, t2;   // (closest-point barycentric) - w
+    float b0, b1, b2;   // barycentrics of the closest boundary point (the reference's t + w, :640)
     float dx, dy, sign, frag;
 };
+
+// RN(1/b) for ordinary b: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_nr(float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r, 1.f), r, r);
+}
+// a/b given r ~ RN(1/b): Markstein's correction -> correctly rounded quotient for ordinary operands
+__device__ __forceinline__ float div_r(float a, float b, float r) {
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+}
 
 // bbox reject (:355), barycentric (:25-29), euclidean distance (:63-152), threshold reject (:382),
 // sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
 __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, float yp, float threshold,
-                                          float sigma) {
-    if (xp > fc.xhi || xp < fc.xlo || yp > fc.yhi || yp < fc.ylo) return false;
-    const float w0 = fc.inv[0] * xp + fc.inv[1] * yp + fc.inv[2];
-    const float w1 = fc.inv[3] * xp + fc.inv[4] * yp + fc.inv[5];
-    const float w2 = fc.inv[6] * xp + fc.inv[7] * yp + fc.inv[8];
+                                          float neg_inv_sigma) {
+    if (xp > fc.g<R_XHI>() || xp < fc.g<R_XLO>() || yp > fc.g<R_YHI>() || yp < fc.g<R_YLO>()) return false;
+    // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
+    // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
+    const float w0 = (fc.g<R_INV + 0>() * xp + fc.g<R_INV + 1>() * yp) + fc.g<R_INV + 2>();
+    const float w1 = (fc.g<R_INV + 3>() * xp + fc.g<R_INV + 4>() * yp) + fc.g<R_INV + 5>();
+    const float w2 = (fc.g<R_INV + 6>() * xp + fc.g<R_INV + 7>() * yp) + fc.g<R_INV + 8>();
     p.w0 = w0; p.w1 = w1; p.w2 = w2;
-    // line parameter of the projection on each edge line: tq_e = tau for edge (e, e+1)
-    const float tq0 = (w0 * fc.a[0] + w1 * fc.a[1] + w2 * fc.a[2] - fc.a[1]) / fc.den[0];
-    const float tq1 = (w0 * fc.a[3] + w1 * fc.a[4] + w2 * fc.a[5] - fc.a[5]) / fc.den[1];
-    const float tq2 = (w0 * fc.a[6] + w1 * fc.a[7] + w2 * fc.a[8] - fc.a[6]) / fc.den[2];
-    float t0, t1, t2, dx, dy, sign;
-    if (w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1) {
-        float best = 100000000.f;
-        dx = 0.f; dy = 0.f; t0 = t1 = t2 = 0.f;
-        {   // edge (0,1): beta = (tq0, 1 - tq0, 0), unclamped (:78-107)
-            const float u0 = tq0 - w0, u1 = (1 - tq0) - w1, u2 = 0 - w2;
-            const float ex = u0 * fc.x0 + u1 * fc.x1 + u2 * fc.x2, ey = u0 * fc.y0 + u1 * fc.y1 + u2 * fc.y2;
-            const float d = ex * ex + ey * ey;
-            if (d < best) { best = d; dx = ex; dy = ey; t0 = u0; t1 = u1; t2 = u2; }
-        }
-        {   // edge (1,2): beta = (0, tq1, 1 - tq1)
-            const float u0 = 0 - w0, u1 = tq1 - w1, u2 = (1 - tq1) - w2;
-            const float ex = u0 * fc.x0 + u1 * fc.x1 + u2 * fc.x2, ey = u0 * fc.y0 + u1 * fc.y1 + u2 * fc.y2;
-            const float d = ex * ex + ey * ey;
-            if (d < best) { best = d; dx = ex; dy = ey; t0 = u0; t1 = u1; t2 = u2; }
-        }
-        {   // edge (2,0): beta = (1 - tq2, 0, tq2)
-            const float u0 = (1 - tq2) - w0, u1 = 0 - w1, u2 = tq2 - w2;
-            const float ex = u0 * fc.x0 + u1 * fc.x1 + u2 * fc.x2, ey = u0 * fc.y0 + u1 * fc.y1 + u2 * fc.y2;
-            const float d = ex * ex + ey * ey;
-            if (d < best) { best = d; dx = ex; dy = ey; t0 = u0; t1 = u1; t2 = u2; }
-        }
-        sign = 1.f;
+    const bool inside = w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1;
+    int k;  // nearest boundary edge (k, k+1)
+    if (inside) {
+        // nearest edge LINE: first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
+        // corner k+2 and its squared distance is w_c^2 K_c
+        const float m0 = w2 * w2 * fc.g<R_K2>(), m1 = w0 * w0 * fc.g<R_K0>(), m2 = w1 * w1 * fc.g<R_K1>();
+        k = 0;
+        float best = m0;
+        if (m1 < best) { best = m1; k = 1; }
+        if (m2 < best) { k = 2; }
     } else {
-        int v0 = -1;  // region selection (:112-126)
-        if (w1 <= 0 && w2 <= 0) {
-            v0 = 0;
-            if (fc.obt == 0 && (xp - fc.x0) * (fc.x2 - fc.x0) + (yp - fc.y0) * (fc.y2 - fc.y0) > 0) v0 = 2;
-        } else if (w2 <= 0 && w0 <= 0) {
-            v0 = 1;
-            if (fc.obt == 1 && (xp - fc.x1) * (fc.x0 - fc.x1) + (yp - fc.y1) * (fc.y0 - fc.y1) > 0) v0 = 0;
-        } else if (w0 <= 0 && w1 <= 0) {
-            v0 = 2;
-            if (fc.obt == 2 && (xp - fc.x2) * (fc.x1 - fc.x2) + (yp - fc.y2) * (fc.y1 - fc.y2) > 0) v0 = 1;
-        } else if (w0 <= 0) v0 = 1;
-        else if (w1 <= 0) v0 = 2;
-        else if (w2 <= 0) v0 = 0;
-        if (v0 < 0) return false;  // reference UB (index -1); defined here and in the oracle as "skip"
-        const float tv = v0 == 0 ? tq0 : (v0 == 1 ? tq1 : tq2);
-        const float c0 = fminf(fmaxf(tv, 0.f), 1.f);        // beta_{v0}
-        const float c1 = fminf(fmaxf(1 - tv, 0.f), 1.f);    // beta_{v0+1}
-        const float b0 = v0 == 0 ? c0 : (v0 == 1 ? 0.f : c1);
-        const float b1 = v0 == 0 ? c1 : (v0 == 1 ? c0 : 0.f);
-        const float b2 = v0 == 0 ? 0.f : (v0 == 1 ? c1 : c0);
-        t0 = b0 - w0; t1 = b1 - w1; t2 = b2 - w2;
-        dx = t0 * fc.x0 + t1 * fc.x1 + t2 * fc.x2;
-        dy = t0 * fc.y0 + t1 * fc.y1 + t2 * fc.y2;
-        sign = -1.f;
+        // region selection (:112-126)
+        const int ob = fc.obt();
+        const float cx = ob == 0 ? fc.g<R_X0>() : (ob == 1 ? fc.g<R_X1>() : fc.g<R_X2>());
+        const float cy = ob == 0 ? fc.g<R_Y0>() : (ob == 1 ? fc.g<R_Y1>() : fc.g<R_Y2>());
+        const bool ovr = (xp - cx) * fc.g<R_OX>() + (yp - cy) * fc.g<R_OY>() > 0;
+        k = -1;
+        if (w1 <= 0 && w2 <= 0) k = (ob == 0 && ovr) ? 2 : 0;
+        else if (w2 <= 0 && w0 <= 0) k = (ob == 1 && ovr) ? 0 : 1;
+        else if (w0 <= 0 && w1 <= 0) k = (ob == 2 && ovr) ? 1 : 2;
+        else if (w0 <= 0) k = 1;
+        else if (w1 <= 0) k = 2;
+        else if (w2 <= 0) k = 0;
+        if (k < 0) return false;  // reference UB (index -1); defined here and in the oracle as "skip"
     }
+    // t[v0] = (w . a - a[v1]) / (a[v0] - a[v1]) in the reference's operation order (:86,:137); IEEE-exact
+    // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
+    // D ~ exp(-d^2/sigma) ~ 1e-9, amplifying rounding noise in d^2 ~20x: parity there needs the reference's
+    // own noise, i.e. its own arithmetic, not just the same formula.
+    const float4 ea = fc.edges[2 * k], eb = fc.edges[2 * k + 1];  // {a0,a1,a2,a[v1]}, {den, 1/den, -, -}
+    const float tv = div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
+    const bool k0 = k == 0, k1 = k == 1;
+    float ba = tv, bb = 1.f - tv;  // unclamped inside (:86-88)
+    if (!inside) { ba = fminf(fmaxf(ba, 0.f), 1.f); bb = fminf(fmaxf(bb, 0.f), 1.f); }  // :142-145
+    const float b0 = k0 ? ba : (k1 ? 0.f : bb);
+    const float b1 = k0 ? bb : (k1 ? ba : 0.f);
+    const float b2 = k0 ? 0.f : (k1 ? bb : ba);
+    const float t0 = b0 - w0, t1 = b1 - w1, t2 = b2 - w2;
+    const float dx = (t0 * fc.g<R_X0>() + t1 * fc.g<R_X1>()) + t2 * fc.g<R_X2>();  // :95-96, :148-149
+    const float dy = (t0 * fc.g<R_Y0>() + t1 * fc.g<R_Y1>()) + t2 * fc.g<R_Y2>();
     const float dis = dx * dx + dy * dy;
-    if (sign < 0 && dis >= threshold) return false;
-    p.t0 = t0; p.t1 = t1; p.t2 = t2; p.dx = dx; p.dy = dy; p.sign = sign;
-    p.frag = 1.f / (1.f + __expf(-sign * dis / sigma));
+    if (!inside && dis >= threshold) return false;
+    p.b0 = b0; p.b1 = b1; p.b2 = b2; p.dx = dx; p.dy = dy;
+    p.sign = inside ? 1.f : -1.f;
+    // 1 / (1 + exp(-sign * dis / sigma))
+    const float e = __expf((inside ? dis : -dis) * neg_inv_sigma);
+    p.frag = __builtin_amdgcn_rcpf(1.f + e);
     return true;
 }
 
-// barycentric_clip (:54-59) + perspective-correct depth (:403)
+// barycentric_clip (:54-59) + perspective-correct depth (:403).  The soft-max weights are exp(zn/gamma) with
+// gamma = 1e-4: one ulp of zn moves a weight by ~7e-4, so this chain reproduces the reference's IEEE
+// divisions to the last bit (Markstein-corrected reciprocal multiplies; plain IEEE when z is degenerate).
 __device__ __forceinline__ float clip_depth(float &c0, float &c1, float &c2, const Pair &p, const Face &fc) {
     c0 = fmaxf(fminf(p.w0, 1.f - 1e-5f), 1e-5f);
     c1 = fmaxf(fminf(p.w1, 1.f - 1e-5f), 1e-5f);
     c2 = fmaxf(fminf(p.w2, 1.f - 1e-5f), 1e-5f);
     const float s = fmaxf(c0 + c1 + c2, 1e-5f);
-    c0 /= s; c1 /= s; c2 /= s;
-    return 1.f / (c0 / fc.z0 + c1 / fc.z1 + c2 / fc.z2);
+    if (fc.slow()) {
+        c0 /= s; c1 /= s; c2 /= s;
+        return 1.f / (c0 / fc.g<R_Z0>() + c1 / fc.g<R_Z1>() + c2 / fc.g<R_Z2>());
+    }
+    const float rs = rcp_nr(s);
+    c0 = div_r(c0, s, rs); c1 = div_r(c1, s, rs); c2 = div_r(c2, s, rs);
+    const float x = (div_r(c0, fc.g<R_Z0>(), fc.g<R_RZ0>()) + div_r(c1, fc.g<R_Z1>(), fc.g<R_RZ1>())) + div_r(c2, fc.g<R_Z2>(), fc.g<R_RZ2>());
+    const float rx = rcp_nr(x);
+    return fmaf(fmaf(-x, rx, 1.f), rx, rx);
 }
 
 __device__ __forceinline__ int texel_index(float c0, float c1, int R) {  // :180-189
+    if (R == 1) return 0;
     const int wx = (int)(c0 * R), wy = (int)(c1 * R);
     if ((c0 + c1) * R - wx - wy <= 1) return wy * R + wx;
     return (R - 1 - wy) * R + (R - 1 - wx);
@@ -349,27 +401,27 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                 load_face(fc, rec_n + (size_t)f * REC);
                 float wgt = 0.f;  // this lane's p2f weight for face f
                 Pair p;
-                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.sigma)) {
+                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis)) {
                     alpha *= 1.f - p.frag;  // 'prod' alpha (:396), BEFORE the depth-range test
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
                     if (!(zp < A.near_ || zp > A.far_)) {
                         if (RGB == 0) {
                             const bool inside = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
-                            if (zp < depth_min && inside && (A.double_side || fc.front)) {
+                            if (zp < depth_min && inside && (A.double_side || fc.front())) {
                                 depth_min = zp;
                                 face_min = f;
                                 const float *tx = tex_n + ((size_t)f * A.TS + texel_index(q0, q1, A.R)) * 3;
                                 c0 = tx[0]; c1 = tx[1]; c2 = tx[2];
                             }
-                        } else if (fc.front || A.double_side) {
-                            const float zn = (A.far_ - zp) / (A.far_ - A.near_);
+                        } else if (fc.front() || A.double_side) {
+                            const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
                             float rescale = 1.f;
                             if (zn > smax) {
-                                rescale = __expf((smax - zn) / A.gamma);
+                                rescale = __expf((smax - zn) * A.inv_gamma);
                                 smax = zn;
                             }
-                            const float ez = __expf((zn - smax) / A.gamma);
+                            const float ez = __expf((zn - smax) * A.inv_gamma);
                             ssum = rescale * ssum + ez * p.frag;
                             wgt = ez * p.frag;
                             const float *tx = tex_n + ((size_t)f * A.TS + texel_index(q0, q1, A.R)) * 3;
@@ -476,8 +528,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                 int tix = 0;
                 bool contrib = false;
                 Pair p;
-                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.sigma)) {
-                    float c_xy = g3 * ((1.f - oa) / fmaxf(1.f - p.frag, 1e-6f));  // :584
+                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis)) {
+                    float c_xy = g3 * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
                     if (!(zp < A.near_ || zp > A.far_)) {  // :592 -- drops the alpha term as well
@@ -487,9 +539,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                                 tix = texel_index(q0, q1, A.R);
                                 gt0 = g0; gt1 = g1; gt2 = g2;
                             }
-                        } else if (fc.front || A.double_side) {
-                            const float zn = (A.far_ - zp) / (A.far_ - A.near_);
-                            const float ps = p.frag * __expf((zn - smax) / A.gamma) / ssum;  // :608
+                        } else if (fc.front() || A.double_side) {
+                            const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
+                            const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
                             tix = texel_index(q0, q1, A.R);
                             const float *tx = tex_n + ((size_t)f * TS + tix) * 3;
                             gt0 = ps * g0; gt1 = ps * g1; gt2 = ps * g2;
@@ -497,15 +549,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                             c_rgb += g1 * (tx[1] - oc1);
                             c_rgb += g2 * (tx[2] - oc2);
                             c_rgb *= ps;
-                            c_xy += c_rgb / p.frag;
-                            const float c_z = c_rgb / A.gamma / (A.near_ - A.far_) * zp * zp;  // :624
-                            gv[2] = c_z * q0 / fc.z0 / fc.z0;
-                            gv[5] = c_z * q1 / fc.z1 / fc.z1;
-                            gv[8] = c_z * q2 / fc.z2 / fc.z2;
+                            c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
+                            const float c_z = -(c_rgb * A.inv_gamma * A.r_range) * zp * zp;  // :624
+                            gv[2] = c_z * q0 * fc.g<R_RZ0>() * fc.g<R_RZ0>();
+                            gv[5] = c_z * q1 * fc.g<R_RZ1>() * fc.g<R_RZ1>();
+                            gv[8] = c_z * q2 * fc.g<R_RZ2>() * fc.g<R_RZ2>();
                         }
-                        c_xy *= p.frag * (1.f - p.frag) / A.sigma;  // :632
+                        c_xy *= p.frag * (1.f - p.frag) * (-A.nis);  // :632
                         const float k2 = 2.f * p.sign * c_xy;        // :640
-                        const float b0 = k2 * (p.t0 + p.w0), b1 = k2 * (p.t1 + p.w1), b2 = k2 * (p.t2 + p.w2);
+                        const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
                         gv[0] = b0 * p.dx; gv[1] = b0 * p.dy;
                         gv[3] = b1 * p.dx; gv[4] = b1 * p.dy;
                         gv[6] = b2 * p.dx; gv[7] = b2 * p.dy;
@@ -537,6 +589,150 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Face-major backward.  Given the saved per-pixel forward state, every (pixel, face) contribution to
+// the gradient is independent (:531-655), so the loop nest can be turned inside out: ONE WAVEFRONT PER
+// FACE walks the 8x8 pixel tiles under that face's dilated bounding box, accumulates the 9 vertex
+// gradients in registers (texel gradients in a per-wave LDS array) across all tiles, reduces across the
+// 64 lanes ONCE and stores.  No global atomics, no per-(tile, face) reduction, deterministic results; the
+// face record lives in SGPRs for the whole walk.  Per-pixel state is re-read once per overlapping face
+// (~6x, L1/L2 hits: consecutive faces of a subdivided mesh are spatial neighbours and share a workgroup).
+#define FM_WAVES 4
+template <int RGB, bool NEED_GF, bool NEED_GT>
+__global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][TS*3]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int F = A.F, IS = A.IS, TS = A.TS;
+    const long fid = (long)blockIdx.x * FM_WAVES + wave;          // (n, f) flattened
+    const bool live = fid < (long)A.N * F;
+    const int n = live ? (int)(fid / F) : 0, f = live ? (int)(fid % F) : 0;
+    const size_t npix = (size_t)IS * IS;
+    float *my_tex = s_tex + (size_t)wave * TS * 3;
+    if (NEED_GT && TS > 1)
+        for (int j = lane; j < TS * 3; j += 64) my_tex[j] = 0.f;
+    float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // TS == 1 texel gradient
+    if (live) {
+        Face fc;
+        load_face(fc, A.rec + ((size_t)n * F + f) * REC);
+        const float *__restrict__ tex_f = A.textures + ((size_t)n * F + f) * TS * 3;
+        // pixel-index window of the dilated bbox, widened by one pixel; the exact per-pixel reject of the
+        // reference (:536) still runs inside eval_pair, so the window only has to be conservative.
+        // xp(i) = (2i + 1 - IS)/IS  <=>  i = (xp*IS + IS - 1)/2
+        const float h = 0.5f * IS;
+        int x0 = (int)floorf(fc.g<R_XLO>() * h + h - 0.5f) - 1, x1 = (int)ceilf(fc.g<R_XHI>() * h + h - 0.5f) + 1;
+        int yi0 = (int)floorf(fc.g<R_YLO>() * h + h - 0.5f) - 1, yi1 = (int)ceilf(fc.g<R_YHI>() * h + h - 0.5f) + 1;
+        // NaN / inf bounds: comparisons below fail safe to the full image (the reference would visit all pixels)
+        if (!(fc.g<R_XLO>() == fc.g<R_XLO>() && fc.g<R_XHI>() == fc.g<R_XHI>() && fc.g<R_YLO>() == fc.g<R_YLO>() && fc.g<R_YHI>() == fc.g<R_YHI>())) { x0 = 0; x1 = IS - 1; yi0 = 0; yi1 = IS - 1; }
+        x0 = max(x0, 0); x1 = min(x1, IS - 1); yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
+        const int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;  // row = IS-1-yi
+        if (x0 <= x1 && r0 <= r1) {
+            const int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = r0 >> 3, ty1 = r1 >> 3;
+            const bool pow2 = (IS & (IS - 1)) == 0;
+            const float inv_is = 1.f / (float)IS;
+            for (int ty = ty0; ty <= ty1; ++ty) {
+                const int row = ty * 8 + (lane >> 3);
+                const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const int xi = tx * 8 + (lane & 7);
+                    if (xi >= IS || row >= IS) continue;
+                    const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                    Pair p;
+                    if (!eval_pair(p, fc, xp, yp, A.threshold, A.nis)) continue;
+                    const size_t pn = (size_t)row * IS + xi;
+                    float g0, g1, g2, g3;
+                    if (A.grad_pooled) {
+                        const int H = IS >> 1;
+                        const float *gp = A.grad_colors + ((size_t)n * 4 * H + (row >> 1)) * H + (xi >> 1);
+                        const size_t hp = (size_t)H * H;
+                        g0 = 0.25f * gp[0]; g1 = 0.25f * gp[hp]; g2 = 0.25f * gp[2 * hp];
+                        g3 = NEED_GF ? 0.25f * gp[3 * hp] : 0.f;
+                    } else {
+                        const float *gp = A.grad_colors + (size_t)n * 4 * npix + pn;
+                        g0 = gp[0]; g1 = gp[npix]; g2 = gp[2 * npix];
+                        g3 = NEED_GF ? gp[3 * npix] : 0.f;
+                    }
+                    const float *ag = A.aggrs + (size_t)n * 2 * npix + pn;
+                    const float ssum = ag[0], smax = ag[npix];
+                    const float *sc = A.soft_colors + (size_t)n * 4 * npix + pn;
+                    float c_xy = 0.f;
+                    if (NEED_GF) c_xy = g3 * ((1.f - sc[3 * npix]) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+                    float q0, q1, q2;
+                    const float zp = clip_depth(q0, q1, q2, p, fc);
+                    if (zp < A.near_ || zp > A.far_) continue;  // :592
+                    float gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+                    if (RGB == 0) {
+                        if (NEED_GT && (float)f == smax) {  // :596
+                            const int tix = texel_index(q0, q1, A.R);
+                            if (TS == 1) { gt0 += g0; gt1 += g1; gt2 += g2; }
+                            else { atomicAdd(&my_tex[tix * 3], g0); atomicAdd(&my_tex[tix * 3 + 1], g1); atomicAdd(&my_tex[tix * 3 + 2], g2); }
+                        }
+                    } else if (fc.front() || A.double_side) {
+                        const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
+                        const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
+                        const int tix = texel_index(q0, q1, A.R);
+                        if (NEED_GT) {
+                            if (TS == 1) { gt0 += ps * g0; gt1 += ps * g1; gt2 += ps * g2; }
+                            else { atomicAdd(&my_tex[tix * 3], ps * g0); atomicAdd(&my_tex[tix * 3 + 1], ps * g1); atomicAdd(&my_tex[tix * 3 + 2], ps * g2); }
+                        }
+                        if (NEED_GF) {
+                            const float *tx = tex_f + (size_t)tix * 3;
+                            float c_rgb = g0 * (tx[0] - sc[0]);
+                            c_rgb += g1 * (tx[1] - sc[npix]);
+                            c_rgb += g2 * (tx[2] - sc[2 * npix]);
+                            c_rgb *= ps;
+                            c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
+                            const float c_z = -(c_rgb * A.inv_gamma * A.r_range) * zp * zp;  // :624
+                            gz0 = c_z * q0 * fc.g<R_RZ0>() * fc.g<R_RZ0>();
+                            gz1 = c_z * q1 * fc.g<R_RZ1>() * fc.g<R_RZ1>();
+                            gz2 = c_z * q2 * fc.g<R_RZ2>() * fc.g<R_RZ2>();
+                        }
+                    }
+                    if (NEED_GF) {
+                        c_xy *= p.frag * (1.f - p.frag) * (-A.nis);  // :632
+                        const float k2 = 2.f * p.sign * c_xy;        // :640
+                        const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
+                        gv[0] += b0 * p.dx; gv[1] += b0 * p.dy; gv[2] += gz0;
+                        gv[3] += b1 * p.dx; gv[4] += b1 * p.dy; gv[5] += gz1;
+                        gv[6] += b2 * p.dx; gv[7] += b2 * p.dy; gv[8] += gz2;
+                    }
+                }
+            }
+        }
+    }
+    if (NEED_GF) {
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float sv = wave_sum(gv[k]);
+            if (lane == k) mine = sv;
+        }
+        if (live && lane < 9) A.grad_faces[((size_t)n * F + f) * 9 + lane] += mine;
+    }
+    if (NEED_GT) {
+        if (TS == 1) {
+            const float s0 = wave_sum(gt0), s1 = wave_sum(gt1), s2 = wave_sum(gt2);
+            if (live && lane < 3) A.grad_textures[((size_t)n * F + f) * 3 + lane] += lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+        } else {
+            __syncthreads();  // every wave arrives exactly once; orders the LDS atomics before the read-out
+            if (live) {
+                float *dst = A.grad_textures + ((size_t)n * F + f) * TS * 3;
+                for (int j = lane; j < TS * 3; j += 64) dst[j] += my_tex[j];
+            }
+        }
+    }
+}
+
+template <int RGB>
+void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
+    const long total = (long)A.N * A.F;
+    const int blocks = (int)((total + FM_WAVES - 1) / FM_WAVES);
+    const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * A.TS * 3 * sizeof(float) : 0;
+    if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else if (A.need_gf) k_raster_backward_fm<RGB, true, false><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else k_raster_backward_fm<RGB, false, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+}
+
 bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int TS, int *R) {
     if (func_id_dist != 2 || func_id_alpha != 2 || texture_sample_type != 0) return false;
     if (func_id_rgb != 0 && func_id_rgb != 1) return false;
@@ -554,6 +750,7 @@ struct ProfRec { hipEvent_t e0, e1; double bytes; int which; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
+bool g_bwd_pixel_major = false;  // umr_debug_set("bwd_pixel_major", 1)
 
 struct ProfScope {  // brackets exactly one kernel launch on `st`
     bool on; hipEvent_t e0, e1; hipStream_t st; int which; double bytes;
@@ -574,6 +771,12 @@ struct ProfScope {  // brackets exactly one kernel launch on `st`
 extern "C" {
 
 const char *umr_version(void) { return "umr_hip 0.1 gfx950"; }
+
+int umr_debug_set(const char *key, int value) {
+    if (!key) return UMR_ERR_ARG;
+    if (std::string(key) == "bwd_pixel_major") { g_bwd_pixel_major = value != 0; return UMR_OK; }
+    return UMR_ERR_ARG;
+}
 
 int umr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -629,6 +832,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;  // :332
     A.gamma = gamma_val; A.double_side = double_side; A.with_p2f = with_p2f;
+    A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     const int total = N * F;
@@ -671,6 +875,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;
     A.gamma = gamma_val; A.double_side = double_side;
+    A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
@@ -683,8 +888,12 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         // arrives 2x2-pooled: 4 instead of 16 B/pixel) IS^2 + F (180 + 24 TS)
         const double px = grad_is_pooled ? 28.0 : 40.0;
         ProfScope ps(st, 1, (double)N * (px * image_size * image_size + (double)F * (180.0 + 24.0 * TS)));
-        if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
-        else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+        const bool lds_ok = (size_t)FM_WAVES * TS * 3 * sizeof(float) <= 48 * 1024;
+        if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
+            if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
+            else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);
+        else launch_backward_fm<1>(A, st);
     }
     return umr_launch_status();
 }
