@@ -66,6 +66,11 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * TS must be a perfect square.  Anything else returns UMR_ERR_ARG.
  * dist_eps is the value the reference binding receives: log(1/eps_dist - 1).
  *
+ * background: NULL = the reference contract above (soft_colors pre-filled by the caller).  A HOST pointer to
+ * 3 floats instead lets soft_colors / aggrs_info arrive uninitialised: the kernel starts every pixel from that
+ * colour and writes all six planes (saves the caller's 0.8 GB of fills per N=128 call,
+ * functional/soft_rasterize.py:48-55).  faces_info may be NULL when the caller does not want it.
+ *
  * flags: bit 0 (UMR_RASTER_NO_P2F) skips the p2f_info/p2f_sum accumulation (callers that discard
  * them, e.g. MultiMaskLoss, nnutils/loss_utils.py:265).
  * -------------------------------------------------------------------------------------------*/
@@ -78,7 +83,8 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                        float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
                        float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
                        int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
-                       int flags, void *workspace, size_t workspace_bytes, void *stream);
+                       int flags, const float *background, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /*   grad_faces    [N,F,9], grad_textures [N,F,TS,3]   zero-filled by the caller; contributions are ADDED
  *   grad_soft_colors [N,4,IS,IS], or -- when grad_is_pooled != 0 -- the gradient of the 2x2-pooled

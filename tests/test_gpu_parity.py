@@ -44,7 +44,7 @@ def _raw_raster(g, flags=0, pooled=False):
             float(g["gamma_val"]), int(g["func_id_rgb"]), 2, 0, int(bool(g["double_side"])))
     st = _lib.stream_ptr(torch.device(DEV))
     rc = L.umr_raster_forward(p(faces), p(tex), p(faces_info), p(aggrs), p(grid), p(p2f_info), p(p2f_sum), p(sc),
-                              p(pool), N, F, TS, IS, *scal, flags, p(ws), wsb, st)
+                              p(pool), N, F, TS, IS, *scal, flags, None, p(ws), wsb, st)
     assert rc == 0
     gsc = torch.from_numpy(g["grad_soft_colors"]).to(DEV)
     gf = torch.zeros(N, F, 9, device=DEV)
@@ -99,9 +99,9 @@ def test_raster_rejects_unsupported_modes():
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     p = _lib.ptr
     base = [p(t), p(t), p(t), p(t), p(t), p(t), p(t), p(t), None, 1, 1, 1, 2, 1., 100., 1e-3, 1e-5]
-    tail = [1e-4, 1, 2, 0, 1, 0, p(ws), wsb, None]
+    tail = [1e-4, 1, 2, 0, 1, 0, None, p(ws), wsb, None]
     assert L.umr_raster_forward(*base, 1, 23.0, *tail) == -1          # barycentric distance: unsupported
-    assert L.umr_raster_forward(*base, 2, 23.0, 1e-4, 1, 1, 0, 1, 0, p(ws), wsb, None) == -1  # alpha 'sum'
+    assert L.umr_raster_forward(*base, 2, 23.0, 1e-4, 1, 1, 0, 1, 0, None, p(ws), wsb, None) == -1  # alpha 'sum'
     assert L.umr_raster_forward(*base[:9], 1, 1, 2, 2, 1., 100., 1e-3, 1e-5, 2, 23.0, *tail) == -1  # TS not square
 
 

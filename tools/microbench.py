@@ -47,5 +47,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for cfg in [(16, 3, 512, 1), (16, 3, 512, 36), (128, 3, 512, 1), (128, 3, 512, 36)]:
         print(json.dumps(bench(*cfg)), flush=True)
+    print("no-p2f + fused pool:", json.dumps(bench(128, 3, 512, 1, pool=True, need_p2f=False)), flush=True)
+    print("no-p2f + fused pool:", json.dumps(bench(128, 3, 512, 36, pool=True, need_p2f=False, need_gf=False)), flush=True)
     print(json.dumps(bench(16, 3, 512, 1, rgb="hard", need_gf=False, need_gt=False)), flush=True)
     print(json.dumps(bench(32, 4, 1024, 36)), flush=True)

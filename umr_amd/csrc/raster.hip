@@ -58,11 +58,14 @@ struct RasterArgs {
     float *grad_textures;
     int N, F, IS, TS, R;
     float near_, far_, eps, sigma, threshold, gamma;
+    float thr;        // sqrt(threshold)
     float nis;        // -1/sigma
     float r_range;    // RN(1/(far-near))
     float inv_gamma;
     int double_side, with_p2f, grad_pooled, need_gf, need_gt;
     int tiles_x, tiles_y;
+    int bg_arg;       // background passed by value: soft_colors arrives uninitialised
+    float bg0, bg1, bg2;
 };
 
 // ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
@@ -282,6 +285,24 @@ __device__ __forceinline__ int texel_index(float c0, float c1, int R) {  // :180
     return (R - 1 - wy) * R + (R - 1 - wx);
 }
 
+
+// Conservative "can any pixel centre of this tile survive the reference's rejects?" test.  A pixel whose
+// perpendicular distance to the outer side of ONE edge line exceeds sqrt(threshold) is outside the triangle and
+// farther than the threshold from it (whatever edge the reference's region logic picks, its clamped closest
+// point is at least that far), so it is rejected at :382.  w_c is affine in the pixel position, so its maximum
+// over the tile is w_c(centre) + hx |dw_c/dx| + hy |dw_c/dy|; signed distance = w_c * h_c with h_c^2 = K_c.
+// NaN / degenerate faces (K_c = 0) never cull.  1e-3 (in barycentric units) absorbs rounding.
+__device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, const float4 i2, float cx, float cy,
+                                             float hx, float hy, float thr) {
+    // i0 = inv[0..3], i1 = inv[4..7], i2 = {inv[8], K0, K1, K2}
+    const float w0 = fmaf(i0.x, cx, fmaf(i0.y, cy, i0.z)) + (hx * fabsf(i0.x) + hy * fabsf(i0.y));
+    const float w1 = fmaf(i0.w, cx, fmaf(i1.x, cy, i1.y)) + (hx * fabsf(i0.w) + hy * fabsf(i1.x));
+    const float w2 = fmaf(i1.z, cx, fmaf(i1.w, cy, i2.x)) + (hx * fabsf(i1.z) + hy * fabsf(i1.w));
+    const bool out = w0 < -(thr * __frsqrt_rn(i2.y)) - 1e-3f || w1 < -(thr * __frsqrt_rn(i2.z)) - 1e-3f ||
+                     w2 < -(thr * __frsqrt_rn(i2.w)) - 1e-3f;
+    return !out;
+}
+
 // XCD-aware work mapping: hardware places workgroup b on XCD b % 8; give each XCD a contiguous
 // run of (mesh, tile) work items so one mesh's face records stay in one L2.
 __device__ __forceinline__ int xcd_remap(int b, int total) {
@@ -371,8 +392,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
     float depth_min = 10000000.f;
     int face_min = -1;
     if (t.valid) {
-        float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
-        c0 = sc[0]; c1 = sc[npix]; c2 = sc[2 * npix];
+        if (A.bg_arg) { c0 = A.bg0; c1 = A.bg1; c2 = A.bg2; }
+        else {
+            const float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
+            c0 = sc[0]; c1 = sc[npix]; c2 = sc[2 * npix];
+        }
         if (RGB == 1) {
             c0 *= ssum; c1 *= ssum; c2 *= ssum;
             if (A.with_p2f) { gx = A.grid[pn * 2]; gy = A.grid[pn * 2 + 1]; }
@@ -391,6 +415,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
             if (fcand >= 0) {
                 const float4 bb = bbox_n[fcand];
                 hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
+                if (hit) {  // one lane per candidate face: exact-ish tile/triangle test
+                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_INV);
+                    hit = tile_may_hit(q[0], q[1], q[2], 0.5f * (t.wxlo + t.wxhi), 0.5f * (t.wylo + t.wyhi),
+                                       0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr);
+                }
             }
             unsigned long long m = __ballot(hit);
             while (m) {
@@ -453,7 +482,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
     else { o0 = c0 / ssum; o1 = c1 / ssum; o2 = c2 / ssum; }
     if (t.valid) {
         float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
-        if (RGB == 1 || face_min != -1) { sc[0] = o0; sc[npix] = o1; sc[2 * npix] = o2; }
+        if (RGB == 1 || face_min != -1 || A.bg_arg) { sc[0] = o0; sc[npix] = o1; sc[2 * npix] = o2; }
         sc[3 * npix] = o3;
         float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
         ag[0] = RGB == 0 ? depth_min : ssum;
@@ -515,6 +544,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
             if (fcand >= 0) {
                 const float4 bb = bbox_n[fcand];
                 hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
+                if (hit) {  // one lane per candidate face: exact-ish tile/triangle test
+                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_INV);
+                    hit = tile_may_hit(q[0], q[1], q[2], 0.5f * (t.wxlo + t.wxhi), 0.5f * (t.wylo + t.wyhi),
+                                       0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr);
+                }
             }
             unsigned long long m = __ballot(hit);
             while (m) {
@@ -630,12 +664,32 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
             const int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = r0 >> 3, ty1 = r1 >> 3;
             const bool pow2 = (IS & (IS - 1)) == 0;
             const float inv_is = 1.f / (float)IS;
-            for (int ty = ty0; ty <= ty1; ++ty) {
-                const int row = ty * 8 + (lane >> 3);
-                const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
-                for (int tx = tx0; tx <= tx1; ++tx) {
+            const int ntx = tx1 - tx0 + 1, ntiles = ntx * (ty1 - ty0 + 1);
+            const float4 i0 = make_float4(fc.g<R_INV + 0>(), fc.g<R_INV + 1>(), fc.g<R_INV + 2>(), fc.g<R_INV + 3>());
+            const float4 i1 = make_float4(fc.g<R_INV + 4>(), fc.g<R_INV + 5>(), fc.g<R_INV + 6>(), fc.g<R_INV + 7>());
+            const float4 i2 = make_float4(fc.g<R_INV + 8>(), fc.g<R_K0>(), fc.g<R_K1>(), fc.g<R_K2>());
+            for (int tb = 0; tb < ntiles; tb += 64) {
+                // one lane per tile: drop tiles no pixel of which can survive (conservative), then walk the rest
+                const int ti = tb + lane;
+                bool want = false;
+                if (ti < ntiles) {
+                    const int ttx = tx0 + ti % ntx, tty = ty0 + ti / ntx;
+                    const int px0 = ttx * 8, px1 = min(px0 + 7, IS - 1), pr0 = tty * 8, pr1 = min(pr0 + 7, IS - 1);
+                    const float cxl = ndc_coord_fast(px0, IS, inv_is, pow2), cxh = ndc_coord_fast(px1, IS, inv_is, pow2);
+                    const float cyh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), cyl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
+                    want = tile_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), 0.5f * (cxh - cxl),
+                                        0.5f * (cyh - cyl), A.thr);
+                }
+                unsigned long long tm = __ballot(want);
+                while (tm) {
+                    const int tbit = __builtin_ctzll(tm);
+                    tm &= tm - 1;
+                    const int tsel = tb + tbit;
+                    const int tx = tx0 + tsel % ntx, ty = ty0 + tsel / ntx;
+                    const int row = ty * 8 + (lane >> 3);
                     const int xi = tx * 8 + (lane & 7);
                     if (xi >= IS || row >= IS) continue;
+                    const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
                     const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
                     Pair p;
                     if (!eval_pair(p, fc, xp, yp, A.threshold, A.nis)) continue;
@@ -811,7 +865,8 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                        float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
                        float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
                        int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
-                       int flags, void *workspace, size_t workspace_bytes, void *stream) {
+                       int flags, const float *background, void *workspace, size_t workspace_bytes,
+                       void *stream) {
     int R = 0;
     if (!faces || !textures || !aggrs_info || !soft_colors || !workspace) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
@@ -832,9 +887,10 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;  // :332
     A.gamma = gamma_val; A.double_side = double_side; A.with_p2f = with_p2f;
-    A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
+    A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
+    if (background) { A.bg_arg = 1; A.bg0 = background[0]; A.bg1 = background[1]; A.bg2 = background[2]; }
     const int total = N * F;
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold));
@@ -875,7 +931,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;
     A.gamma = gamma_val; A.double_side = double_side;
-    A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
+    A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;

@@ -3,6 +3,7 @@
 PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and autograd
 bookkeeping.  All arithmetic happens in libumr_hip.so; there is no CPU or eager-torch fallback.
 """
+import ctypes
 import math
 
 import torch
@@ -61,22 +62,21 @@ class SoftRasterizeFunction(Function):
                    float(math.log(1. / dist_eps - 1.)), float(gamma_val), _FUNC_RGB[aggr_func_rgb],
                    _FUNC_ALPHA[aggr_func_alpha], _FUNC_SAMPLE[texture_type], 1 if fill_back else 0)
         ctx.pool = bool(pool)
-        faces_info = torch.zeros(N, F, 27, device=dev, dtype=torch.float32)
-        aggrs_info = torch.zeros(N, 2, IS, IS, device=dev, dtype=torch.float32)
-        p2f_info = torch.zeros(N, F, 2, device=dev, dtype=torch.float32)
-        p2f_sum = torch.zeros(N, F, 2, device=dev, dtype=torch.float32)
-        soft_colors = torch.ones(N, 4, IS, IS, device=dev, dtype=torch.float32)
-        for k in range(3):
-            if background_color[k] != 1:
-                soft_colors[:, k].mul_(float(background_color[k]))
+        # the reference fills 0.8 GB of buffers per N=128 call (functional/soft_rasterize.py:47-55); here the
+        # kernel takes the background colour by value and writes every plane, so nothing is pre-filled
+        aggrs_info = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
+        p2f_acc = torch.zeros(2, N, F, 2, device=dev, dtype=torch.float32)
+        p2f_info, p2f_sum = p2f_acc[0], p2f_acc[1]
+        soft_colors = torch.empty(N, 4, IS, IS, device=dev, dtype=torch.float32)
+        bg = (ctypes.c_float * 3)(float(background_color[0]), float(background_color[1]), float(background_color[2]))
         pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
         grid = standard_grid(IS, dev) if (need_p2f and ctx.cfg[8] == 1) else None
         ws_bytes = L.umr_raster_workspace_bytes(N, F)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
-        rc = L.umr_raster_forward(ptr(fv), ptr(tex), ptr(faces_info), ptr(aggrs_info), ptr(grid), ptr(p2f_info),
+        rc = L.umr_raster_forward(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_info),
                                   ptr(p2f_sum), ptr(soft_colors), ptr(pooled), N, F, TS, IS_, near_, far_, eps_,
-                                  sig, fd, de, gam, frgb, fal, fsm, ds, 0 if need_p2f else 1, ptr(ws), ws_bytes,
+                                  sig, fd, de, gam, frgb, fal, fsm, ds, 0 if need_p2f else 1, bg, ptr(ws), ws_bytes,
                                   _lib.stream_ptr(dev))
         _lib.check(rc, "umr_raster_forward")
         p2f = p2f_info / p2f_sum.clamp_min(1e-12)  # functional/soft_rasterize.py:73

@@ -51,3 +51,23 @@ def unique_edges(faces):
     e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 0)
     e = np.sort(e, axis=1)
     return np.unique(e, axis=0)
+
+
+def make_symmetric(verts, faces, axis=1):
+    """Vertex re-ordering of utils/mesh.py:44-100: [on-plane, right (coord > 0), left (mirror images, same order)]
+    so that V = cat(V[:n_indep + n_sym], flip * V[n_indep : n_indep + n_sym]).
+    Returns (verts, faces, num_indept, num_sym).  (The reference additionally re-orders FACES for a symmetric
+    texture predictor, utils/mesh.py:102-195; not reproduced.)"""
+    c = verts[:, axis]
+    center = np.where(c == 0)[0]
+    right = np.where(c > 0)[0]
+    left = np.where(c < 0)[0]
+    assert len(left) == len(right), "mesh is not mirror symmetric"
+    lut = {tuple(v): i for i, v in enumerate(verts)}
+    flip = np.ones(3)
+    flip[axis] = -1
+    mirror = np.array([lut[tuple(verts[r] * flip)] for r in right], dtype=np.int64)   # exact match or KeyError
+    order = np.concatenate([center, right, mirror])
+    perm = np.empty(len(verts), dtype=np.int64)
+    perm[order] = np.arange(len(verts))
+    return verts[order], perm[faces], len(center), len(right)

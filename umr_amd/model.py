@@ -1,0 +1,351 @@
+"""MeshNet re-hosted for the MI355X training harness.
+
+The network is OUT OF SCOPE as kernels (dense conv / GEMM -> PyTorch-ROCm, MIOpen
+and hipBLASLt, i.e. MFMA); what matters is that its forward() keeps the reference's signature so the
+render-and-compare step is a drop-in (nnutils/cub_mesh.py:450-485):
+
+    MeshNet(input_shape, opts).forward(img [B,3,256,256]) -> dict(cam, cam_probs, cam_sample_inds, mean, logvar,
+        noise, tex_flow [B,F,T,T,2], uvimage_pred [B,2,128,256], delta_v [B,V',3], ...)
+    .symmetrize(V), .get_mean_shape(), .faces, .uv_sampler, .mean_v
+
+torchvision is not available here, so the ResNet-18 trunk (cub_mesh.py:53-74) is written out in plain torch.nn
+with random initialisation (the pretrained weights are not obtainable offline).  Parameter shapes follow the
+reference, so the gradient all-reduce volume (~85 M fp32) is the reference's.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import mesh as mesh_utils
+
+
+def default_opts(**kw):
+    """The absl flags of nnutils/cub_mesh.py:29-48 + train_utils.py as plain attributes."""
+    o = dict(symmetric=True, multiple_cam_hypo=False, nz_feat=200, z_dim=350, num_hypo_cams=8, use_texture=True,
+             tex_size=6, subdivide=3, batch_size=16, gpu_num=1, scale_lr_decay=0.05, scale_bias=1.0, pred_cam=True,
+             learning_rate=1e-4, beta1=0.9, grl_wt=0.2)
+    o.update(kw)
+    return SimpleNamespace(**o)
+
+
+# ------------------------------------------------------------------ nnutils/net_blocks.py
+def net_init(net):
+    """net_blocks.py:225-252."""
+    for m in net.modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            m.weight.data.normal_(0, 0.02)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+def fc(batch_norm, nc_inp, nc_out):
+    if batch_norm:
+        return nn.Sequential(nn.Linear(nc_inp, nc_out, bias=True), nn.BatchNorm1d(nc_out), nn.LeakyReLU(0.2, inplace=True))
+    return nn.Sequential(nn.Linear(nc_inp, nc_out), nn.LeakyReLU(0.1, inplace=True))
+
+
+def fc_stack(nc_inp, nc_out, nlayers, use_bn=True):
+    mods = []
+    for _ in range(nlayers):
+        mods.append(fc(use_bn, nc_inp, nc_out))
+        nc_inp = nc_out
+    enc = nn.Sequential(*mods)
+    net_init(enc)
+    return enc
+
+
+def conv2d(batch_norm, cin, cout, kernel_size=3, stride=1):
+    layers = [nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True)]
+    if batch_norm:
+        layers.append(nn.BatchNorm2d(cout))
+    layers.append(nn.LeakyReLU(0.2, inplace=True))
+    return nn.Sequential(*layers)
+
+
+def upconv2d(cin, cout, mode='bilinear'):
+    return nn.Sequential(nn.Upsample(scale_factor=2, mode=mode), nn.ReflectionPad2d(1),
+                         nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=0), nn.LeakyReLU(0.2, inplace=True))
+
+
+def decoder2d(nlayers, nc_input, nc_final, nc_min=8, use_bn=True):
+    """net_blocks.py decoder2d with init_fc=False, use_deconv=False."""
+    mods = []
+    nc_output = nc_input
+    for _ in range(nlayers):
+        if nc_output // 2 >= nc_min:
+            nc_output = nc_output // 2
+        mods.append(upconv2d(nc_input, nc_output))
+        nc_input = nc_output
+        mods.append(conv2d(use_bn, nc_input, nc_output))
+    mods.append(nn.Conv2d(nc_output, nc_final, kernel_size=3, stride=1, padding=1, bias=True))
+    dec = nn.Sequential(*mods)
+    net_init(dec)
+    return dec
+
+
+# ------------------------------------------------------------------ ResNet-18 trunk (torchvision layout)
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = self.bn2(self.conv2(out))
+        return F.relu(out + idt, inplace=True)
+
+
+class ResNetConv(nn.Module):
+    """cub_mesh.py:53-74: resnet18 without avgpool/fc (the reference keeps an unused fc; dropping it also removes the
+    one parameter that never receives a gradient)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cfg = [(64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)]
+        self.layers = nn.ModuleList([nn.Sequential(BasicBlock(a, b, s), BasicBlock(b, b, 1)) for a, b, s in cfg])
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, 2, 1)
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+class Encoder(nn.Module):
+    """cub_mesh.py:77-118."""
+
+    def __init__(self, input_shape, nz_feat=100, z_dim=200):
+        super().__init__()
+        self.resnet_conv = ResNetConv()
+        self.enc_conv1 = conv2d(True, 512, 256, stride=2, kernel_size=4)
+        nc_input = 256 * (input_shape[0] // 64) * (input_shape[1] // 64)
+        self.enc_fc = fc_stack(nc_input, nz_feat, 2)
+        self.mean_fc = nn.Sequential(nn.Linear(nz_feat, nz_feat), nn.LeakyReLU(), nn.Linear(nz_feat, z_dim))
+        self.logvar_fc = nn.Sequential(nn.Linear(nz_feat, nz_feat), nn.LeakyReLU(), nn.Linear(nz_feat, z_dim))
+        net_init(self.enc_conv1)
+
+    def forward(self, img):
+        f = self.enc_conv1(self.resnet_conv(img)).view(img.size(0), -1)
+        feat = self.enc_fc(f)
+        mean, logvar = self.mean_fc(feat), self.logvar_fc(feat)
+        noise = torch.randn_like(mean) * logvar.mul(0.5).exp() + mean   # :103-107
+        return feat, noise, mean, logvar
+
+
+class TexturePredictorUV(nn.Module):
+    """cub_mesh.py:120-165 (predict_flow=True)."""
+
+    def __init__(self, nz_feat, num_faces, T, img_H=64, img_W=128, n_upconv=5, nc_init=256, num_sym_faces=0):
+        super().__init__()
+        self.feat_H, self.feat_W = img_H // (2 ** n_upconv), img_W // (2 ** n_upconv)
+        self.nc_init, self.F, self.T, self.num_sym_faces = nc_init, num_faces, T, num_sym_faces
+        self.enc = fc_stack(nz_feat, nc_init * self.feat_H * self.feat_W, 2)
+        self.decoder = decoder2d(n_upconv, nc_init, nc_final=2)
+
+    def forward(self, feat, uv_sampler):
+        x = self.enc(feat).view(feat.size(0), self.nc_init, self.feat_H, self.feat_W)
+        uvimage_pred = torch.tanh(self.decoder(x))
+        tex = F.grid_sample(uvimage_pred, uv_sampler, mode='bilinear', padding_mode='zeros', align_corners=True)
+        tex = tex.view(tex.size(0), -1, self.F, self.T, self.T).permute(0, 2, 3, 4, 1)
+        if self.num_sym_faces:
+            tex = torch.cat([tex, tex[:, -self.num_sym_faces:]], 1)   # :159-162
+        return tex.contiguous(), uvimage_pred
+
+
+class Camera(nn.Module):
+    """cub_mesh.py:276-301 -> [quat(4), prob(1), scale(1), trans(2)]."""
+
+    def __init__(self, nz):
+        super().__init__()
+        self.fc_layer = fc_stack(nz, nz, 2)
+        self.quat = nn.Linear(nz, 4)
+        self.prob = nn.Linear(nz, 1)
+        self.scale = nn.Linear(nz, 1)
+        self.trans = nn.Linear(nz, 2)
+        net_init(self)
+        self.quat.bias.data = torch.tensor([1., 0., 0., 0.])   # initialize_to_zero_rotation (:200-203)
+
+    def forward(self, feat):
+        f = self.fc_layer(feat)
+        quat = F.normalize(self.quat(f))
+        scale = F.relu(self.scale(f) + 1.0) + 1e-12                # ScalePredictor (:213-216)
+        return torch.cat([quat, self.prob(f), scale, self.trans(f)], dim=1)
+
+
+class MultiCamPredictor(nn.Module):
+    """cub_mesh.py:303-362: K camera hypotheses + multinomial sampling."""
+
+    def __init__(self, nz_feat, num_cams=8):
+        super().__init__()
+        self.fc = fc_stack(nz_feat, nz_feat, 2, use_bn=False)
+        self.cameras = nn.ModuleList([Camera(nz_feat) for _ in range(num_cams)])
+        self.num_cams = num_cams
+
+    def forward(self, feat):
+        f = self.fc(feat)
+        cams = torch.stack([c(f) for c in self.cameras], dim=1)      # [B,K,8]
+        probs = F.softmax(cams[:, :, 4], dim=1)
+        cam = torch.cat([cams[:, :, 5:6], cams[:, :, 6:8], cams[:, :, 0:4], probs.unsqueeze(-1)], dim=2)
+        inds = torch.multinomial(probs.detach(), 1)                  # per-rank RNG stream (:358-359)
+        sampled = torch.gather(cam, 1, inds.unsqueeze(-1).expand(-1, 1, 8)).squeeze(1)[:, 0:7]
+        return sampled, inds, cam[:, :, 7], cam[:, :, 0:7], cams[:, :, 0:4]
+
+
+class Discriminator(nn.Module):
+    """nnutils/discriminators.py:60-86 with the gradient-reversal layer (:32-57)."""
+
+    class _GRL(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, lam):
+            ctx.lam = lam
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            return -ctx.lam * g, None
+
+    def __init__(self, lambda_, in_dim=1, img_size=64):
+        super().__init__()
+        self.lambda_ = lambda_
+        fc_size = int(img_size // 16)
+        self.img_conv = nn.Conv2d(in_dim, 32, 3, 2, 1)
+        self.convs = nn.Sequential(nn.Conv2d(32, 64, 3, 2, 1), nn.ReLU(True), nn.Conv2d(64, 32, 3, 2, 1), nn.ReLU(True),
+                                   nn.Conv2d(32, 32, 3, 2, 1), nn.ReLU(True), nn.Conv2d(32, 1, 1, 1, 0))
+        self.fc = nn.Linear(fc_size * fc_size, 1)
+
+    def forward(self, imgs):
+        x = Discriminator._GRL.apply(imgs, self.lambda_)
+        p = self.convs(F.relu(self.img_conv(x)))
+        return self.fc(p.view(imgs.size(0), -1))
+
+
+def spherical_uv(X):
+    """utils/mesh.py get_spherical_coords: points on the unit sphere -> (u,v) in [-1,1]."""
+    rad = np.linalg.norm(X, axis=1)
+    theta = np.arccos(np.clip(X[:, 2] / rad, -1, 1))
+    phi = np.arctan2(X[:, 1], X[:, 0])
+    return np.stack([((phi + np.pi) / (2 * np.pi)) * 2 - 1, (theta / np.pi) * 2 - 1], 1)
+
+
+def compute_uvsampler(verts, faces, tex_size):
+    """utils/mesh.py:247-272 -> [F,T,T,2]."""
+    a = np.arange(tex_size, dtype=np.float64) / (tex_size - 1)
+    coords = np.stack(np.meshgrid(a, a, indexing="ij"), -1).reshape(-1, 2)      # product(alpha, beta)
+    vs = verts[faces]
+    v2, v0v2, v1v2 = vs[:, 2], vs[:, 0] - vs[:, 2], vs[:, 1] - vs[:, 2]
+    samples = np.dstack([v0v2, v1v2]).dot(coords.T) + v2.reshape(-1, 3, 1)
+    samples = np.transpose(samples, (0, 2, 1))
+    return spherical_uv(samples.reshape(-1, 3)).reshape(-1, tex_size, tex_size, 2)
+
+
+class MeshNet(nn.Module):
+    """nnutils/cub_mesh.py:366-507.  Vertex symmetry about `axis` is implemented (delta_v is predicted for the
+    on-plane + right-half vertices and mirrored); the face re-ordering of utils/mesh.py:102-195 (symmetric texture)
+    is not: the texture predictor emits all F faces."""
+
+    def __init__(self, input_shape, opts, nz_feat=100, axis=1, temp_path=None):
+        super().__init__()
+        self.opts = opts
+        self.symmetric = opts.symmetric
+        verts, faces = mesh_utils.create_sphere(opts.subdivide)
+        if self.symmetric:
+            verts, faces, self.num_indept, self.num_sym = mesh_utils.make_symmetric(verts, faces, axis)
+            self.num_output = self.num_indept + self.num_sym
+            flip = torch.ones(1, 3)
+            flip[0, axis] = -1
+            self.register_buffer("flip", flip)
+        else:
+            self.num_output = verts.shape[0]
+        self.register_buffer("mean_v", torch.from_numpy(verts[:self.num_output]).float())
+        self.register_buffer("faces", torch.from_numpy(faces).long())
+        self.verts_np, self.faces_np = verts, faces
+        self.encoder = Encoder(input_shape, nz_feat=nz_feat, z_dim=opts.z_dim)
+        self.shape_predictor = nn.Linear(opts.z_dim, self.num_output * 3)
+        self.shape_predictor.weight.data.normal_(0, 0.0001)           # cub_mesh.py:176-177
+        self.cam_predictor = MultiCamPredictor(nz_feat, opts.num_hypo_cams) if opts.multiple_cam_hypo else Camera(nz_feat)
+        T = opts.tex_size
+        uv = torch.from_numpy(compute_uvsampler(verts, faces, T)).float().view(1, faces.shape[0], T * T, 2)
+        self.register_buffer("uv_sampler", uv)
+        img_H = int(2 ** np.floor(np.log2(np.sqrt(faces.shape[0]) * T)))
+        self.texture_predictor = TexturePredictorUV(nz_feat, faces.shape[0], T, img_H=img_H, img_W=2 * img_H)
+        net_init(self.texture_predictor)
+
+    def forward(self, img=None):
+        out = {}
+        img_feat, noise, mean, logvar = self.encoder(img)
+        out['delta_v'] = self.shape_predictor(noise).view(img.size(0), -1, 3)
+        if self.opts.multiple_cam_hypo:
+            cam, inds, probs, all_cams, quats = self.cam_predictor(img_feat)
+            out['cam_hypotheses'], out['base_quats'] = all_cams, quats[:, 0]
+        else:
+            c = self.cam_predictor(img_feat)
+            cam = torch.cat([c[:, 5:6], c[:, 6:8], c[:, 0:4]], dim=1)
+            inds = torch.zeros(cam.size(0), 1, dtype=torch.long, device=cam.device)
+            probs = inds.float() + 1 + 0 * c[:, 4:5]   # keeps the (unused) prob head in the autograd graph for DDP
+        out.update(mean=mean, logvar=logvar, cam_sample_inds=inds, cam_probs=probs, cam=cam, noise=noise)
+        tex, uvimg = self.texture_predictor(img_feat, self.uv_sampler.expand(img.size(0), -1, -1, -1))
+        out['tex_flow'], out['uvimage_pred'] = tex, uvimg
+        return out
+
+    def symmetrize(self, V):
+        if not self.symmetric:
+            return V
+        if V.dim() == 2:
+            return torch.cat([V, self.flip * V[-self.num_sym:]], 0)
+        return torch.cat([V, self.flip * V[:, -self.num_sym:]], 1)
+
+    def get_mean_shape(self):
+        return self.symmetrize(self.mean_v)
+
+
+# ------------------------------------------------------------------ training step (bench.py / examples)
+def build_training_step(tv, faces, args, dev, world):
+    """One full train_s1 iteration on resident synthetic data: MeshNet fwd -> render-and-compare (HIP) -> bwd with
+    bucketed RCCL all-reduce overlapped (DDP) -> Adam with the reference's lr schedule (train_utils.py:186-194)."""
+    from .parallel import wrap_ddp
+    from .synthetic import make_s1_inputs
+    from .train_step import RenderCompareS1
+    opts = default_opts(subdivide=args.subdivide, batch_size=args.batch)
+    net = MeshNet((args.image_size, args.image_size), opts, nz_feat=opts.nz_feat).to(dev)
+    disc = Discriminator(opts.grl_wt, img_size=args.image_size).to(dev)
+    model = nn.ModuleDict(dict(net=net, disc=disc))
+    ddp_net, ddp_disc = wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world)
+    rc = RenderCompareS1(net.get_mean_shape().detach(), net.faces, args.image_size, discriminator=ddp_disc).to(dev)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
+                           betas=(opts.beta1, 0.999))
+    rank = torch.distributed.get_rank() if world > 1 else 0
+    _, _, _, batch = make_s1_inputs(args.batch, args.image_size, args.subdivide, seed=100 + rank, device=dev)
+    mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    input_imgs = (batch["imgs"] - mean) / std                         # train_s1.py:128-131,164
+    state = dict(it=0)
+
+    def step():
+        for g in opt.param_groups:
+            g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)  # train_utils.py:194
+        opt.zero_grad(set_to_none=True)
+        out = ddp_net(input_imgs)
+        out["pred_vs"] = net.get_mean_shape()[None] + net.symmetrize(out["delta_v"])   # train_s1.py:183-192
+        total, _ = rc(out, batch)
+        total.backward()
+        opt.step()
+        state["it"] += 1
+        return total.detach()
+
+    step.model = model
+    return step

@@ -1,0 +1,54 @@
+"""Data parallelism: one process per GPU + RCCL, replacing the reference's single-process nn.DataParallel
+(experiments/train_s2.py:95-164: per-step replicate/scatter/gather of ~85 M parameters, GPU-0 serial sections).
+
+Every rank runs the model AND the whole render-and-compare path on its own shard of the batch; the only
+collective is the bucketed gradient all-reduce (sum / world) that torch DDP overlaps with backward.  On ROCm the
+"nccl" backend is RCCL; over xGMI each all-reduce bucket is per-link bound, so buckets are kept large.
+BatchNorm statistics stay per rank (what DataParallel does as well).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+BUCKET_MB = 64   # ~340 MB of fp32 grads -> 6 buckets; the first fires while the trunk is still in backward
+
+
+def init_distributed(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the torchrun environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def wrap_ddp(module, device, world):
+    if world <= 1:
+        return module
+    if device is not None and torch.device(device).type == "cuda":
+        return torch.nn.parallel.DistributedDataParallel(module, device_ids=[torch.device(device).index],
+                                                         bucket_cap_mb=BUCKET_MB, gradient_as_bucket_view=True)
+    return torch.nn.parallel.DistributedDataParallel(module, bucket_cap_mb=BUCKET_MB)
+
+
+def shard(tensor, rank, world):
+    """Contiguous batch shard of rank `rank` (images are independent in every kernel and loss)."""
+    n = tensor.shape[0]
+    per = (n + world - 1) // world
+    return tensor[rank * per:min(n, (rank + 1) * per)]
+
+
+def mean_scalars(values, world):
+    """All-reduce a dict of python/torch scalars to their mean over ranks (logging only)."""
+    if world <= 1:
+        return {k: float(v) for k, v in values.items()}
+    keys = sorted(values)
+    t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64,
+                     device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t)
+    return {k: float(x) / world for k, x in zip(keys, t)}
