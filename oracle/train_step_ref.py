@@ -60,3 +60,82 @@ class RenderCompareS1Ref:
             + t["ori"] * w.ori_reg_wt + t["deform"] * w.deform_reg_wt + t["tex"] * w.tex_loss_wt \
             + t["tex_dt"] * w.tex_dt_loss_wt + t["tex_cycle"] * w.tex_cycle_loss_wt + t["gan"] * w.gan_loss_wt
         return total, t
+
+
+class RenderCompareS2Ref:
+    """experiments/train_s2.py:201-316 on the oracle, term by term as umr_amd.train_step.RenderCompareS2 with
+    texture_loss_type='l1' (masked L1, nnutils/loss_utils.py:103-116) and no discriminator network."""
+
+    def __init__(self, template_verts, faces, part_vertex_ids, uv_img, uv_sampler, image_size=256, num_hypo_cams=8,
+                 weights=None, n_threads=1, backend="port", tex_size=6):
+        from umr_amd.train_step import S2Weights
+        self.w = weights or S2Weights()
+        self.K, self.image_size = num_hypo_cams, image_size
+        self.faces = faces.long()
+        mk = lambda kind: TR.SoftRenderer(image_size, kind, backend=backend, n_threads=n_threads)
+        self.mask_r, self.tex_r, self.hard_r, self.dis_r, self.part_r = mk("softmax"), mk("softmax"), mk("hard"), mk("softmax"), mk("softmax")
+        for r in (self.tex_r, self.dis_r, self.part_r):
+            r.ambient_light_only()
+        self.lap, self.flat = TR.LaplacianLoss(template_verts, faces), TR.FlattenLoss(faces)
+        names = ("head", "belly", "neck", "back")
+        self.part_ids = [torch.as_tensor(part_vertex_ids[n]).long() for n in names]
+        tex = TR.grid_sample(uv_img.float().view(1, 1, 128, 256), uv_sampler)
+        tex = tex.view(1, -1, tex.size(2), tex_size, tex_size).permute(0, 2, 3, 4, 1)
+        stex = torch.round(tex.reshape(tex.size(1), -1))
+        nf, nt = stex.size()
+        one_hot = torch.zeros(nf * nt, 5)
+        one_hot.scatter_(1, stex.view(-1, 1).long().clamp(0, 4), 1)
+        self.stex = one_hot.view(1, nf, nt, 5)
+
+    def __call__(self, outputs, batch):
+        w, K, H = self.w, self.K, self.image_size
+        pred_vs, delta_v = outputs["pred_vs"], outputs["delta_v"]
+        B = pred_vs.shape[0]
+        faces = self.faces[None].expand(B, -1, -1)
+        imgs, masks = batch["imgs"], batch["masks"]
+        proj_cam = outputs["cam"].detach()
+        cams_all, probs = outputs["cam_hypotheses"], outputs["cam_probs"]
+        t = {}
+        t["cam_div"] = -1 * (torch.log(probs + 1E-9) * probs).sum(1).mean()
+        t["mask"], mask_all = TR.multi_mask_loss(self.mask_r, pred_vs, faces, cams_all, probs, masks, K, H)
+        t["triangle"] = self.lap(pred_vs).mean()
+        t["flatten"] = self.flat(pred_vs).mean()
+        t["deform"] = TR.deform_l2reg(delta_v)
+        tex_flow = outputs["tex_flow"]
+        tex = TR.sample_textures(tex_flow, imgs).contiguous()
+        bs, fs = tex.shape[:2]
+        tex = tex.view(bs, fs, -1, 3)
+        rep = lambda x: x.unsqueeze(1).repeat(1, K, *([1] * (x.dim() - 1))).view(-1, *x.shape[1:])
+        rgba, _, _ = self.tex_r(rep(pred_vs.detach()), rep(faces), cams_all.detach().view(-1, 7), rep(tex))
+        tl = TR.texture_loss_masks(rgba[:, :3], rep(imgs), rep(masks), mask_all, avg=False)
+        t["tex"] = (tl.view(bs, -1) * probs.detach()).sum(dim=1).mean()
+        t["tex_dt"] = TR.texture_dt_loss(tex_flow, batch["dts_barrier"])
+        _, p2f, aggr = self.hard_r(pred_vs.detach(), faces, proj_cam)
+        t["tex_cycle"], _ = TR.tex_cycle(tex_flow, p2f.detach(), aggr[:, 1].reshape(bs, -1).detach())
+        pred_unseen, _, _ = self.dis_r(pred_vs, faces, rotate_cam_y(proj_cam, batch["gan_angles"]), tex.detach())
+        t["gan"] = pred_unseen[:, 0:3].mean()
+        projs = []
+        for i in range(1, 5):
+            stex = self.stex[:, :, :, i].unsqueeze(-1).repeat(B, 1, 1, 3)
+            pr, _, _ = self.part_r(pred_vs, faces, proj_cam, stex)
+            projs.append(torch.mean(pr[:, 0:3], dim=1).unsqueeze(1))
+        t["part"] = TR.part_matching_core(projs, batch["part_segs"])
+        mean_shape = outputs["mean_shape"][None].expand(B, -1, -1)
+        # (head, belly, back, neck) passed into (head, belly, neck, back): train_s2.py:311 vs loss_utils.py:223
+        pts = [rep(batch["head_points"]), rep(batch["belly_points"]), rep(batch["back_points"]), rep(batch["neck_points"])]
+        ms, cf = rep(mean_shape), cams_all.reshape(-1, 7)
+        coords = torch.cat([ms[:, ids, :] for ids in self.part_ids], dim=1)
+        v2d = TR.orthographic_proj_withz(coords, cf)[:, :, :2]
+        import numpy as np
+        nums = np.cumsum([0] + [len(i) for i in self.part_ids])
+        cds = []
+        for i, wt in enumerate((1, 1, 0, 0)):
+            d1, _, _, _ = TR.dist_chamfer(v2d[:, nums[i]:nums[i + 1], :], pts[i])
+            cds.append(d1 * wt)
+        corr = torch.mean(torch.cat(cds, dim=1), dim=1)
+        t["corr"] = (corr.view(B, K) * probs.detach()).sum(dim=1).mean()
+        total = t["mask"] * w.mask_loss_wt + t["triangle"] * w.triangle_reg_wt + t["flatten"] * w.flatten_reg_wt \
+            + t["deform"] * w.deform_reg_wt + t["tex"] * w.tex_loss_wt + t["tex_dt"] * w.tex_dt_loss_wt \
+            + t["tex_cycle"] * w.tex_cycle_loss_wt + t["gan"] * w.gan_loss_wt + t["cam_div"] * w.ent_loss_wt \
+            + t["part"] * w.prob_loss_wt + t["corr"] * w.vertex_loss_wt
+        return total, t

@@ -54,3 +54,33 @@ def test_size_queries_need_no_gpu():
     assert L.umr_raster_workspace_bytes(2, 1280) >= 2 * 1280 * (16 + 160)
     assert L.umr_raster_workspace_bytes(0, 5) == 0
     assert L.umr_project_workspace_bytes(2, 642) == 2 * 642 * 12
+
+
+def test_host_side_helpers_vs_reference_goldens():
+    """Pure-torch host logic that replaces reference python loops: vectorised SCOPS centroids, PNet cosine head,
+    on-device camera rotation."""
+    import numpy as np
+    from conftest import load_golden
+    from umr_amd.loss_utils import batch_get_centers
+    from umr_amd.perceptual import cos_sim
+    g = load_golden("parts_and_cossim.npz")
+    pm = torch.from_numpy(g["part_maps"]).requires_grad_(True)
+    cen = batch_get_centers(pm[:, 1:])
+    np.testing.assert_allclose(cen.detach().numpy(), g["centers"], atol=1e-6)
+    cen.backward(torch.ones_like(cen))
+    np.testing.assert_allclose(pm.grad.numpy(), g["grad_part_maps"], atol=1e-7, rtol=1e-4)
+    f0 = [torch.from_numpy(g["f0_0"]), torch.from_numpy(g["f0_1"])]
+    f1 = [torch.from_numpy(g["f1_0"]), torch.from_numpy(g["f1_1"])]
+    np.testing.assert_allclose(sum(1. - cos_sim(a, b) for a, b in zip(f0, f1)).numpy(), g["cos_dist"], atol=1e-6)
+
+
+def test_symmetric_mesh_counts_match_reference_constants():
+    """subdivide 3 -> 32 on-plane + 305 mirrored pairs (ShapePredictor emits 337 vertices)."""
+    from umr_amd.mesh import create_sphere, make_symmetric
+    import numpy as np
+    v, f = create_sphere(3)
+    v2, f2, n_ind, n_sym = make_symmetric(v, f, axis=1)
+    assert (n_ind, n_sym) == (32, 305) and v2.shape == (642, 3) and f2.shape == (1280, 3)
+    flip = np.array([1, -1, 1])
+    assert np.array_equal(v2[n_ind + n_sym:], v2[n_ind:n_ind + n_sym] * flip)
+    assert (v2[:n_ind, 1] == 0).all()

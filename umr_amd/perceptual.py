@@ -1,0 +1,88 @@
+"""Perceptual distance used by the texture loss (nnutils/perceptual_loss.py:38-57 ->
+external/PerceptualSimilarity/models/{dist_model,networks_basic,pretrained_networks}.py, model='net', net='alex').
+
+AlexNet's convolutions are dense contractions and stay on MIOpen (out of scope as kernels);
+torchvision is not installed and the pretrained weights cannot be downloaded here, so the feature extractor is
+written out (torchvision `alexnet().features` layout, taps after each of the 5 ReLUs,
+pretrained_networks.py:59-95) with RANDOM weights unless a state_dict is supplied.  The distance head
+(networks_basic.py:42-64 + util/util.py:71-83) is exact: sum over taps of 1 - mean_xy cos(f0, f1)."""
+import torch
+import torch.nn as nn
+
+
+class AlexNetFeatures(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.slices = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(3, 64, 11, 4, 2), nn.ReLU(inplace=False)),
+            nn.Sequential(nn.MaxPool2d(3, 2), nn.Conv2d(64, 192, 5, 1, 2), nn.ReLU(inplace=False)),
+            nn.Sequential(nn.MaxPool2d(3, 2), nn.Conv2d(192, 384, 3, 1, 1), nn.ReLU(inplace=False)),
+            nn.Sequential(nn.Conv2d(384, 256, 3, 1, 1), nn.ReLU(inplace=False)),
+            nn.Sequential(nn.Conv2d(256, 256, 3, 1, 1), nn.ReLU(inplace=False))])
+        for p in self.parameters():
+            p.requires_grad = False       # requires_grad=False in the reference (networks_basic.py:29)
+
+    def forward(self, x):
+        outs = []
+        for s in self.slices:
+            x = s(x)
+            outs.append(x)
+        return outs
+
+
+def cos_sim(in0, in1, eps=1e-10):
+    """util/util.py:71-83: features normalised over channels, dot product, mean over x then y -> [N]."""
+    n0 = in0 / (torch.sqrt(torch.sum(in0 ** 2, dim=1, keepdim=True)) + eps)
+    n1 = in1 / (torch.sqrt(torch.sum(in1 ** 2, dim=1, keepdim=True)) + eps)
+    return torch.mean(torch.mean(torch.sum(n0 * n1, dim=1), dim=1), dim=1)
+
+
+class PNet(nn.Module):
+    """networks_basic.py:13-64."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("shift", torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1))
+        self.register_buffer("scale", torch.tensor([.458, .448, .450]).view(1, 3, 1, 1))
+        self.net = AlexNetFeatures()
+
+    def forward(self, in0, in1):
+        f0 = self.net((in0 - self.shift) / self.scale)
+        f1 = self.net((in1 - self.shift) / self.scale)
+        val = 0
+        for a, b in zip(f0, f1):
+            val = val + (1. - cos_sim(a, b))
+        return val
+
+
+class PerceptualLoss(object):
+    """nnutils/perceptual_loss.py:38-57."""
+
+    def __init__(self, device=None, state_dict=None):
+        self.model = PNet()
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        if device is not None:
+            self.model.to(device)
+        self.model.eval()
+
+    def __call__(self, pred, target, normalize=True):
+        if normalize:
+            target = 2 * target - 1
+            pred = 2 * pred - 1
+        return self.model(target, pred)     # forward_pair(target, pred)
+
+
+class PerceptualTextureLoss(object):
+    """nnutils/loss_utils.py:128-150."""
+
+    def __init__(self, device=None):
+        self.perceptual_loss = PerceptualLoss(device)
+
+    def __call__(self, img_pred, img_gt, mask_gt, mask_pred=None, avg=True):
+        mask_gt = mask_gt.unsqueeze(1)
+        if mask_pred is not None:
+            dist = self.perceptual_loss(img_pred * mask_pred.unsqueeze(1), img_gt * mask_gt)
+        else:
+            dist = self.perceptual_loss(img_pred * mask_gt, img_gt * mask_gt)
+        return dist.mean() if avg else dist

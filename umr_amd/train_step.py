@@ -119,3 +119,91 @@ class RenderCompareS1(nn.Module):
             + terms["tex"] * w.tex_loss_wt + terms["tex_dt"] * w.tex_dt_loss_wt \
             + terms["tex_cycle"] * w.tex_cycle_loss_wt + terms["gan"] * w.gan_loss_wt
         return total, terms
+
+
+class S2Weights:
+    """experiments/train_s2.py:49-60 defaults."""
+    mask_loss_wt = 2.5
+    gan_loss_wt = 1.0
+    triangle_reg_wt = 0.15
+    flatten_reg_wt = 0.0005
+    tex_loss_wt = 3.0
+    tex_dt_loss_wt = 3.0
+    tex_cycle_loss_wt = 1.0
+    ent_loss_wt = 0.05
+    prob_loss_wt = 5.0
+    vertex_loss_wt = 10.0
+    deform_reg_wt = 1.0
+
+
+class RenderCompareS2(nn.Module):
+    """train_s2 render-and-compare (experiments/train_s2.py:201-316): K=8 camera hypotheses, 22 raster forwards and
+    21 backwards per image: MultiMaskLoss (8), MultiTextureLoss (8 + 1 hard), GAN view (1), part matching (4),
+    chamfer vertex-part correspondence.
+
+    outputs: pred_vs [B,V,3], delta_v, mean_shape [V,3], cam [B,7], cam_hypotheses [B,K,7], cam_probs [B,K], tex_flow
+    batch:   imgs, masks, dts_barrier, gan_angles [B], part_segs [B,5,H,H], random_imgs [B,3,H,H] (previous step's
+             masked images, :268), head/belly/back/neck_points [B,n,2]
+    """
+
+    def __init__(self, template_verts, faces, part_vertex_ids, uv_img, uv_sampler, image_size=256, num_hypo_cams=8,
+                 weights=None, texture_loss_type="perceptual", discriminator=None, num_sym_faces=0, tex_size=6):
+        super().__init__()
+        self.w = weights or S2Weights()
+        self.K = num_hypo_cams
+        self.register_buffer("faces", faces.long())
+        self.mask_loss_fn = loss_utils.MultiMaskLoss(image_size, "softmax", num_hypo_cams)          # :127-129
+        self.laplacian_loss_fn = loss_utils.LaplacianLoss(template_verts, faces)                    # :135
+        self.flatten_loss_fn = loss_utils.FlattenLoss(faces)                                        # :136
+        self.texture_loss_fn = loss_utils.MultiTextureLoss(0, num_hypo_cams, image_size, "softmax", texture_loss_type)
+        self.corr_loss_fn = loss_utils.CorrLossChamfer(part_vertex_ids, image_size)                 # :152
+        self.part_loss_fn = loss_utils.part_matching_loss(uv_img, uv_sampler, num_sym_faces, im_size=image_size,
+                                                          tex_size=tex_size)                        # :154-161
+        self.dis_renderer = SoftRenderer(image_size, "softmax")                                     # :105-106
+        self.dis_renderer.ambient_light_only()
+        self.dis_renderer.need_p2f = False
+        self.discriminator = discriminator
+
+    def forward(self, outputs, batch):
+        w, K = self.w, self.K
+        pred_vs, delta_v = outputs["pred_vs"], outputs["delta_v"]
+        B = pred_vs.shape[0]
+        faces = self.faces[None].expand(B, -1, -1)
+        imgs, masks = batch["imgs"], batch["masks"]
+        proj_cam = outputs["cam"].detach()
+        cams_all_hypo, cam_probs = outputs["cam_hypotheses"], outputs["cam_probs"]
+        t = {}
+        t["cam_div"] = -1 * (torch.log(cam_probs + 1E-9) * cam_probs).sum(1).mean()                 # :222
+        t["mask"], mask_all_hypo = self.mask_loss_fn(pred_vs, faces, cams_all_hypo, cam_probs, masks)
+        t["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
+        t["flatten"] = self.flatten_loss_fn(pred_vs).mean()
+        t["deform"] = loss_utils.deform_l2reg(delta_v)
+        tex_flow = outputs["tex_flow"]
+        tex = geom_utils.sample_textures(tex_flow, imgs)
+        bs, fs = tex.shape[:2]
+        tex = tex.reshape(bs, fs, -1, 3)
+        t["tex"], t["tex_dt"], t["tex_cycle"], _ = self.texture_loss_fn(
+            pred_vs.detach(), faces, cams_all_hypo.detach(), cam_probs.detach(), proj_cam, imgs, masks, mask_all_hypo,
+            tex, tex_flow, batch["dts_barrier"])
+        random_cams = rotate_cam_y(proj_cam, batch["gan_angles"])                                   # :257-258
+        pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, random_cams, tex.detach())            # :260
+        if self.discriminator is not None:
+            pred = torch.cat((batch["random_imgs"], pred_unseen[:, 0:3]))
+            labels = torch.cat((torch.ones(B, device=pred.device), torch.zeros(B, device=pred.device)))
+            t["gan"] = nn.functional.binary_cross_entropy_with_logits(self.discriminator(pred).view(-1), labels)
+        else:
+            t["gan"] = pred_unseen[:, 0:3].mean()
+        part_loss, _ = self.part_loss_fn(pred_vs, faces, proj_cam, batch["part_segs"])              # :294-296
+        t["part"] = torch.mean(part_loss)
+        mean_shape = outputs["mean_shape"][None].expand(B, -1, -1)
+        rep = lambda x: x.unsqueeze(1).repeat(1, K, 1, 1).view(-1, x.size(1), x.size(2))
+        # NOTE the reference passes (head, belly, back, neck) into parameters named (head, belly, neck, back)
+        # (:311 vs loss_utils.py:223); the swapped pair carries weight 0, kept as is.
+        corr = self.corr_loss_fn(rep(batch["head_points"]), rep(batch["belly_points"]), rep(batch["back_points"]),
+                                 rep(batch["neck_points"]), rep(mean_shape), cams_all_hypo.reshape(-1, 7), avg=False)
+        t["corr"] = (corr.view(B, K) * cam_probs.detach()).sum(dim=1).mean()                        # :313-314
+        total = t["mask"] * w.mask_loss_wt + t["triangle"] * w.triangle_reg_wt + t["flatten"] * w.flatten_reg_wt \
+            + t["deform"] * w.deform_reg_wt + t["tex"] * w.tex_loss_wt + t["tex_dt"] * w.tex_dt_loss_wt \
+            + t["tex_cycle"] * w.tex_cycle_loss_wt + t["gan"] * w.gan_loss_wt + t["cam_div"] * w.ent_loss_wt \
+            + t["part"] * w.prob_loss_wt + t["corr"] * w.vertex_loss_wt
+        return total, t
