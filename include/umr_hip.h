@@ -75,6 +75,16 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * them, e.g. MultiMaskLoss, nnutils/loss_utils.py:265).
  * -------------------------------------------------------------------------------------------*/
 #define UMR_RASTER_NO_P2F 1
+/* flags bit 1: silhouette only.  For renders of which only the alpha channel is consumed (the mask render of
+ * MultiMaskLoss / train_s1.py:199-200, the GAN-view render train_s1.py:235-236): the kernel evaluates the soft
+ * coverage only -- alpha = 1 - prod(1 - D_f) does not depend on depth, colour or the depth-range test (:396
+ * precedes :404) -- and `soft_colors` / `pooled_out` are then ALPHA PLANES [N,IS,IS] / [N,IS/2,IS/2];
+ * textures, aggrs_info, grid, p2f_* may be NULL.  Bit-identical alpha to the full kernel. */
+#define UMR_RASTER_ALPHA_ONLY 2
+/* umr_raster_backward `grad_is_pooled` is a bit field: */
+#define UMR_BWD_GRAD_POOLED 1   /* gradient arrives at the 2x2-pooled resolution */
+#define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb
+                                   gradient is zero, which is what "only alpha is consumed" means; needs need_grad_faces */
 
 size_t umr_raster_workspace_bytes(int N, int F);
 

@@ -379,3 +379,24 @@ def test_train_s2_step_vs_oracle(oracle_built):
         r = out_c[k].grad.numpy()
         s = np.abs(r).max()
         assert_close_frac(t2n(out_g[k].grad), r, atol=5e-4 * s, rtol=1e-2, frac=0.97, name="grad_" + k)
+
+
+def test_silhouette_only_kernels_match_full_kernels():
+    """UMR_RASTER_ALPHA_ONLY: alpha bit-identical to the full render's channel 3; gradients equal the full backward's
+    when the rgb gradient is zero (what "only alpha is consumed" means)."""
+    from umr_amd.smr import SoftRenderer
+    verts, faces, cams, gen = scene(3, 3, seed=13)
+    gi = torch.randn(3, 256, 256, generator=gen).to(DEV)
+    res = []
+    for ao in (False, True):
+        v = verts.to(DEV).requires_grad_(True)
+        c = cams.to(DEV).requires_grad_(True)
+        r = SoftRenderer(256, "softmax")
+        r.alpha_only = ao
+        imgs, _, _ = r(v, faces.to(DEV), c)
+        (imgs[:, 3] * gi).sum().backward()
+        res.append((imgs[:, 3].detach(), v.grad, c.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for i in (1, 2):
+        s = float(res[0][i].abs().max())
+        assert float((res[0][i] - res[1][i]).abs().max()) <= 2e-5 * s

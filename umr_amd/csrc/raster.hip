@@ -70,7 +70,8 @@ struct RasterArgs {
 
 // ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
 __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
-                             float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr) {
+                             float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
+                             float near_, float far_) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float *f = faces + (size_t)i * 9;
@@ -124,7 +125,12 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     }
     // depth chain may use reciprocal-multiply division only when every z is an ordinary positive number
     const bool sane = z0 > 1e-20f && z1 > 1e-20f && z2 > 1e-20f && z0 < 1e20f && z1 < 1e20f && z2 < 1e20f;
-    r[R_FLAGS] = __int_as_float((obt + 1) | (sane ? 0 : 4));  // bits 0-1: obtuse corner + 1 (0 = none); bit 2: slow
+    // bit 3: every vertex depth strictly inside (near, far) => the interpolated depth (a convex combination of the
+    // 1/z_k with positive clipped weights) can never be rejected by the depth-range test (:404, :592)
+    const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
+    const bool inrange = sane && zmin > near_ * 1.0001f && zmax < far_ * 0.9999f;
+    // bits 0-1: obtuse corner + 1 (0 = none); bit 2: slow division path
+    r[R_FLAGS] = __int_as_float((obt + 1) | (sane ? 0 : 4) | (inrange ? 8 : 0));
     r[R_FRONT] = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1.f : 0.f;  // :42-44
     // vector of the obtuse-corner override test (:116,:119,:122): corner k -> p_{k+2} - p_k
     const int ob = obt < 0 ? 0 : obt;
@@ -173,6 +179,7 @@ struct Face {  // wave-uniform: 32 SGPRs + the record's address
     __device__ __forceinline__ int obt() const { return (__float_as_int(g<R_FLAGS>()) & 3) - 1; }
     __device__ __forceinline__ bool front() const { return g<R_FRONT>() != 0.f; }
     __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
+    __device__ __forceinline__ bool depth_in_range() const { return (__float_as_int(g<R_FLAGS>()) & 8) != 0; }
 };
 
 __device__ __forceinline__ void load_face(Face &fc, const float *rg) {
@@ -373,7 +380,8 @@ __device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int RGB>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437)
+template <int RGB>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
+                    // 2 = silhouette only: alpha plane, no depth / colour / p2f (soft_colors is then [N,IS,IS])
 __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs A) {
     __shared__ int s_list[LIST_CAP];
     __shared__ int s_wcnt[BLK_THREADS / 64];
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, gx = 0.f, gy = 0.f;
     float depth_min = 10000000.f;
     int face_min = -1;
-    if (t.valid) {
+    if (t.valid && RGB != 2) {
         if (A.bg_arg) { c0 = A.bg0; c1 = A.bg1; c2 = A.bg2; }
         else {
             const float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
@@ -432,9 +440,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                 Pair p;
                 if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis)) {
                     alpha *= 1.f - p.frag;  // 'prod' alpha (:396), BEFORE the depth-range test
-                    float q0, q1, q2;
-                    const float zp = clip_depth(q0, q1, q2, p, fc);
-                    if (!(zp < A.near_ || zp > A.far_)) {
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f, zp = 0.f;
+                    if (RGB != 2) zp = clip_depth(q0, q1, q2, p, fc);
+                    if (RGB != 2 && !(zp < A.near_ || zp > A.far_)) {
                         if (RGB == 0) {
                             const bool inside = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
                             if (zp < depth_min && inside && (A.double_side || fc.front())) {
@@ -475,9 +483,20 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
     }
 
     if (!t.wave_on) return;
+    const float o3 = 1.f - alpha;
+    if (RGB == 2) {
+        if (t.valid) A.soft_colors[(size_t)t.n * npix + pn] = o3;
+        if (A.pooled) {
+            const int H = IS >> 1;
+            float sv = o3 + __shfl_xor(o3, 1, 64);
+            sv += __shfl_xor(sv, 8, 64);
+            if (t.valid && !(t.lane & 1) && !(t.lane & 8))
+                A.pooled[((size_t)t.n * H + (t.row >> 1)) * H + (t.xi >> 1)] = 0.25f * sv;
+        }
+        return;
+    }
     // epilogue (:442-475)
     float o0, o1, o2;
-    const float o3 = 1.f - alpha;
     if (RGB == 0) { o0 = c0; o1 = c1; o2 = c2; }
     else { o0 = c0 / ssum; o1 = c1 / ssum; o2 = c2 / ssum; }
     if (t.valid) {
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // face record lives in SGPRs for the whole walk.  Per-pixel state is re-read once per overlapping face
 // (~6x, L1/L2 hits: consecutive faces of a subdivided mesh are spatial neighbours and share a workgroup).
 #define FM_WAVES 4
-template <int RGB, bool NEED_GF, bool NEED_GT>
+template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][TS*3]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -694,6 +713,25 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                     Pair p;
                     if (!eval_pair(p, fc, xp, yp, A.threshold, A.nis)) continue;
                     const size_t pn = (size_t)row * IS + xi;
+                    if (RGB == 2) {  // silhouette: d alpha only (:584, :632-642); soft_colors/grad are [N,IS,IS] | [N,H,H]
+                        if (!fc.depth_in_range()) {
+                            float u0, u1, u2;
+                            const float zq = clip_depth(u0, u1, u2, p, fc);
+                            if (zq < A.near_ || zq > A.far_) continue;  // :592
+                        }
+                        const float ga = A.grad_pooled
+                            ? 0.25f * A.grad_colors[((size_t)n * (IS >> 1) + (row >> 1)) * (IS >> 1) + (xi >> 1)]
+                            : A.grad_colors[(size_t)n * npix + pn];
+                        const float oa = A.soft_colors[(size_t)n * npix + pn];
+                        float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
+                        c_a *= p.frag * (1.f - p.frag) * (-A.nis);
+                        const float k2a = 2.f * p.sign * c_a;
+                        const float a0 = k2a * p.b0, a1 = k2a * p.b1, a2 = k2a * p.b2;
+                        gv[0] += a0 * p.dx; gv[1] += a0 * p.dy;
+                        gv[3] += a1 * p.dx; gv[4] += a1 * p.dy;
+                        gv[6] += a2 * p.dx; gv[7] += a2 * p.dy;
+                        continue;
+                    }
                     float g0, g1, g2, g3;
                     if (A.grad_pooled) {
                         const int H = IS >> 1;
@@ -782,7 +820,8 @@ void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
     const long total = (long)A.N * A.F;
     const int blocks = (int)((total + FM_WAVES - 1) / FM_WAVES);
     const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * A.TS * 3 * sizeof(float) : 0;
-    if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    if (RGB == 2) k_raster_backward_fm<2, true, false><<<blocks, FM_WAVES * 64, 0, st>>>(A);
+    else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
     else if (A.need_gf) k_raster_backward_fm<RGB, true, false><<<blocks, FM_WAVES * 64, lds, st>>>(A);
     else k_raster_backward_fm<RGB, false, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
 }
@@ -868,11 +907,13 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                        int flags, const float *background, void *workspace, size_t workspace_bytes,
                        void *stream) {
     int R = 0;
-    if (!faces || !textures || !aggrs_info || !soft_colors || !workspace) return UMR_ERR_ARG;
+    const bool alpha_only = (flags & UMR_RASTER_ALPHA_ONLY) != 0;
+    if (!faces || !soft_colors || !workspace) return UMR_ERR_ARG;
+    if (!alpha_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
     if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
-    const int with_p2f = func_id_rgb == 1 && !(flags & UMR_RASTER_NO_P2F);
+    const int with_p2f = func_id_rgb == 1 && !alpha_only && !(flags & UMR_RASTER_NO_P2F);
     if (with_p2f && (!grid || !p2f_info || !p2f_sum)) return UMR_ERR_ARG;
     if (pooled_out && (image_size & 1)) return UMR_ERR_ARG;
     if ((long long)N * ((image_size + BLK_W - 1) / BLK_W) * ((image_size + BLK_H - 1) / BLK_H) > 0x7fffffffLL)
@@ -893,12 +934,16 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     if (background) { A.bg_arg = 1; A.bg0 = background[0]; A.bg1 = background[1]; A.bg2 = background[2]; }
     const int total = N * F;
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
-                                                      sqrtf(A.threshold));
+                                                      sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
     {
         // algorithmic bytes of one forward launch: 24 IS^2 + F (36 + 12 TS + 16) per mesh
-        ProfScope ps(st, 0, (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
-        if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
+        // (silhouette-only launches are accounted separately, id 2: 4 IS^2 + 36 F)
+        ProfScope ps(st, alpha_only ? 2 : 0,
+                     alpha_only ? (double)N * (4.0 * image_size * image_size + 36.0 * F)
+                                : (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
+        if (alpha_only) k_raster_forward<2><<<blocks, BLK_THREADS, 0, st>>>(A);
+        else if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
         else k_raster_forward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
     }
     return umr_launch_status();
@@ -914,7 +959,11 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
                         void *stream) {
     (void)faces_info;  // recomputed into the workspace (bit-identical: same kernel, same input)
     int R = 0;
-    if (!faces || !textures || !soft_colors || !aggrs_info || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
+    const bool alpha_only = (grad_is_pooled & UMR_BWD_ALPHA_ONLY) != 0;
+    grad_is_pooled &= UMR_BWD_GRAD_POOLED;
+    if (!faces || !soft_colors || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
+    if (!alpha_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
+    if (alpha_only && (need_grad_textures || !need_grad_faces)) return UMR_ERR_ARG;
     if ((need_grad_faces && !grad_faces) || (need_grad_textures && !grad_textures)) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
@@ -937,15 +986,19 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     const int total = N * F;
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
-                                                      sqrtf(A.threshold));
+                                                      sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
     {
         // algorithmic bytes of one backward launch: per mesh (40 | 28 when the gradient
         // arrives 2x2-pooled: 4 instead of 16 B/pixel) IS^2 + F (180 + 24 TS)
         const double px = grad_is_pooled ? 28.0 : 40.0;
-        ProfScope ps(st, 1, (double)N * (px * image_size * image_size + (double)F * (180.0 + 24.0 * TS)));
+        // (silhouette-only launches, id 3: alpha + its gradient per pixel, faces + grad_faces per face)
+        ProfScope ps(st, alpha_only ? 3 : 1,
+                     alpha_only ? (double)N * ((grad_is_pooled ? 5.0 : 8.0) * image_size * image_size + 72.0 * F)
+                                : (double)N * (px * image_size * image_size + (double)F * (180.0 + 24.0 * TS)));
         const bool lds_ok = (size_t)FM_WAVES * TS * 3 * sizeof(float) <= 48 * 1024;
-        if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
+        if (alpha_only) launch_backward_fm<2>(A, st);
+        else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
             if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
             else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
         } else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);

@@ -108,6 +108,52 @@ class SoftRasterizeFunction(Function):
         return (gf, grad_textures) + (None,) * 15
 
 
+class SilhouetteFunction(Function):
+    """Alpha channel of the soft render only (UMR_RASTER_ALPHA_ONLY): face_vertices [N,F,3,3] -> alpha [N,S,S]
+    with S = image_size (or image_size/2 when `pool`).  Bit-identical to channel 3 of SoftRasterizeFunction; the
+    backward is the reference's with a zero rgb gradient (mask / GAN-view renders)."""
+
+    @staticmethod
+    def forward(ctx, face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
+        L = _lib.lib()
+        dev = face_vertices.device
+        fv = _f32c(face_vertices)
+        N, F = fv.shape[:2]
+        IS = int(image_size)
+        ctx.cfg = (IS, float(near), float(far), float(eps), float(sigma_val), 2, float(math.log(1. / dist_eps - 1.)),
+                   float(gamma_val), 1, 2, 0, 1 if fill_back else 0)
+        ctx.pool = bool(pool)
+        alpha = torch.empty(N, IS, IS, device=dev, dtype=torch.float32)
+        pooled = torch.empty(N, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
+        ws_bytes = L.umr_raster_workspace_bytes(N, F)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
+        rc = L.umr_raster_forward(ptr(fv), None, None, None, None, None, None, ptr(alpha), ptr(pooled), N, F, 1, IS_,
+                                  near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds, 2 | 1, None, ptr(ws),
+                                  ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_raster_forward(alpha only)")
+        ctx.save_for_backward(fv, alpha)
+        ctx.fv_shape = face_vertices.shape
+        return pooled if pool else alpha
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        fv, alpha = ctx.saved_tensors
+        dev = fv.device
+        N, F = fv.shape[:2]
+        grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32)
+        g = g.to(torch.float32).contiguous()
+        ws_bytes = L.umr_raster_workspace_bytes(N, F)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
+        rc = L.umr_raster_backward(ptr(fv), None, ptr(alpha), None, None, ptr(grad_faces), None, ptr(g),
+                                   2 | (1 if ctx.pool else 0), 1, 0, N, F, 1, IS_, near_, far_, eps_, sig, fd, de, gam,
+                                   frgb, fal, fsm, ds, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_raster_backward(alpha only)")
+        return (grad_faces.view(ctx.fv_shape),) + (None,) * 9
+
+
 def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',

@@ -68,6 +68,7 @@ class MultiMaskLoss(nn.Module):
         super(MultiMaskLoss, self).__init__()
         self.renderer = SoftRenderer(image_size, renderer_type)
         self.renderer.need_p2f = False       # the reference discards p2f/aggr here (:265)
+        self.renderer.alpha_only = True      # ... and reads the alpha channel only (:266)
         self.num_hypo_cams = num_hypo_cams
         self.image_size = image_size
 

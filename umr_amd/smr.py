@@ -33,6 +33,9 @@ class SoftRenderer(torch.nn.Module):
         self.offset_z = 5.           # smr.py:66
         self.near, self.far, self.eps = 1., 100., 1e-3   # renderer.py:48-49
         self.need_p2f = True         # set False to skip the p2f accumulators (callers that discard them)
+        # set True when only imgs[:, 3] is consumed (mask / GAN-view renders): the silhouette-only kernels run,
+        # rgb channels of the returned image hold the background colour, p2f is zeros and aggr is None
+        self.alpha_only = False
 
     def ambient_light_only(self):
         """smr.py:68-71."""
@@ -64,6 +67,15 @@ class SoftRenderer(torch.nn.Module):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
         textures None | [N,F,TS,3]."""
         faces = faces.int().contiguous()                                  # smr.py:81
+        if self.alpha_only:
+            _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
+            size = self.img_size * (2 if self.anti_aliasing else 1)
+            alpha = UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
+                                                self.dist_eps, self.gamma_val, self.anti_aliasing)
+            N, S = alpha.shape[0], alpha.shape[1]
+            bg = alpha.new_tensor(self.background_color).view(1, 3, 1, 1).expand(N, 3, S, S)
+            imgs = torch.cat([bg, alpha.unsqueeze(1)], dim=1)
+            return imgs, alpha.new_zeros(N, faces.shape[1], 2), None
         directional = self.light_intensity_directional != 0
         face_pre, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z,
                                                            directional)

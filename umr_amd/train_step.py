@@ -70,6 +70,9 @@ class RenderCompareS1(nn.Module):
         # outputs nobody reads are not computed: only tex_renderer's p2f is consumed (:226)
         self.renderer.need_p2f = False
         self.dis_renderer.need_p2f = False
+        # ... and of the mask (:200) and unseen-view (:236) renders only the alpha channel is read
+        self.renderer.alpha_only = True
+        self.dis_renderer.alpha_only = True
         self.laplacian_loss_fn = loss_utils.LaplacianLoss(template_verts, faces)   # :141
         self.flatten_loss_fn = loss_utils.FlattenLoss(faces)                       # :142
         self.texture_cycle_fn = loss_utils.TexCycle()
