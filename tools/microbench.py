@@ -43,7 +43,7 @@ def bench(N, subdiv, IS, TS, rgb="softmax", iters=10, need_gf=True, need_gt=True
                 fwd_us_per_mesh=round(tf * 1e3 / N, 2), bwd_us_per_mesh=round(tb * 1e3 / N, 2))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--alpha" not in sys.argv:
     print(torch.cuda.get_device_name(0))
     for cfg in [(16, 3, 512, 1), (16, 3, 512, 36), (128, 3, 512, 1), (128, 3, 512, 36)]:
         print(json.dumps(bench(*cfg)), flush=True)
@@ -51,3 +51,30 @@ if __name__ == "__main__":
     print("no-p2f + fused pool:", json.dumps(bench(128, 3, 512, 36, pool=True, need_p2f=False, need_gf=False)), flush=True)
     print(json.dumps(bench(16, 3, 512, 1, rgb="hard", need_gf=False, need_gt=False)), flush=True)
     print(json.dumps(bench(32, 4, 1024, 36)), flush=True)
+
+
+def bench_alpha(N, subdiv, IS, iters=10, pool=True):
+    dev = torch.device("cuda:0")
+    verts, faces, cams, gen = scene(N, subdiv, seed=0)
+    _, fv = UF.ProjectFacesFunction.apply(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732, False)
+    fv = fv.detach().requires_grad_(True)
+    H = IS // 2 if pool else IS
+    g = torch.randn(N, H, H, device=dev)
+    tf = tb = 0.0
+    for it in range(iters + 2):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        fv.grad = None
+        e0.record()
+        a = UF.SilhouetteFunction.apply(fv, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, pool)
+        e1.record()
+        a.backward(g)
+        e2.record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            tf += e0.elapsed_time(e1); tb += e1.elapsed_time(e2)
+    return dict(kind="alpha_only", N=N, IS=IS, fwd_us_per_mesh=round(tf / iters * 1e3 / N, 2), bwd_us_per_mesh=round(tb / iters * 1e3 / N, 2))
+
+
+if __name__ == "__main__" and "--alpha" in sys.argv:
+    print(json.dumps(bench_alpha(16, 3, 512)), flush=True)
+    print(json.dumps(bench_alpha(128, 3, 512)), flush=True)

@@ -16,7 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
          "-munsafe-fp-atomics",   # native global_atomic_add_f32 instead of CAS loops
          "-ffp-contract=off",     # branch-deciding expressions round like the reference's float code
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 
 def _stale():

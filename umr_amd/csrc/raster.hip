@@ -209,38 +209,37 @@ __device__ __forceinline__ float div_r(float a, float b, float r) {
 // sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
 __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, float yp, float threshold,
                                           float neg_inv_sigma) {
-    if (xp > fc.g<R_XHI>() || xp < fc.g<R_XLO>() || yp > fc.g<R_YHI>() || yp < fc.g<R_YLO>()) return false;
+    // Written branch-free (predicates + selects): per-lane divergence would otherwise cost ~80 scalar
+    // exec-mask instructions per face visit.  Dead lanes compute garbage that the returned predicate masks.
+    const bool inb = !((xp > fc.g<R_XHI>()) | (xp < fc.g<R_XLO>()) | (yp > fc.g<R_YHI>()) | (yp < fc.g<R_YLO>()));
     // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
     // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
     const float w0 = (fc.g<R_INV + 0>() * xp + fc.g<R_INV + 1>() * yp) + fc.g<R_INV + 2>();
     const float w1 = (fc.g<R_INV + 3>() * xp + fc.g<R_INV + 4>() * yp) + fc.g<R_INV + 5>();
     const float w2 = (fc.g<R_INV + 6>() * xp + fc.g<R_INV + 7>() * yp) + fc.g<R_INV + 8>();
     p.w0 = w0; p.w1 = w1; p.w2 = w2;
-    const bool inside = w0 > 0 && w1 > 0 && w2 > 0 && w0 < 1 && w1 < 1 && w2 < 1;
-    int k;  // nearest boundary edge (k, k+1)
-    if (inside) {
-        // nearest edge LINE: first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
-        // corner k+2 and its squared distance is w_c^2 K_c
-        const float m0 = w2 * w2 * fc.g<R_K2>(), m1 = w0 * w0 * fc.g<R_K0>(), m2 = w1 * w1 * fc.g<R_K1>();
-        k = 0;
-        float best = m0;
-        if (m1 < best) { best = m1; k = 1; }
-        if (m2 < best) { k = 2; }
-    } else {
-        // region selection (:112-126)
-        const int ob = fc.obt();
-        const float cx = ob == 0 ? fc.g<R_X0>() : (ob == 1 ? fc.g<R_X1>() : fc.g<R_X2>());
-        const float cy = ob == 0 ? fc.g<R_Y0>() : (ob == 1 ? fc.g<R_Y1>() : fc.g<R_Y2>());
-        const bool ovr = (xp - cx) * fc.g<R_OX>() + (yp - cy) * fc.g<R_OY>() > 0;
-        k = -1;
-        if (w1 <= 0 && w2 <= 0) k = (ob == 0 && ovr) ? 2 : 0;
-        else if (w2 <= 0 && w0 <= 0) k = (ob == 1 && ovr) ? 0 : 1;
-        else if (w0 <= 0 && w1 <= 0) k = (ob == 2 && ovr) ? 1 : 2;
-        else if (w0 <= 0) k = 1;
-        else if (w1 <= 0) k = 2;
-        else if (w2 <= 0) k = 0;
-        if (k < 0) return false;  // reference UB (index -1); defined here and in the oracle as "skip"
-    }
+    const bool inside = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
+    // inside: nearest edge LINE, first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
+    // corner k+2 and its squared distance is w_c^2 K_c
+    const float m0 = w2 * w2 * fc.g<R_K2>(), m1 = w0 * w0 * fc.g<R_K0>(), m2 = w1 * w1 * fc.g<R_K1>();
+    const bool c1 = m1 < m0;
+    const float best = c1 ? m1 : m0;
+    const int kin = (m2 < best) ? 2 : (c1 ? 1 : 0);
+    // outside: region selection (:112-126), lowest priority first so the highest-priority match is applied last
+    const int ob = fc.obt();
+    const float cx = ob == 0 ? fc.g<R_X0>() : (ob == 1 ? fc.g<R_X1>() : fc.g<R_X2>());
+    const float cy = ob == 0 ? fc.g<R_Y0>() : (ob == 1 ? fc.g<R_Y1>() : fc.g<R_Y2>());
+    const bool ovr = (xp - cx) * fc.g<R_OX>() + (yp - cy) * fc.g<R_OY>() > 0;
+    const bool n0 = w0 <= 0, n1 = w1 <= 0, n2 = w2 <= 0;
+    int kout = n2 ? 0 : -1;
+    kout = n1 ? 2 : kout;
+    kout = n0 ? 1 : kout;
+    kout = (n0 & n1) ? (((ob == 2) & ovr) ? 1 : 2) : kout;
+    kout = (n2 & n0) ? (((ob == 1) & ovr) ? 0 : 1) : kout;
+    kout = (n1 & n2) ? (((ob == 0) & ovr) ? 2 : 0) : kout;
+    const int ksel = inside ? kin : kout;
+    const bool kvalid = ksel >= 0;  // k = -1: reference UB (index -1); defined here and in the oracle as "skip"
+    const int k = max(ksel, 0);
     // t[v0] = (w . a - a[v1]) / (a[v0] - a[v1]) in the reference's operation order (:86,:137); IEEE-exact
     // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
     // D ~ exp(-d^2/sigma) ~ 1e-9, amplifying rounding noise in d^2 ~20x: parity there needs the reference's
@@ -248,8 +247,9 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, flo
     const float4 ea = fc.edges[2 * k], eb = fc.edges[2 * k + 1];  // {a0,a1,a2,a[v1]}, {den, 1/den, -, -}
     const float tv = div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
     const bool k0 = k == 0, k1 = k == 1;
-    float ba = tv, bb = 1.f - tv;  // unclamped inside (:86-88)
-    if (!inside) { ba = fminf(fmaxf(ba, 0.f), 1.f); bb = fminf(fmaxf(bb, 0.f), 1.f); }  // :142-145
+    const float tb = 1.f - tv;
+    const float ba = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f);  // unclamped inside (:86-88), clamped outside (:142-145)
+    const float bb = inside ? tb : fminf(fmaxf(tb, 0.f), 1.f);
     const float b0 = k0 ? ba : (k1 ? 0.f : bb);
     const float b1 = k0 ? bb : (k1 ? ba : 0.f);
     const float b2 = k0 ? 0.f : (k1 ? bb : ba);
@@ -257,13 +257,12 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, flo
     const float dx = (t0 * fc.g<R_X0>() + t1 * fc.g<R_X1>()) + t2 * fc.g<R_X2>();  // :95-96, :148-149
     const float dy = (t0 * fc.g<R_Y0>() + t1 * fc.g<R_Y1>()) + t2 * fc.g<R_Y2>();
     const float dis = dx * dx + dy * dy;
-    if (!inside && dis >= threshold) return false;
     p.b0 = b0; p.b1 = b1; p.b2 = b2; p.dx = dx; p.dy = dy;
     p.sign = inside ? 1.f : -1.f;
     // 1 / (1 + exp(-sign * dis / sigma))
     const float e = __expf((inside ? dis : -dis) * neg_inv_sigma);
     p.frag = __builtin_amdgcn_rcpf(1.f + e);
-    return true;
+    return inb & kvalid & (inside | !(dis >= threshold));  // rejects of :355, :382
 }
 
 // barycentric_clip (:54-59) + perspective-correct depth (:403).  The soft-max weights are exp(zn/gamma) with
@@ -438,11 +437,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                 load_face(fc, rec_n + (size_t)f * REC);
                 float wgt = 0.f;  // this lane's p2f weight for face f
                 Pair p;
-                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis)) {
+                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis) & t.valid;
+                if (RGB == 2) {
+                    alpha *= live ? 1.f - p.frag : 1.f;
+                } else if (live) {
                     alpha *= 1.f - p.frag;  // 'prod' alpha (:396), BEFORE the depth-range test
-                    float q0 = 0.f, q1 = 0.f, q2 = 0.f, zp = 0.f;
-                    if (RGB != 2) zp = clip_depth(q0, q1, q2, p, fc);
-                    if (RGB != 2 && !(zp < A.near_ || zp > A.far_)) {
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                    const float zp = clip_depth(q0, q1, q2, p, fc);
+                    if (!(zp < A.near_ || zp > A.far_)) {
                         if (RGB == 0) {
                             const bool inside = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
                             if (zp < depth_min && inside && (A.double_side || fc.front())) {
