@@ -653,10 +653,13 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // face record lives in SGPRs for the whole walk.  Per-pixel state is re-read once per overlapping face
 // (~6x, L1/L2 hits: consecutive faces of a subdivided mesh are spatial neighbours and share a workgroup).
 #define FM_WAVES 4
+#ifndef FM_RELOAD_PER_TILE
+#define FM_RELOAD_PER_TILE 1
+#endif
 template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][TS*3]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
     const int F = A.F, IS = A.IS, TS = A.TS;
     const long fid = (long)blockIdx.x * FM_WAVES + wave;          // (n, f) flattened
     const bool live = fid < (long)A.N * F;
@@ -707,6 +710,14 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                     tm &= tm - 1;
                     const int tsel = tb + tbit;
                     const int tx = tx0 + tsel % ntx, ty = ty0 + tsel / ntx;
+#if FM_RELOAD_PER_TILE
+                    {   // re-fetch the record from the scalar cache every tile: keeps the 32 constants loop-VARIANT so the
+                        // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop (which cost 2 waves/SIMD)
+                        const float *rp = A.rec + ((size_t)n * F + f) * REC;
+                        asm volatile("" : "+s"(rp));
+                        load_face(fc, rp);
+                    }
+#endif
                     const int row = ty * 8 + (lane >> 3);
                     const int xi = tx * 8 + (lane & 7);
                     if (xi >= IS || row >= IS) continue;
