@@ -209,6 +209,17 @@ int umr_flatten_backward(const float *x, const int *quads, const float *grad_los
  * -------------------------------------------------------------------------------------------*/
 int umr_visible_face_mask(const float *face_ids, float *mask, int B, long P, int F, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Barrier distance transform.  Replaces utils/image.py:130-141 (compute_dt_barrier), two scipy EDTs per image per
+ * step on the host (experiments/train_s2.py:196):
+ *   out = sigmoid(k * (EDT(1 - mask) - EDT(mask)) / max(H, W)),   mask [B,H,W] (non-zero = foreground)
+ * sq_out / sq_in (optional, int32 [B,H,W]) receive the exact squared distances of the two transforms.
+ * workspace: umr_dt_barrier_workspace_bytes(B, H, W).
+ * -------------------------------------------------------------------------------------------*/
+size_t umr_dt_barrier_workspace_bytes(int B, int H, int W);
+int umr_dt_barrier(const float *mask, float *out, int *sq_out, int *sq_in, int B, int H, int W, float k,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

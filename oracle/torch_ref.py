@@ -348,3 +348,13 @@ def cos_sim_distance(feats0, feats1, eps=1e-10):
         n1 = f1 / (torch.sqrt(torch.sum(f1 ** 2, dim=1, keepdim=True)) + eps)
         val = val + (1. - torch.mean(torch.mean(torch.sum(n0 * n1, dim=1), dim=1), dim=1))
     return val
+
+
+def compute_dt_barrier(mask, k=50):
+    """utils/image.py:130-141 (numpy + scipy; scipy is the EDT oracle)."""
+    from scipy.ndimage import distance_transform_edt
+    mask = np.asarray(mask)
+    dist_out = distance_transform_edt(1 - mask)
+    dist_in = distance_transform_edt(mask)
+    dist_diff = (dist_out - dist_in) / max(mask.shape)
+    return 1. / (1 + np.exp(k * -dist_diff)), dist_out, dist_in

@@ -400,3 +400,33 @@ def test_silhouette_only_kernels_match_full_kernels():
     for i in (1, 2):
         s = float(res[0][i].abs().max())
         assert float((res[0][i] - res[1][i]).abs().max()) <= 2e-5 * s
+
+
+def test_dt_barrier_vs_scipy():
+    """EDT kernel: squared distances bit-exact (integer work) against scipy; barrier value within 1e-6."""
+    from oracle import torch_ref
+    from umr_amd.image_utils import compute_dt_barrier
+    g = torch.Generator().manual_seed(2)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing="ij")
+    masks = []
+    for i in range(4):   # blobs, a ragged noise mask, a single pixel
+        c = torch.rand(3, 2, generator=g) - 0.5
+        r = 0.15 + 0.3 * torch.rand(3, generator=g)
+        m = sum((((xx - c[j, 0]) ** 2 + (yy - c[j, 1]) ** 2) < r[j] ** 2).float() for j in range(3)).clamp(max=1)
+        masks.append(m)
+    masks.append((torch.rand(256, 256, generator=g) > 0.7).float())
+    one = torch.zeros(256, 256); one[17, 200] = 1
+    masks.append(one)
+    m = torch.stack(masks)
+    out, so, si = compute_dt_barrier(m.to(DEV), return_squared=True)
+    for i in range(m.shape[0]):
+        ref, d_out, d_in = torch_ref.compute_dt_barrier(m[i].numpy())
+        assert np.array_equal(t2n(so[i]), np.rint(d_out ** 2).astype(np.int32))
+        assert np.array_equal(t2n(si[i]), np.rint(d_in ** 2).astype(np.int32))
+        np.testing.assert_allclose(t2n(out[i]), ref, atol=1e-6)
+    # non-square, non multiple of 64
+    m2 = (torch.rand(2, 70, 45, generator=g) > 0.6).float()
+    o2, so2, _ = compute_dt_barrier(m2.to(DEV), return_squared=True)
+    ref, d_out, _ = torch_ref.compute_dt_barrier(m2[1].numpy())
+    assert np.array_equal(t2n(so2[1]), np.rint(d_out ** 2).astype(np.int32))
+    np.testing.assert_allclose(t2n(o2[1]), ref, atol=1e-6)
