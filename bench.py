@@ -141,6 +141,15 @@ def main():
 
     images = args.batch * world * args.steps
     achieved = (b_bytes / 1e9) / (b_ms / 1e3) if b_ms > 0 else 0.0
+    # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+    # this very command, tools/collect_traffic.sh); bench.py cannot run the profiler on itself, so the committed
+    # per-launch figure is attached when it was measured for the same workload, else null.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("workload") == [args.batch, args.image_size, args.subdivide, bool(use_model)]:
+            traffic = tj.get("raster_backward_bytes_per_launch")
     out = {
         "metric": METRIC, "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -152,7 +161,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "includes_network": use_model,
                    "final_loss": float(loss)},
         "roofline": {"bound": "hbm", "kernel": "k_raster_backward", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "launches": b_n, "avg_us": (1e3 * b_ms / b_n) if b_n else None,
                      "alg_bytes_per_launch": (b_bytes / b_n) if b_n else None,
                      "forward_kernel": {"achieved": (f_bytes / 1e9) / (f_ms / 1e3) if f_ms > 0 else 0.0,

@@ -318,6 +318,7 @@ class MeshNet(nn.Module):
 def build_training_step(tv, faces, args, dev, world):
     """One full train_s1 iteration on resident synthetic data: MeshNet fwd -> render-and-compare (HIP) -> bwd with
     bucketed RCCL all-reduce overlapped (DDP) -> Adam with the reference's lr schedule (train_utils.py:186-194)."""
+    from .image_utils import compute_dt_barrier
     from .parallel import wrap_ddp
     from .synthetic import make_s1_inputs
     from .train_step import RenderCompareS1
@@ -340,6 +341,8 @@ def build_training_step(tv, faces, args, dev, world):
         for g in opt.param_groups:
             g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)  # train_utils.py:194
         opt.zero_grad(set_to_none=True)
+        # the reference computes the barrier distance transform on the host in set_input (train_s1.py:171-174)
+        batch["dts_barrier"] = compute_dt_barrier(batch["masks"]).unsqueeze(1)
         out = ddp_net(input_imgs)
         out["pred_vs"] = net.get_mean_shape()[None] + net.symmetrize(out["delta_v"])   # train_s1.py:183-192
         total, _ = rc(out, batch)
