@@ -220,6 +220,14 @@ size_t umr_dt_barrier_workspace_bytes(int B, int H, int W);
 int umr_dt_barrier(const float *mask, float *out, int *sq_out, int *sq_in, int B, int H, int W, float k,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 2x bilinear up-sampling of the texture-flow decoder (nn.Upsample(scale_factor=2, mode='bilinear'),
+ * nnutils/net_blocks.py upconv2d; align_corners=False).  in [planes,H,W] -> out [planes,2H,2W]; backward is the
+ * exact transpose in gather form (deterministic).  grad_in is overwritten.
+ * -------------------------------------------------------------------------------------------*/
+int umr_upsample2x_bilinear_forward(const float *in, float *out, long planes, int H, int W, void *stream);
+int umr_upsample2x_bilinear_backward(const float *grad_out, float *grad_in, long planes, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,3 +430,19 @@ def test_dt_barrier_vs_scipy():
     ref, d_out, _ = torch_ref.compute_dt_barrier(m2[1].numpy())
     assert np.array_equal(t2n(so2[1]), np.rint(d_out ** 2).astype(np.int32))
     np.testing.assert_allclose(t2n(o2[1]), ref, atol=1e-6)
+
+
+def test_upsample2x_matches_torch():
+    """fp32 kernel vs the plain PyTorch op it replaces (values and gradient)."""
+    from umr_amd.functional import Upsample2xBilinearFunction
+    g = torch.Generator().manual_seed(4)
+    for shape in ((2, 3, 4, 8), (1, 5, 7, 3), (2, 16, 32, 64)):
+        x = torch.randn(*shape, generator=g).to(DEV)
+        go = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g).to(DEV)
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        ya = Upsample2xBilinearFunction.apply(a)
+        yb = torch.nn.functional.interpolate(b, scale_factor=2, mode='bilinear', align_corners=False)
+        ya.backward(go); yb.backward(go)
+        assert float((ya - yb).abs().max()) <= 1e-6     # fp32 tolerance
+        assert float((a.grad - b.grad).abs().max()) <= 1e-5

@@ -40,6 +40,8 @@ SIGNATURES = {
     "umr_flatten_forward": ([_P] * 3 + [_I, _I, _I, _P], _I),
     "umr_flatten_backward": ([_P] * 4 + [_I, _I, _I, _P], _I),
     "umr_visible_face_mask": ([_P, _P, _I, _L, _I, _P], _I),
+    "umr_upsample2x_bilinear_forward": ([_P, _P, _L, _I, _I, _P], _I),
+    "umr_upsample2x_bilinear_backward": ([_P, _P, _L, _I, _I, _P], _I),
     "umr_dt_barrier_workspace_bytes": ([_I, _I, _I], _Z),
     "umr_dt_barrier": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P], _I),
 }

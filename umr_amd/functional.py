@@ -387,3 +387,28 @@ def visible_face_mask(face_ids, num_faces):
     _lib.check(L.umr_visible_face_mask(ptr(ids), ptr(mask), B, P, num_faces, _lib.stream_ptr(ids.device)),
                "umr_visible_face_mask")
     return mask
+
+
+class Upsample2xBilinearFunction(Function):
+    """[B,C,H,W] -> [B,C,2H,2W], == F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        x_ = _f32c(x)
+        B, C, H, W = x_.shape
+        out = torch.empty(B, C, 2 * H, 2 * W, device=x_.device, dtype=torch.float32)
+        _lib.check(L.umr_upsample2x_bilinear_forward(ptr(x_), ptr(out), B * C, H, W, _lib.stream_ptr(x_.device)),
+                   "umr_upsample2x_bilinear_forward")
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        B, C, H, W = ctx.shape
+        g = g.to(torch.float32).contiguous()
+        gi = torch.empty(B, C, H, W, device=g.device, dtype=torch.float32)
+        _lib.check(L.umr_upsample2x_bilinear_backward(ptr(g), ptr(gi), B * C, H, W, _lib.stream_ptr(g.device)),
+                   "umr_upsample2x_bilinear_backward")
+        return gi

@@ -69,8 +69,19 @@ def conv2d(batch_norm, cin, cout, kernel_size=3, stride=1):
     return nn.Sequential(*layers)
 
 
+class Upsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='bilinear') (net_blocks.py upconv2d); on the GPU the fixed-2x HIP stencil
+    replaces PyTorch-ROCm's generic kernel (same values), on CPU (tests of the DDP harness) plain torch runs."""
+
+    def forward(self, x):
+        if x.is_cuda:
+            from .functional import Upsample2xBilinearFunction
+            return Upsample2xBilinearFunction.apply(x)
+        return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+
+
 def upconv2d(cin, cout, mode='bilinear'):
-    return nn.Sequential(nn.Upsample(scale_factor=2, mode=mode), nn.ReflectionPad2d(1),
+    return nn.Sequential(Upsample2x(), nn.ReflectionPad2d(1),
                          nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=0), nn.LeakyReLU(0.2, inplace=True))
 
 
