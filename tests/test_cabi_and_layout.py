@@ -84,3 +84,22 @@ def test_symmetric_mesh_counts_match_reference_constants():
     flip = np.array([1, -1, 1])
     assert np.array_equal(v2[n_ind + n_sym:], v2[n_ind:n_ind + n_sym] * flip)
     assert (v2[:n_ind, 1] == 0).all()
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Rejected calls return UMR_ERR_ARG before anything is enqueued (the reference only printf()s launch errors)."""
+    import ctypes
+    from umr_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(8)     # any non-NULL value: arguments are validated before being dereferenced on the device
+    z = [one] * 9
+    tail = [1.0, 100.0, 1e-3, 1e-5, 2, 23.0, 1e-4, 1, 2, 0, 1, 0, None, one, 1 << 30, None]
+    assert L.umr_raster_forward(*z, 0, 5, 1, 64, *tail) == -1        # N = 0 (empty batch)
+    assert L.umr_raster_forward(*z, 1, 0, 1, 64, *tail) == -1        # F = 0 (empty mesh)
+    assert L.umr_raster_forward(*z, 1, 5, 1, 0, *tail) == -1         # empty image
+    assert L.umr_raster_forward(*z, 1, 5, 1, 64, 1.0, 100.0, 1e-3, 1e-5, 2, 23.0, 1e-4, 1, 2, 0, 1, 0, None, one, 16, None) == -1  # workspace too small
+    assert L.umr_raster_forward(None, *z[1:], 1, 5, 1, 64, *tail) == -1  # NULL faces
+    assert L.umr_chamfer_forward(one, one, one, one, one, one, 1, 4, 4, 5, None) == -1   # D not in {2,3}
+    assert L.umr_dt_barrier(one, one, None, None, 1, 16, 16, 50.0, one, 8, None) == -1   # workspace too small
+    assert L.umr_project_faces_forward(one, one, one, None, one, 0, 4, 4, 5.0, -2.732, None) == -1
+    assert L.umr_debug_set(b"no_such_switch", 1) == -1

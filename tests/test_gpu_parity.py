@@ -446,3 +446,27 @@ def test_upsample2x_matches_torch():
         ya.backward(go); yb.backward(go)
         assert float((ya - yb).abs().max()) <= 1e-6     # fp32 tolerance
         assert float((a.grad - b.grad).abs().max()) <= 1e-5
+
+
+def test_cfg4_size_vs_oracle(oracle_built):
+    """BASELINE config 4 shape: 2562-vertex / 5120-face mesh rendered at 512x512 (internal raster 1024^2), TS=36."""
+    from oracle import softras, torch_ref
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(1, 4, seed=8)
+    assert verts.shape[1] == 2562 and faces.shape[1] == 5120
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).contiguous()
+    tex = torch.rand(1, 5120, 36, 3, generator=gen)
+    gsc = torch.randn(1, 4, 1024, 1024, generator=gen)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4,
+               func_id_rgb=1, double_side=True)
+    nt = softras.max_threads()
+    o = softras.raster_forward(fv.numpy(), tex.numpy(), 1024, backend="port", n_threads=nt, **cfg)
+    gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                     gsc.numpy(), 1024, backend="port", n_threads=nt, **cfg)
+    fvd, texd = fv.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True)
+    sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 1024, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
+    sc.backward(gsc.to(DEV))
+    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.999, max_outlier=1.0, name="soft_colors")
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="gt")
