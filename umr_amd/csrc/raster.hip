@@ -440,7 +440,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                 const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis) & t.valid;
                 if (RGB == 2) {
                     alpha *= live ? 1.f - p.frag : 1.f;
-                } else if (live) {
+                    continue;
+                }
+                if (live) {
                     alpha *= 1.f - p.frag;  // 'prod' alpha (:396), BEFORE the depth-range test
                     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
@@ -734,9 +736,28 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                     if (xi >= IS || row >= IS) continue;
                     const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
                     const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                    const size_t pn = (size_t)row * IS + xi;
+                    // Exact tile skips from the saved forward state, before any geometry:
+                    //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
+                    //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
+                    //    is >= 89 gamma behind the pixel's soft-max maximum (hard mode: the face is not the winner).
+                    {
+                        bool dead;
+                        if (RGB == 2) {
+                            dead = A.soft_colors[(size_t)n * npix + pn] == 1.f;
+                        } else {
+                            dead = false;
+                            if (!NEED_GF) {   // (with vertex gradients both terms must vanish: too rare to pay for)
+                                const float smx = A.aggrs[((size_t)n * 2 + 1) * npix + pn];
+                                const float zmin_f = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
+                                dead = RGB == 0 ? (float)f != smx
+                                                : ((A.far_ - zmin_f) * A.r_range - smx) * A.inv_gamma < -89.f;
+                            }
+                        }
+                        if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;
+                    }
                     Pair p;
                     if (!eval_pair(p, fc, xp, yp, A.threshold, A.nis)) continue;
-                    const size_t pn = (size_t)row * IS + xi;
                     if (RGB == 2) {  // silhouette: d alpha only (:584, :632-642); soft_colors/grad are [N,IS,IS] | [N,H,H]
                         if (!fc.depth_in_range()) {
                             float u0, u1, u2;
