@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--model", type=int, default=-1, help="1: include MeshNet fwd/bwd + all-reduce + Adam; 0: hot path only")
     ap.add_argument("--cpu-baseline", type=int, default=-1, help="1/0; default: on for N=1")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU sample (0 = auto)")
+    ap.add_argument("--workload", default="s1", choices=["s1", "s2"],
+                    help="s1 = BASELINE configs[1] (headline); s2 = train_s2 sequence of configs[2]/[3] (8 camera hypotheses)")
     return ap.parse_args()
 
 
@@ -90,7 +92,11 @@ def main():
     torch.manual_seed(1234 + rank)   # per-rank synthetic shard (weak scaling: fixed per-GPU batch)
     tv, faces, outputs, batch = make_s1_inputs(args.batch, args.image_size, args.subdivide, seed=100 + rank, device=dev)
     step_fn = None
-    if use_model:
+    if args.workload == "s2":
+        from umr_amd.model import build_training_step_s2
+        use_model = True
+        step_fn = build_training_step_s2(args, dev, world)
+    elif use_model:
         from umr_amd.model import build_training_step
         step_fn = build_training_step(tv, faces, args, dev, world)
     else:
@@ -148,14 +154,17 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("workload") == [args.batch, args.image_size, args.subdivide, bool(use_model)]:
+        if args.workload == "s1" and tj.get("workload") == [args.batch, args.image_size, args.subdivide, bool(use_model)]:
             traffic = tj.get("raster_backward_bytes_per_launch")
     out = {
         "metric": METRIC, "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: 4 raster fwd + 3 bwd "
-                               "per image + IoU/texture/tex-cycle/Laplacian/flatten losses, fwd+bwd%s"
+        "config": {"workload": ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: 4 raster fwd + 3 bwd "
+                                "per image + IoU/texture/tex-cycle/Laplacian/flatten losses, fwd+bwd%s"
+                                if args.workload == "s1" else
+                                "train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: 22 raster "
+                                "fwd + 21 bwd per image + mask/perceptual-texture/tex-cycle/part/chamfer losses, fwd+bwd%s")
                                % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
                                   "; MeshNet fwd/bwd + RCCL all-reduce + Adam" if use_model else "; network excluded"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "includes_network": use_model,
@@ -167,7 +176,7 @@ def main():
                      "forward_kernel": {"achieved": (f_bytes / 1e9) / (f_ms / 1e3) if f_ms > 0 else 0.0,
                                         "launches": f_n, "avg_us": (1e3 * f_ms / f_n) if f_n else None}},
     }
-    want_cpu = (world == 1) if args.cpu_baseline < 0 else bool(args.cpu_baseline)
+    want_cpu = (world == 1 and args.workload == "s1") if args.cpu_baseline < 0 else bool(args.cpu_baseline)
     if want_cpu:
         from oracle import softras
         n = args.cpu_sample or max(1, min(args.batch, softras.max_threads() // 2))

@@ -364,3 +364,47 @@ def build_training_step(tv, faces, args, dev, world):
 
     step.model = model
     return step
+
+
+def build_training_step_s2(args, dev, world):
+    """One full train_s2 iteration (experiments/train_s2.py:201-316, 409-444): MeshNet with K=8 camera hypotheses ->
+    22 raster forwards + 21 backwards per image + mask / texture (AlexNet perceptual) / part / chamfer losses ->
+    backward with DDP all-reduce -> Adam.  SCOPS data being absent, part labels / points are synthetic."""
+    from .image_utils import compute_dt_barrier
+    from .parallel import wrap_ddp
+    from .synthetic import make_s2_inputs
+    from .train_step import RenderCompareS2
+    opts = default_opts(subdivide=args.subdivide, batch_size=args.batch, multiple_cam_hypo=True)
+    net = MeshNet((args.image_size, args.image_size), opts, nz_feat=opts.nz_feat).to(dev)
+    disc = Discriminator(opts.grl_wt, in_dim=3, img_size=args.image_size).to(dev)     # train_s2.py:91-93: rgb input
+    model = nn.ModuleDict(dict(net=net, disc=disc))
+    ddp_net, ddp_disc = wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world)
+    rank = torch.distributed.get_rank() if world > 1 else 0
+    _, _, _, batch, ex = make_s2_inputs(args.batch, opts.num_hypo_cams, args.image_size, args.subdivide, seed=100 + rank,
+                                        device=dev)
+    rc = RenderCompareS2(net.get_mean_shape().detach(), net.faces, ex["part_vertex_ids"], ex["uv_img"],
+                         net.uv_sampler, args.image_size, opts.num_hypo_cams, texture_loss_type="perceptual",
+                         discriminator=ddp_disc, tex_size=opts.tex_size).to(dev)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
+                           betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))
+    mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    input_imgs = (batch["imgs"] - mean) / std
+    state = dict(it=0)
+
+    def step():
+        for g in opt.param_groups:
+            g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)
+        opt.zero_grad(set_to_none=True)
+        batch["dts_barrier"] = compute_dt_barrier(batch["masks"]).unsqueeze(1)        # train_s2.py:196
+        out = ddp_net(input_imgs)
+        out["mean_shape"] = net.get_mean_shape()
+        out["pred_vs"] = out["mean_shape"][None] + net.symmetrize(out["delta_v"])
+        total, _ = rc(out, batch)
+        total.backward()
+        opt.step()
+        batch["random_imgs"] = (batch["imgs"] * batch["masks"].unsqueeze(1)).detach()  # :268
+        state["it"] += 1
+        return total.detach()
+
+    step.model = model
+    return step
