@@ -12,27 +12,52 @@ namespace {
 
 #define EDT_INF 30000   // > any in-image distance; EDT_INF^2 + W^2 < 2^31
 
-// one thread per column; features of EDT(1-mask) are mask != 0, features of EDT(mask) are mask == 0
+// one thread per column; features of EDT(1-mask) are mask != 0, features of EDT(mask) are mask == 0.
+// The sweep is serial in y, so rows are fetched in batches of 16 independent (coalesced-across-columns) loads:
+// one memory latency per 16 rows instead of one per row (314 us -> tens of us for 16 x 256^2).
+#define EDT_BATCH 16
 __global__ void k_edt_columns(const float *__restrict__ mask, int *__restrict__ g, int H, int W) {
     const int b = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= W) return;
-    const float *m = mask + (size_t)b * H * W;
-    int *go = g + (size_t)b * 2 * H * W, *gi = go + (size_t)H * W;
+    const float *__restrict__ m = mask + (size_t)b * H * W + x;
+    int *__restrict__ go = g + (size_t)b * 2 * H * W + x;
+    int *__restrict__ gi = go + (size_t)H * W;
     int dofg = EDT_INF, dobg = EDT_INF;  // distance to the last foreground / background pixel seen
-    for (int y = 0; y < H; ++y) {
-        const bool fg = m[(size_t)y * W + x] != 0.f;
-        dofg = fg ? 0 : min(dofg + 1, EDT_INF);
-        dobg = fg ? min(dobg + 1, EDT_INF) : 0;
-        go[(size_t)y * W + x] = dofg;
-        gi[(size_t)y * W + x] = dobg;
+    for (int y0 = 0; y0 < H; y0 += EDT_BATCH) {
+        float mv[EDT_BATCH];
+#pragma unroll
+        for (int j = 0; j < EDT_BATCH; ++j) mv[j] = (y0 + j < H) ? m[(size_t)(y0 + j) * W] : 0.f;
+#pragma unroll
+        for (int j = 0; j < EDT_BATCH; ++j) {
+            if (y0 + j >= H) break;
+            const bool fg = mv[j] != 0.f;
+            dofg = fg ? 0 : min(dofg + 1, EDT_INF);
+            dobg = fg ? min(dobg + 1, EDT_INF) : 0;
+            go[(size_t)(y0 + j) * W] = dofg;
+            gi[(size_t)(y0 + j) * W] = dobg;
+        }
     }
     dofg = dobg = EDT_INF;
-    for (int y = H - 1; y >= 0; --y) {
-        const bool fg = m[(size_t)y * W + x] != 0.f;
-        dofg = fg ? 0 : min(dofg + 1, EDT_INF);
-        dobg = fg ? min(dobg + 1, EDT_INF) : 0;
-        go[(size_t)y * W + x] = min(go[(size_t)y * W + x], dofg);
-        gi[(size_t)y * W + x] = min(gi[(size_t)y * W + x], dobg);
+    for (int y1 = H - 1; y1 >= 0; y1 -= EDT_BATCH) {
+        float mv[EDT_BATCH];
+        int vo[EDT_BATCH], vi[EDT_BATCH];
+#pragma unroll
+        for (int j = 0; j < EDT_BATCH; ++j) {
+            const int y = y1 - j;
+            mv[j] = y >= 0 ? m[(size_t)y * W] : 0.f;
+            vo[j] = y >= 0 ? go[(size_t)y * W] : 0;
+            vi[j] = y >= 0 ? gi[(size_t)y * W] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < EDT_BATCH; ++j) {
+            const int y = y1 - j;
+            if (y < 0) break;
+            const bool fg = mv[j] != 0.f;
+            dofg = fg ? 0 : min(dofg + 1, EDT_INF);
+            dobg = fg ? min(dobg + 1, EDT_INF) : 0;
+            go[(size_t)y * W] = min(vo[j], dofg);
+            gi[(size_t)y * W] = min(vi[j], dobg);
+        }
     }
 }
 
@@ -82,8 +107,8 @@ int umr_dt_barrier(const float *mask, float *out, int *sq_out, int *sq_in, int B
         return UMR_ERR_ARG;
     if (workspace_bytes < umr_dt_barrier_workspace_bytes(B, H, W)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 g1((W + 255) / 256, B);
-    k_edt_columns<<<g1, 256, 0, st>>>(mask, (int *)workspace, H, W);
+    dim3 g1((W + 63) / 64, B);   // 64-thread blocks: spread the (few) columns over more CUs
+    k_edt_columns<<<g1, 64, 0, st>>>(mask, (int *)workspace, H, W);
     dim3 g2(H, B);
     const int threads = W >= 256 ? 256 : ((W + 63) / 64) * 64;
     k_edt_rows<<<g2, threads, (size_t)2 * W * sizeof(int), st>>>((const int *)workspace, out, sq_out, sq_in, H, W, k,
