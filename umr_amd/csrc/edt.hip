@@ -29,12 +29,13 @@ __global__ void k_edt_columns(const float *__restrict__ mask, int *__restrict__ 
         for (int j = 0; j < EDT_BATCH; ++j) mv[j] = (y0 + j < H) ? m[(size_t)(y0 + j) * W] : 0.f;
 #pragma unroll
         for (int j = 0; j < EDT_BATCH; ++j) {
-            if (y0 + j >= H) break;
-            const bool fg = mv[j] != 0.f;
-            dofg = fg ? 0 : min(dofg + 1, EDT_INF);
-            dobg = fg ? min(dobg + 1, EDT_INF) : 0;
-            go[(size_t)(y0 + j) * W] = dofg;
-            gi[(size_t)(y0 + j) * W] = dobg;
+            if (y0 + j < H) {
+                const bool fg = mv[j] != 0.f;
+                dofg = fg ? 0 : min(dofg + 1, EDT_INF);
+                dobg = fg ? min(dobg + 1, EDT_INF) : 0;
+                go[(size_t)(y0 + j) * W] = dofg;
+                gi[(size_t)(y0 + j) * W] = dobg;
+            }
         }
     }
     dofg = dobg = EDT_INF;
@@ -51,12 +52,13 @@ __global__ void k_edt_columns(const float *__restrict__ mask, int *__restrict__ 
 #pragma unroll
         for (int j = 0; j < EDT_BATCH; ++j) {
             const int y = y1 - j;
-            if (y < 0) break;
-            const bool fg = mv[j] != 0.f;
-            dofg = fg ? 0 : min(dofg + 1, EDT_INF);
-            dobg = fg ? min(dobg + 1, EDT_INF) : 0;
-            go[(size_t)y * W] = min(vo[j], dofg);
-            gi[(size_t)y * W] = min(vi[j], dobg);
+            if (y >= 0) {
+                const bool fg = mv[j] != 0.f;
+                dofg = fg ? 0 : min(dofg + 1, EDT_INF);
+                dobg = fg ? min(dobg + 1, EDT_INF) : 0;
+                go[(size_t)y * W] = min(vo[j], dofg);
+                gi[(size_t)y * W] = min(vi[j], dobg);
+            }
         }
     }
 }

@@ -337,16 +337,20 @@ __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     t.row = py0 + (t.lane >> 3);
     t.valid = t.xi < IS && t.row < IS;
     t.wave_on = px0 < IS && py0 < IS;
-    t.xp = ndc_coord(t.xi, IS);
-    t.yp = ndc_coord(IS - 1 - t.row, IS);
-    t.bxlo = ndc_coord(bx * BLK_W, IS);
-    t.bxhi = ndc_coord(min(bx * BLK_W + BLK_W - 1, IS - 1), IS);
-    t.byhi = ndc_coord(IS - 1 - by * BLK_H, IS);
-    t.bylo = ndc_coord(IS - 1 - min(by * BLK_H + BLK_H - 1, IS - 1), IS);
-    t.wxlo = ndc_coord(px0, IS);
-    t.wxhi = ndc_coord(min(px0 + 7, IS - 1), IS);
-    t.wyhi = ndc_coord(IS - 1 - py0, IS);
-    t.wylo = ndc_coord(IS - 1 - min(py0 + 7, IS - 1), IS);
+    // pixel centres: exact float path when IS is a power of two (12 fp64 divisions per thread otherwise -- they
+    // were 40 % of the silhouette kernel's VALU instructions)
+    const bool pow2 = (IS & (IS - 1)) == 0;
+    const float inv_is = 1.f / (float)IS;
+    t.xp = ndc_coord_fast(t.xi, IS, inv_is, pow2);
+    t.yp = ndc_coord_fast(IS - 1 - t.row, IS, inv_is, pow2);
+    t.bxlo = ndc_coord_fast(bx * BLK_W, IS, inv_is, pow2);
+    t.bxhi = ndc_coord_fast(min(bx * BLK_W + BLK_W - 1, IS - 1), IS, inv_is, pow2);
+    t.byhi = ndc_coord_fast(IS - 1 - by * BLK_H, IS, inv_is, pow2);
+    t.bylo = ndc_coord_fast(IS - 1 - min(by * BLK_H + BLK_H - 1, IS - 1), IS, inv_is, pow2);
+    t.wxlo = ndc_coord_fast(px0, IS, inv_is, pow2);
+    t.wxhi = ndc_coord_fast(min(px0 + 7, IS - 1), IS, inv_is, pow2);
+    t.wyhi = ndc_coord_fast(IS - 1 - py0, IS, inv_is, pow2);
+    t.wylo = ndc_coord_fast(IS - 1 - min(py0 + 7, IS - 1), IS, inv_is, pow2);
 }
 
 // Block-level binning of faces [f0, f1) into the LDS list, ascending order.  Returns the count.
