@@ -358,3 +358,54 @@ def compute_dt_barrier(mask, k=50):
     dist_in = distance_transform_edt(mask)
     dist_diff = (dist_out - dist_in) / max(mask.shape)
     return 1. / (1 + np.exp(k * -dist_diff)), dist_out, dist_in
+
+
+# --------------------------------------------------------------------------- evaluation (BASELINE config 5)
+def draw_labelmap(img, pt, sigma):
+    """utils/kp_utils.py:42-69, numpy as in the reference."""
+    img = np.array(img, dtype=np.float64)
+    ul = [int(pt[0] - 3 * sigma), int(pt[1] - 3 * sigma)]
+    br = [int(pt[0] + 3 * sigma + 1), int(pt[1] + 3 * sigma + 1)]
+    if ul[0] >= img.shape[1] or ul[1] >= img.shape[0] or br[0] < 0 or br[1] < 0:
+        return img
+    size = 6 * sigma + 1
+    x = np.arange(0, size, 1, float)
+    y = x[:, np.newaxis]
+    x0 = y0 = size // 2
+    g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+    g_x = max(0, -ul[0]), min(br[0], img.shape[1]) - ul[0]
+    g_y = max(0, -ul[1]), min(br[1], img.shape[0]) - ul[1]
+    img_x = max(0, ul[0]), min(br[0], img.shape[1])
+    img_y = max(0, ul[1]), min(br[1], img.shape[0])
+    img[img_y[0]:img_y[1], img_x[0]:img_x[1]] = g[g_y[0]:g_y[1], g_x[0]:g_x[1]]
+    return img
+
+
+def map_kp_flow(kp_src, flow_src, flow_tgt, image_size=256, sigma=3):
+    """experiments/test_kp.py:125-158."""
+    theta = torch.tensor([[1., 0, 0], [0, 1., 0]]).unsqueeze(0)
+    sgrid = F.affine_grid(theta, (1, 2, image_size, image_size), align_corners=True).permute(0, 3, 1, 2)
+    nf = flow_tgt.size(0)
+    p2face = grid_sample(sgrid, flow_tgt.view(1, nf, -1, 2))
+    p2face = torch.mean(p2face, dim=-1).permute(0, 2, 1).squeeze()
+    kp_num = kp_src.size(0)
+    hp = torch.zeros(1, kp_num, image_size, image_size)
+    kp_pix = (kp_src[:, 0:2] + 1) / 2.0 * 256
+    for c in range(kp_num):
+        hp[0, c] = torch.from_numpy(draw_labelmap(hp[0, c].numpy(), (float(kp_pix[c][0]), float(kp_pix[c][1])), sigma)).float()
+    k2face = grid_sample(hp, flow_src.view(1, nf, -1, 2))
+    k2face = torch.mean(k2face, dim=-1)
+    _, idx = torch.max(k2face, dim=-1)
+    return p2face[idx.squeeze(0)]
+
+
+def map_kp_cam(kp_src, cam_src, cam_tgt, mask_tgt, mean_shape, image_size=256):
+    """experiments/test_kp.py:160-193."""
+    v_tgt = orthographic_proj_withz(mean_shape.view(1, -1, 3), cam_tgt.view(1, 7))[:, :, :2]
+    theta = torch.tensor([[1., 0, 0], [0, 1., 0]]).unsqueeze(0)
+    sgrid = F.affine_grid(theta, (1, 2, image_size, image_size), align_corners=True).squeeze().view(-1, 2)
+    fg_coords = sgrid[torch.nonzero(mask_tgt.view(-1)).squeeze(), :]
+    _, _, _, proj2fg_idx = dist_chamfer(fg_coords.unsqueeze(0), v_tgt)
+    v_src = orthographic_proj_withz(mean_shape.view(1, -1, 3), cam_src.view(1, 7))[:, :, :2]
+    _, _, kp2proj_idx, _ = dist_chamfer(kp_src[:, 0:2].unsqueeze(0), v_src)
+    return fg_coords[proj2fg_idx.squeeze().long()[kp2proj_idx.squeeze().long()], :]
