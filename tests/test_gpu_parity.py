@@ -518,3 +518,55 @@ def test_eval_metrics_vs_reference_restatement(oracle_built):
     nv = vis.numpy().sum(0)
     assert abs(p1 - (((err < 0.1) * vis.numpy()).sum(0) / nv).mean()) < 1e-6
     assert abs(p15 - (((err < 0.15) * vis.numpy()).sum(0) / nv).mean()) < 1e-6
+
+
+@pytest.mark.parametrize("rgb", ["softmax", "hard"])
+def test_front_face_culling_and_depth_range_vs_oracle(oracle_built, rgb):
+    """Paths UMR never takes but the boundary exposes: fill_back=False (front-face test, :42-44, :409, :418, :604)
+    and faces leaving [near, far] (alpha accumulated but colour / gradient skipped, :404 vs :592)."""
+    from oracle import softras, torch_ref
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(2, 2, seed=33)
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).contiguous()
+    tex = torch.rand(2, 320, 4, 3, generator=gen)
+    gsc = torch.randn(2, 4, 128, 128, generator=gen)
+    # near/far chosen INSIDE the mesh's depth extent so that a good part of the faces is rejected by the range test
+    zmid = float(fv[..., 2].mean())
+    cfg = dict(near=zmid - 0.35, far=zmid + 0.25, eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)),
+               gamma_val=1e-4, func_id_rgb={"hard": 0, "softmax": 1}[rgb], double_side=False)
+    o = softras.raster_forward(fv.numpy(), tex.numpy(), 128, n_threads=8, **cfg)
+    gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                     gsc.numpy(), 128, n_threads=8, **cfg)
+    fvd, texd = fv.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True)
+    sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 128, [0, 0, 0], cfg["near"], cfg["far"], False, 1e-3, 1e-5,
+                                      'euclidean', 1e-10, 1e-4, rgb, 'prod', 'surface')
+    sc.backward(gsc.to(DEV))
+    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.999, max_outlier=1.0, name="soft_colors")
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * max(np.abs(gt).max(), 1e-12), rtol=5e-3, frac=0.99, name="gt")
+    # and the silhouette-only kernels under the same depth range (the per-face "always in range" shortcut must not fire)
+    a = UF.SilhouetteFunction.apply(fv.to(DEV).requires_grad_(True), 128, cfg["near"], cfg["far"], False, 1e-3, 1e-5, 1e-10,
+                                    1e-4, False)
+    assert torch.equal(a, sc.detach()[:, 3])
+
+
+def test_degenerate_faces_do_not_poison_the_image():
+    """Zero-area and sliver triangles (the reference clamps |det| at 1e-10, :259): finite output, parity with the oracle."""
+    from oracle import softras, torch_ref
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(1, 1, seed=41)
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).contiguous().clone()
+    fv[0, 3, 1] = fv[0, 3, 0]                              # two coincident vertices (zero area)
+    fv[0, 7, 2] = 0.5 * (fv[0, 7, 0] + fv[0, 7, 1])       # three collinear vertices
+    fv[0, 11, 2, :2] = fv[0, 11, 1, :2] + 1e-7            # sliver
+    tex = torch.rand(1, 80, 1, 3, generator=gen)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4,
+               func_id_rgb=1, double_side=True)
+    o = softras.raster_forward(fv.numpy(), tex.numpy(), 64, n_threads=4, **cfg)
+    sc, _, _ = UF.soft_rasterize(fv.to(DEV), tex.to(DEV), 64, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
+    got = t2n(sc)
+    finite_ref = np.isfinite(o["soft_colors"])
+    assert np.isfinite(got[finite_ref]).all()
+    assert_close_frac(got[finite_ref], o["soft_colors"][finite_ref], atol=1e-4, frac=0.995, name="soft_colors")
