@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--model", type=int, default=-1, help="1: include MeshNet fwd/bwd + all-reduce + Adam; 0: hot path only")
     ap.add_argument("--cpu-baseline", type=int, default=-1, help="1/0; default: on for N=1")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU sample (0 = auto)")
+    ap.add_argument("--force-ddp", type=int, default=0,
+                    help="debug: create a 1-rank RCCL process group and wrap the model in DDP even when --gpus 1")
     ap.add_argument("--workload", default="s1", choices=["s1", "s2"],
                     help="s1 = BASELINE configs[1] (headline); s2 = train_s2 sequence of configs[2]/[3] (8 camera hypotheses)")
     return ap.parse_args()
@@ -78,9 +80,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" = RCCL on ROCm
 
     from umr_amd import _lib
@@ -95,10 +98,10 @@ def main():
     if args.workload == "s2":
         from umr_amd.model import build_training_step_s2
         use_model = True
-        step_fn = build_training_step_s2(args, dev, world)
+        step_fn = build_training_step_s2(args, dev, 2 if args.force_ddp else world)
     elif use_model:
         from umr_amd.model import build_training_step
-        step_fn = build_training_step(tv, faces, args, dev, world)
+        step_fn = build_training_step(tv, faces, args, dev, 2 if args.force_ddp else world)
     else:
         rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size).to(dev)
         leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
@@ -183,7 +186,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, n)
         out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

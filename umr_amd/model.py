@@ -342,7 +342,7 @@ def build_training_step(tv, faces, args, dev, world):
     # same update rule as train_utils.py:186-187; `fused` runs it as one multi-tensor kernel on the GPU
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
                            betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))
-    rank = torch.distributed.get_rank() if world > 1 else 0
+    rank = torch.distributed.get_rank() if (world > 1 and torch.distributed.is_initialized()) else 0
     _, _, _, batch = make_s1_inputs(args.batch, args.image_size, args.subdivide, seed=100 + rank, device=dev)
     mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
     input_imgs = (batch["imgs"] - mean) / std                         # train_s1.py:128-131,164
