@@ -103,3 +103,42 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.umr_dt_barrier(one, one, None, None, 1, 16, 16, 50.0, one, 8, None) == -1   # workspace too small
     assert L.umr_project_faces_forward(one, one, one, None, one, 0, 4, 4, 5.0, -2.732, None) == -1
     assert L.umr_debug_set(b"no_such_switch", 1) == -1
+
+
+def test_symmetric_face_ordering_matches_reference_constants():
+    """utils/mesh.py:102-195 restated: 32 self-mirrored faces + 624 mirrored pairs for the 642-vertex sphere
+    (the reference hard-codes num_sym_faces=624, nnutils/cub_mesh.py:125); pairs share vertex order."""
+    import numpy as np
+    from umr_amd.mesh import create_sphere, make_symmetric, make_faces_symmetric
+    v, f = create_sphere(3)
+    v2, f2, n_ind, n_sym = make_symmetric(v, f, axis=1)
+    f3, nif, nsf = make_faces_symmetric(v2, f2, n_ind, n_sym, axis=1)
+    assert (nif, nsf) == (32, 624) and f3.shape == (1280, 3)
+    assert sorted(map(tuple, np.sort(f3, 1))) == sorted(map(tuple, np.sort(f2, 1)))       # same face set
+    r, l = v2[f3[nif:nif + nsf]], v2[f3[nif + nsf:]]
+    assert np.array_equal(r * np.array([1, -1, 1]), l)
+    assert (r[..., 1].sum(1) >= l[..., 1].sum(1)).all()                                     # right = positive side
+    v4, f4 = create_sphere(4)
+    v4s, f4s, ni4, ns4 = make_symmetric(v4, f4, axis=1)
+    _, nif4, nsf4 = make_faces_symmetric(v4s, f4s, ni4, ns4, axis=1)
+    assert (ni4, ns4, nif4, nsf4) == (64, 1249, 64, 2528)                                    # SURVEY appendix D
+
+
+def test_checkpoint_and_obj_formats(tmp_path):
+    """Reference file formats: '<label>_net_<epoch>.pth' with un-prefixed keys; tolerant load; OBJ round trip."""
+    from umr_amd import io_utils
+    from umr_amd.model import MeshNet, default_opts
+    opts = default_opts(subdivide=1, nz_feat=16, z_dim=8)
+    a = MeshNet((64, 64), opts, nz_feat=16)
+    path = io_utils.save_network(torch.nn.DataParallel(a), "pred", "latest", str(tmp_path))
+    assert path.endswith("pred_net_latest.pth")
+    sd = torch.load(path)
+    assert not any(k.startswith("module.") for k in sd) and "encoder.resnet_conv.conv1.weight" in sd
+    b = MeshNet((64, 64), opts, nz_feat=16)
+    loaded = io_utils.load_network(b, "pred", "latest", str(tmp_path))
+    assert "uv_sampler" not in loaded and "shape_predictor.weight" in loaded
+    assert torch.equal(a.shape_predictor.weight, b.shape_predictor.weight)
+    io_utils.save_obj(str(tmp_path / "m.obj"), a.get_mean_shape(), a.faces)
+    lines = open(tmp_path / "m.obj").read().split("\n")
+    assert sum(l.startswith("v ") for l in lines) == 42 and sum(l.startswith("f ") for l in lines) == 80
+    assert min(int(t) for l in lines if l.startswith("f ") for t in l.split()[1:]) == 1

@@ -59,7 +59,15 @@ def _worker(rank, world, port, q):
     opt.step()
     checksum = float(sum(p.double().sum() for p in net.parameters()))
     means = parallel.mean_scalars({"loss": float(loss), "rank": float(rank)}, world)
-    q.put((rank, err, checksum, means["rank"]))
+    # stage-1 template update: per-rank feature sums over different numbers of samples -> identical new template
+    feats = torch.randn(5, 16, generator=torch.Generator().manual_seed(3))
+    local = feats[:2] if rank == 0 else feats[2:]
+    before = net.mean_v.clone()
+    parallel.update_template(net, local.sum(0), local.shape[0], world)
+    with torch.no_grad():
+        expect = before + net.shape_predictor(feats.mean(0, keepdim=True)).view(-1, 3)
+    terr = float((net.mean_v - expect).abs().max())
+    q.put((rank, max(err, terr), checksum, means["rank"]))
     dist.destroy_process_group()
 
 

@@ -71,3 +71,33 @@ def make_symmetric(verts, faces, axis=1):
     perm = np.empty(len(verts), dtype=np.int64)
     perm[order] = np.arange(len(verts))
     return verts[order], perm[faces], len(center), len(right)
+
+
+def make_faces_symmetric(verts, faces, num_indept_verts, num_sym_verts, axis=1):
+    """Face re-ordering of utils/mesh.py:102-195 for a vertex-symmetric mesh (output of make_symmetric):
+    [self-mirrored faces, right faces, left faces] where left face i is the mirror image of right face i WITH THE SAME
+    VERTEX ORDER (so per-face texels of the pair correspond).  Returns (faces, num_indept_faces, num_sym_faces)."""
+    n_i, n_s = num_indept_verts, num_sym_verts
+    twin = np.arange(len(verts))
+    twin[n_i:n_i + n_s] = np.arange(n_i + n_s, n_i + 2 * n_s)
+    twin[n_i + n_s:] = np.arange(n_i, n_i + n_s)
+    lut = {tuple(sorted(f)): i for i, f in enumerate(faces)}
+    done = np.zeros(len(faces), bool)
+    indept, right, left = [], [], []
+    for fid, face in enumerate(faces):
+        if done[fid]:
+            continue
+        mirrored = twin[face]                       # the mirror triangle, in THIS face's vertex order
+        if sorted(mirrored) == sorted(face):
+            indept.append(face)
+            done[fid] = True
+            continue
+        sym_fid = lut[tuple(sorted(mirrored))]      # KeyError => the mesh is not face-symmetric
+        moved = mirrored != face                    # vertices that are not on the mirror plane
+        if np.all(verts[face][moved, axis] < verts[mirrored][moved, axis]):
+            left.append(face); right.append(mirrored)
+        else:
+            left.append(mirrored); right.append(face)
+        done[fid] = done[sym_fid] = True
+    assert len(indept) + len(right) + len(left) == len(faces)
+    return np.vstack([np.array(indept).reshape(-1, 3), np.array(right), np.array(left)]).astype(np.int64), len(indept), len(right)

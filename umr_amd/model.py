@@ -25,7 +25,8 @@ from . import mesh as mesh_utils
 
 def default_opts(**kw):
     """The absl flags of nnutils/cub_mesh.py:29-48 + train_utils.py as plain attributes."""
-    o = dict(symmetric=True, multiple_cam_hypo=False, nz_feat=200, z_dim=350, num_hypo_cams=8, use_texture=True,
+    o = dict(symmetric=True, symmetric_texture=True, multiple_cam_hypo=False, nz_feat=200, z_dim=350, num_hypo_cams=8,
+             use_texture=True,
              tex_size=6, subdivide=3, batch_size=16, gpu_num=1, scale_lr_decay=0.05, scale_bias=1.0, pred_cam=True,
              learning_rate=1e-4, beta1=0.9, grl_wt=0.2)
     o.update(kw)
@@ -266,17 +267,22 @@ def compute_uvsampler(verts, faces, tex_size):
 
 
 class MeshNet(nn.Module):
-    """nnutils/cub_mesh.py:366-507.  Vertex symmetry about `axis` is implemented (delta_v is predicted for the
-    on-plane + right-half vertices and mirrored); the face re-ordering of utils/mesh.py:102-195 (symmetric texture)
-    is not: the texture predictor emits all F faces."""
+    """nnutils/cub_mesh.py:366-507.  Symmetric about `axis`: delta_v is predicted for the on-plane + right-half
+    vertices and mirrored (:487-504); with `symmetric_texture` the texture-flow is predicted for the self-mirrored +
+    right faces and copied to the left faces (:417-446, :159-162), faces being ordered by utils/mesh.py:102-195."""
 
     def __init__(self, input_shape, opts, nz_feat=100, axis=1, temp_path=None):
         super().__init__()
         self.opts = opts
         self.symmetric = opts.symmetric
         verts, faces = mesh_utils.create_sphere(opts.subdivide)
+        self.symmetric_texture = bool(getattr(opts, "symmetric_texture", False)) and self.symmetric
+        self.num_indept_faces, self.num_sym_faces = faces.shape[0], 0
         if self.symmetric:
             verts, faces, self.num_indept, self.num_sym = mesh_utils.make_symmetric(verts, faces, axis)
+            if self.symmetric_texture:
+                faces, self.num_indept_faces, self.num_sym_faces = mesh_utils.make_faces_symmetric(
+                    verts, faces, self.num_indept, self.num_sym, axis)
             self.num_output = self.num_indept + self.num_sym
             flip = torch.ones(1, 3)
             flip[0, axis] = -1
@@ -291,10 +297,12 @@ class MeshNet(nn.Module):
         self.shape_predictor.weight.data.normal_(0, 0.0001)           # cub_mesh.py:176-177
         self.cam_predictor = MultiCamPredictor(nz_feat, opts.num_hypo_cams) if opts.multiple_cam_hypo else Camera(nz_feat)
         T = opts.tex_size
-        uv = torch.from_numpy(compute_uvsampler(verts, faces, T)).float().view(1, faces.shape[0], T * T, 2)
+        num_faces = self.num_indept_faces + self.num_sym_faces if self.symmetric_texture else faces.shape[0]   # :418-421
+        uv = torch.from_numpy(compute_uvsampler(verts, faces[:num_faces], T)).float().view(1, num_faces, T * T, 2)
         self.register_buffer("uv_sampler", uv)
-        img_H = int(2 ** np.floor(np.log2(np.sqrt(faces.shape[0]) * T)))
-        self.texture_predictor = TexturePredictorUV(nz_feat, faces.shape[0], T, img_H=img_H, img_W=2 * img_H)
+        img_H = int(2 ** np.floor(np.log2(np.sqrt(num_faces) * T)))                                            # :438
+        self.texture_predictor = TexturePredictorUV(nz_feat, num_faces, T, img_H=img_H, img_W=2 * img_H,
+                                                    num_sym_faces=self.num_sym_faces if self.symmetric_texture else 0)
         net_init(self.texture_predictor)
 
     def forward(self, img=None):
@@ -309,7 +317,7 @@ class MeshNet(nn.Module):
             cam = torch.cat([c[:, 5:6], c[:, 6:8], c[:, 0:4]], dim=1)
             inds = torch.zeros(cam.size(0), 1, dtype=torch.long, device=cam.device)
             probs = inds.float() + 1 + 0 * c[:, 4:5]   # keeps the (unused) prob head in the autograd graph for DDP
-        out.update(mean=mean, logvar=logvar, cam_sample_inds=inds, cam_probs=probs, cam=cam, noise=noise)
+        out.update(mean=mean, logvar=logvar, cam_sample_inds=inds, cam_probs=probs, cam=cam, noise=noise, feat=noise)
         tex, uvimg = self.texture_predictor(img_feat, self.uv_sampler.expand(img.size(0), -1, -1, -1))
         out['tex_flow'], out['uvimage_pred'] = tex, uvimg
         return out

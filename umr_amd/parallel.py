@@ -52,3 +52,19 @@ def mean_scalars(values, world):
                      device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t)
     return {k: float(x) / world for k, x in zip(keys, t)}
+
+
+@torch.no_grad()
+def update_template(net, feat_sum, n_samples, world):
+    """Stage-1 template update (experiments/train_s1.py:386-411) under data parallelism: every rank accumulates the
+    encoder feature of ITS shard over an epoch; sum and count are all-reduced so all ranks feed the same dataset-mean
+    feature to the shape predictor and add the same delta to `mean_v` (replicas stay identical without a broadcast).
+    net: the un-wrapped MeshNet; feat_sum [z_dim] local sum of outputs['feat'] rows; n_samples local row count."""
+    t = torch.cat([feat_sum.reshape(-1).double(), torch.tensor([float(n_samples)], dtype=torch.float64,
+                                                               device=feat_sum.device)])
+    if world > 1:
+        dist.all_reduce(t)
+    mean_feat = (t[:-1] / t[-1]).to(feat_sum.dtype).unsqueeze(0)
+    delta_v = net.shape_predictor(mean_feat).view(-1, 3)
+    net.mean_v += delta_v
+    return delta_v
