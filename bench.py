@@ -34,8 +34,8 @@ METRIC = "train images/sec (CUB 256^2, 642-vert mesh)"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)   # covers MIOpen's first-use kernel search on a fresh box
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--subdivide", type=int, default=3)
