@@ -81,6 +81,10 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * precedes :404) -- and `soft_colors` / `pooled_out` are then ALPHA PLANES [N,IS,IS] / [N,IS/2,IS/2];
  * textures, aggrs_info, grid, p2f_* may be NULL.  Bit-identical alpha to the full kernel. */
 #define UMR_RASTER_ALPHA_ONLY 2
+/* flags bit 2: visibility only (hard mode): writes aggrs_info = (nearest depth, its face id | -1) and nothing
+ * else -- what TexCycle consumes from the hard renderer (nnutils/loss_utils.py:327-328, train_s1.py:223-224).
+ * soft_colors, textures, grid, p2f_* may be NULL.  Bit-identical planes to the full hard kernel. */
+#define UMR_RASTER_FACE_ID_ONLY 4
 /* umr_raster_backward `grad_is_pooled` is a bit field: */
 #define UMR_BWD_GRAD_POOLED 1   /* gradient arrives at the 2x2-pooled resolution */
 #define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb

@@ -570,3 +570,16 @@ def test_degenerate_faces_do_not_poison_the_image():
     finite_ref = np.isfinite(o["soft_colors"])
     assert np.isfinite(got[finite_ref]).all()
     assert_close_frac(got[finite_ref], o["soft_colors"][finite_ref], atol=1e-4, frac=0.995, name="soft_colors")
+
+
+def test_visibility_only_kernel_matches_hard_render():
+    """UMR_RASTER_FACE_ID_ONLY: (depth, face id) planes bit-identical to the full hard-mode forward."""
+    from umr_amd.smr import SoftRenderer
+    verts, faces, cams, gen = scene(3, 3, seed=17)
+    full = SoftRenderer(256, "hard")
+    fast = SoftRenderer(256, "hard")
+    fast.ids_only = True
+    _, p2f_a, aggr_a = full(verts.to(DEV), faces.to(DEV), cams.to(DEV))
+    img, p2f_b, aggr_b = fast(verts.to(DEV), faces.to(DEV), cams.to(DEV))
+    assert img is None and torch.equal(aggr_a, aggr_b) and torch.equal(p2f_a, p2f_b)
+    assert float(aggr_b[:, 1].max()) > 0 and float(aggr_b[:, 1].min()) == -1.0

@@ -384,7 +384,8 @@ __device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4
 
 // ------------------------------------------------------------------------------------------------
 template <int RGB>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
-                    // 2 = silhouette only: alpha plane, no depth / colour / p2f (soft_colors is then [N,IS,IS])
+                    // 2 = silhouette only: alpha plane, no depth / colour / p2f (soft_colors is then [N,IS,IS]),
+                    // 3 = visibility only: the hard z-buffer's (depth, face id) planes, nothing else
 __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs A) {
     __shared__ int s_list[LIST_CAP];
     __shared__ int s_wcnt[BLK_THREADS / 64];
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, gx = 0.f, gy = 0.f;
     float depth_min = 10000000.f;
     int face_min = -1;
-    if (t.valid && RGB != 2) {
+    if (t.valid && RGB < 2) {
         if (A.bg_arg) { c0 = A.bg0; c1 = A.bg1; c2 = A.bg2; }
         else {
             const float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
@@ -440,6 +441,26 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                 Face fc;
                 load_face(fc, rec_n + (size_t)f * REC);
                 float wgt = 0.f;  // this lane's p2f weight for face f
+                if (RGB == 3) {
+                    // z-buffer winner only (:408-411): needs the bbox test, the barycentrics, the depth -- no distance.
+                    // A pixel inside [0,1]^3 is never rejected by the distance threshold (inside: sign > 0; on the
+                    // boundary: d = 0), except the defined-as-skip k = -1 case (no w <= 0 yet some w >= 1).
+                    const float w0 = (fc.g<R_INV + 0>() * t.xp + fc.g<R_INV + 1>() * t.yp) + fc.g<R_INV + 2>();
+                    const float w1 = (fc.g<R_INV + 3>() * t.xp + fc.g<R_INV + 4>() * t.yp) + fc.g<R_INV + 5>();
+                    const float w2 = (fc.g<R_INV + 6>() * t.xp + fc.g<R_INV + 7>() * t.yp) + fc.g<R_INV + 8>();
+                    const bool inb = !((t.xp > fc.g<R_XHI>()) | (t.xp < fc.g<R_XLO>()) | (t.yp > fc.g<R_YHI>()) | (t.yp < fc.g<R_YLO>()));
+                    const bool incl = (w0 <= 1) & (w0 >= 0) & (w1 <= 1) & (w1 >= 0) & (w2 <= 1) & (w2 >= 0);
+                    const bool strict = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
+                    const bool cand = inb & incl & t.valid & (strict | (w0 <= 0) | (w1 <= 0) | (w2 <= 0)) &
+                                      (A.double_side | fc.front());
+                    if (__any(cand)) {
+                        Pair pw; pw.w0 = w0; pw.w1 = w1; pw.w2 = w2;
+                        float q0, q1, q2;
+                        const float zp = clip_depth(q0, q1, q2, pw, fc);
+                        if (cand & !(zp < A.near_ || zp > A.far_) & (zp < depth_min)) { depth_min = zp; face_min = f; }
+                    }
+                    continue;
+                }
                 Pair p;
                 const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis) & t.valid;
                 if (RGB == 2) {
@@ -491,6 +512,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
     }
 
     if (!t.wave_on) return;
+    if (RGB == 3) {
+        if (t.valid) {
+            float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
+            ag[0] = depth_min;
+            ag[npix] = (float)face_min;
+        }
+        return;
+    }
     const float o3 = 1.f - alpha;
     if (RGB == 2) {
         if (t.valid) A.soft_colors[(size_t)t.n * npix + pn] = o3;
@@ -956,8 +985,11 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                        void *stream) {
     int R = 0;
     const bool alpha_only = (flags & UMR_RASTER_ALPHA_ONLY) != 0;
-    if (!faces || !soft_colors || !workspace) return UMR_ERR_ARG;
-    if (!alpha_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
+    const bool ids_only = (flags & UMR_RASTER_FACE_ID_ONLY) != 0;
+    if (alpha_only && ids_only) return UMR_ERR_ARG;
+    if (ids_only && (func_id_rgb != 0 || !aggrs_info)) return UMR_ERR_ARG;
+    if (!faces || (!soft_colors && !ids_only) || !workspace) return UMR_ERR_ARG;
+    if (!alpha_only && !ids_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
     if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
@@ -987,10 +1019,12 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     {
         // algorithmic bytes of one forward launch: 24 IS^2 + F (36 + 12 TS + 16) per mesh
         // (silhouette-only launches are accounted separately, id 2: 4 IS^2 + 36 F)
-        ProfScope ps(st, alpha_only ? 2 : 0,
+        ProfScope ps(st, (alpha_only || ids_only) ? 2 : 0,
                      alpha_only ? (double)N * (4.0 * image_size * image_size + 36.0 * F)
+                     : ids_only ? (double)N * (8.0 * image_size * image_size + 36.0 * F)
                                 : (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
-        if (alpha_only) k_raster_forward<2><<<blocks, BLK_THREADS, 0, st>>>(A);
+        if (ids_only) k_raster_forward<3><<<blocks, BLK_THREADS, 0, st>>>(A);
+        else if (alpha_only) k_raster_forward<2><<<blocks, BLK_THREADS, 0, st>>>(A);
         else if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
         else k_raster_forward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
     }

@@ -154,6 +154,27 @@ class SilhouetteFunction(Function):
         return (grad_faces.view(ctx.fv_shape),) + (None,) * 9
 
 
+def visibility(face_vertices, image_size, near=1., far=100., fill_back=True, eps=1e-3, sigma_val=1e-5, dist_eps=1e-10,
+               gamma_val=1e-4):
+    """Hard z-buffer planes only (UMR_RASTER_FACE_ID_ONLY): -> aggrs_info [N,2,IS,IS] = (nearest depth, face id | -1),
+    bit-identical to the third output of soft_rasterize(..., aggr_func_rgb='hard').  Forward only (no gradient flows
+    through these planes in the reference either)."""
+    L = _lib.lib()
+    fv = _f32c(face_vertices)
+    dev = fv.device
+    N, F = fv.shape[:2]
+    IS = int(image_size)
+    aggrs = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
+    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    rc = L.umr_raster_forward(ptr(fv), None, None, ptr(aggrs), None, None, None, None, None, N, F, 1, IS, float(near),
+                              float(far), float(eps), float(sigma_val), 2, float(math.log(1. / dist_eps - 1.)),
+                              float(gamma_val), 0, 2, 0, 1 if fill_back else 0, 4 | 1, None, ptr(ws), ws_bytes,
+                              _lib.stream_ptr(dev))
+    _lib.check(rc, "umr_raster_forward(visibility only)")
+    return aggrs
+
+
 def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',

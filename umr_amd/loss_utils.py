@@ -197,6 +197,7 @@ class MultiTextureLoss(nn.Module):
         self.renderer.ambient_light_only()
         self.renderer.need_p2f = False            # :313 discards p2f / aggr
         self.hard_renderer = SoftRenderer(image_size, "hard")
+        self.hard_renderer.ids_only = True        # only aggr_info[:, 1] is read (:328)
         if texture_loss_type in "perceptual":
             from .perceptual import PerceptualTextureLoss
             self._ptl = PerceptualTextureLoss()

@@ -36,6 +36,9 @@ class SoftRenderer(torch.nn.Module):
         # set True when only imgs[:, 3] is consumed (mask / GAN-view renders): the silhouette-only kernels run,
         # rgb channels of the returned image hold the background colour, p2f is zeros and aggr is None
         self.alpha_only = False
+        # hard renderer only: set True when only aggr (the face-id / depth planes) is consumed (TexCycle): the
+        # visibility-only kernel runs and the returned image is None
+        self.ids_only = False
 
     def ambient_light_only(self):
         """smr.py:68-71."""
@@ -67,6 +70,13 @@ class SoftRenderer(torch.nn.Module):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
         textures None | [N,F,TS,3]."""
         faces = faces.int().contiguous()                                  # smr.py:81
+        if self.ids_only and self.render_type == 'hard':
+            with torch.no_grad():
+                _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
+                size = self.img_size * (2 if self.anti_aliasing else 1)
+                aggr = UF.visibility(face_out, size, self.near, self.far, True, self.eps, self.sigma_val, self.dist_eps,
+                                     self.gamma_val)
+            return None, aggr.new_zeros(faces.shape[0], faces.shape[1], 2), aggr   # hard p2f is identically 0
         if self.alpha_only:
             _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
             size = self.img_size * (2 if self.anti_aliasing else 1)

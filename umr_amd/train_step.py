@@ -73,6 +73,7 @@ class RenderCompareS1(nn.Module):
         # ... and of the mask (:200) and unseen-view (:236) renders only the alpha channel is read
         self.renderer.alpha_only = True
         self.dis_renderer.alpha_only = True
+        self.hard_renderer.ids_only = True      # only the face-id plane is read (:224)
         self.laplacian_loss_fn = loss_utils.LaplacianLoss(template_verts, faces)   # :141
         self.flatten_loss_fn = loss_utils.FlattenLoss(faces)                       # :142
         self.texture_cycle_fn = loss_utils.TexCycle()
