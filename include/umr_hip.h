@@ -232,6 +232,20 @@ int umr_dt_barrier(const float *mask, float *out, int *sq_out, int *sq_in, int B
 int umr_upsample2x_bilinear_forward(const float *in, float *out, long planes, int H, int W, void *stream);
 int umr_upsample2x_bilinear_backward(const float *grad_out, float *grad_in, long planes, int H, int W, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Texture-atlas bake for textured OBJ dumps: create_texture_image
+ * (external/SoftRas/soft_renderer/cuda/create_texture_image_cuda.cpp:20-31 -> create_texture_image_cuda_kernel.cu:10-70)
+ * plus the host prologue/epilogue of functional/save_obj.py:9-35, 50-53 (atlas triangle layout, vt normalisation,
+ * clip/x255/uint8/vertical flip).  textures [F, res_in^2, 3]; the atlas is [height, width, 3] with
+ * (height, width) from umr_texture_atlas_shape (tile grid of save_obj.py:11-12, cells of res_out^2 pixels).
+ * Any of the three outputs may be NULL:  image = float atlas, NOT flipped (what the reference kernel returns);
+ * image_u8 = the bytes save_obj hands to imsave (clipped, x255, truncated, rows reversed);
+ * uv [F,3,2] = vt coordinates (corners / (width-1, height-1)).  eps = 1e-5 in the reference (save_obj.py:26).
+ * -------------------------------------------------------------------------------------------*/
+int umr_texture_atlas_shape(int F, int res_out, int *height, int *width);
+int umr_texture_atlas(const float *textures, float *image, unsigned char *image_u8, float *uv, int F, int res_in,
+                      int res_out, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

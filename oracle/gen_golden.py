@@ -128,11 +128,61 @@ def np_(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
+def gen_save_obj(lib):
+    """(vii) functional/save_obj.py run unmodified: the atlas bake goes through the reference's own kernel body
+    (ref_create_texture_image), `imsave` is captured instead of encoded, and LongTensor / int is given its
+    torch-1.1 meaning (integer division; save_obj.py:17 relies on it) for the duration of the call."""
+    import tempfile
+
+    def create_texture_image(vertices, textures, image, eps):
+        vertices, textures = vertices.contiguous(), textures.contiguous()
+        nf, r_in = textures.shape[0], int(textures.shape[1] ** 0.5)
+        tile_width = int((nf - 1) ** 0.5) + 1                 # create_texture_image_cuda_kernel.cu:82
+        lib.ref_create_texture_image(_p(vertices), _p(textures), _p(image), ctypes.c_long(image.numel()), nf, r_in,
+                                     image.shape[1] // tile_width, tile_width, ctypes.c_float(eps))
+        return image
+
+    sys.modules["soft_renderer.cuda.create_texture_image"].create_texture_image = create_texture_image
+    captured = {}
+    sys.modules["skimage.io"].imsave = lambda fn, arr: captured.update(png=np.array(arr))
+    spec = importlib.util.spec_from_file_location(
+        "ref_save_obj", os.path.join(REF, "external", "SoftRas", "soft_renderer", "functional", "save_obj.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    g = torch.Generator().manual_seed(23)
+    v, f = create_sphere(1)                                   # 42 verts / 80 faces
+    verts = torch.from_numpy(v).float() + 0.05 * torch.randn(v.shape, generator=g)
+    faces = torch.from_numpy(f).long()
+    tex = torch.rand(faces.shape[0], 36, 3, generator=g) * 1.2 - 0.1      # some values outside [0,1]: exercises clip
+    tex7 = torch.rand(7, 4, 3, generator=g)                   # ragged atlas: 7 faces in a 3x3 grid, R=2, 8 px cells
+    true_div = torch.Tensor.__truediv__
+    torch.Tensor.__truediv__ = lambda a, b: (torch.floor_divide(a, b) if (not a.is_floating_point()
+                                             and isinstance(b, int)) else true_div(a, b))
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            mod.save_obj(os.path.join(d, "bird.obj"), verts, faces, textures=tex, texture_res=16)
+            obj_tex, mtl = open(os.path.join(d, "bird.obj")).read(), open(os.path.join(d, "bird.mtl")).read()
+            mod.save_obj(os.path.join(d, "plain.obj"), verts, faces)
+            obj_plain = open(os.path.join(d, "plain.obj")).read()
+        img8, uv8 = mod.create_texture_image(tex7, texture_res=8)
+    finally:
+        torch.Tensor.__truediv__ = true_div
+    np.savez_compressed(os.path.join(OUT, "save_obj.npz"), verts=np_(verts), faces=np_(faces), textures=np_(tex),
+                        png=captured["png"], obj_textured=np.frombuffer(obj_tex.encode(), np.uint8),
+                        mtl=np.frombuffer(mtl.encode(), np.uint8),
+                        obj_plain=np.frombuffer(obj_plain.encode(), np.uint8),
+                        tex7=np_(tex7), atlas7=np.ascontiguousarray(img8), uv7=uv8)
+    print("save_obj golden:", captured["png"].shape, len(obj_tex), "bytes of OBJ")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     lib, sr, smr, loss_utils, geom_utils, chamfer_python, scops_utils, ps_spec = install_reference()
     sys.path.insert(0, ROOT)
     from oracle import softras  # only for its ctypes helper on the ref .so
+    if sys.argv[1:] == ["save_obj"]:
+        return gen_save_obj(lib)
 
     # (i) kernel-level: faces in screen space straight into the reference kernels -------------------------
     for tag, ts, rgb in (("softmax_ts36", 36, 1), ("softmax_ts1", 1, 1), ("hard_ts1", 1, 0), ("hard_ts4", 4, 0)):
@@ -274,6 +324,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "parts_and_cossim.npz"), part_maps=np_(pm), centers=np_(cen),
                         grad_part_maps=np_(pm.grad), f0_0=np_(f0[0]), f0_1=np_(f0[1]), f1_0=np_(f1[0]),
                         f1_1=np_(f1[1]), cos_dist=np_(val))
+    gen_save_obj(lib)
     print("done ->", OUT)
 
 

@@ -17,6 +17,9 @@ trap 'rm -rf "$SCRATCH"' EXIT
 # device code only: the anonymous namespace (helpers + 3 kernels); the host launchers
 # below it use <<<>>> and ATen and are replaced by the loops in host_exec_shim.cpp
 sed -n '22,659p' "$SRC" > "$SCRATCH/kernels_body.inc"
+# texture-atlas bake (functional/save_obj.py's device step): anonymous namespace of
+# create_texture_image_cuda_kernel.cu, lines 8-72 (the launcher below it is replaced by a loop)
+sed -n '8,72p' "$(dirname "$SRC")/create_texture_image_cuda_kernel.cu" > "$SCRATCH/atlas_body.inc"
 mkdir -p "$OUT"
 CXX=/opt/rocm/lib/llvm/bin/clang++
 "$CXX" -O2 -fPIC -shared -std=c++17 -ffp-contract=off -ftrivial-auto-var-init=zero \

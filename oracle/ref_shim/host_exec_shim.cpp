@@ -43,6 +43,7 @@ using std::pow;
 using std::sqrt;
 
 #include "kernels_body.inc"   // extracted at build time, lives only in the scratch dir
+#include "atlas_body.inc"     // create_texture_image_cuda_kernel.cu:8-72, same treatment
 
 extern "C" {
 
@@ -90,6 +91,22 @@ int ref_backward_soft_rasterize(const float *faces, const float *textures, const
                                                    far, eps, sigma_val, func_id_dist, dist_eps, gamma_val,
                                                    func_id_rgb, func_id_alpha, texture_sample_type,
                                                    double_side != 0);
+    }
+    return 0;
+}
+
+// launcher of cuda/create_texture_image_cuda_kernel.cu:74-107: one "thread" per atlas pixel, rounded up to
+// whole 1024-thread blocks exactly as the reference launches it (the kernel has no i < pixels guard of its own)
+int ref_create_texture_image(const float *faces_uv, const float *textures, float *image, long image_numel,
+                             int num_faces, int texture_res_in, int texture_res_out, int tile_width, float eps) {
+    const long threads = 1024, blocks = (image_numel / 3 - 1) / threads + 1;
+    blockDim = {1, 1, 1};
+    threadIdx = {0, 0, 0};
+    for (long i = 0; i < blocks * threads; ++i) {
+        blockIdx.x = (unsigned)i;
+        create_texture_image_cuda_kernel<float>(faces_uv, textures, image, (size_t)image_numel, (size_t)num_faces,
+                                                (size_t)texture_res_in, (size_t)texture_res_out,
+                                                (size_t)tile_width, eps);
     }
     return 0;
 }

@@ -160,3 +160,71 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=(0,
     return _SoftRasterizeCPU.apply(face_vertices, textures, image_size, list(background_color), float(near),
                                    float(far), bool(fill_back), float(eps), float(sigma_val), float(dist_eps),
                                    float(gamma_val), aggr_func_rgb, backend, n_threads)
+
+
+def texture_atlas(faces_uv, textures, image, res_out, tile_width, eps=1e-5, backend="port"):
+    """cuda/create_texture_image_cuda_kernel.cu: bake per-face texels [F,R*R,3] into `image` [H,W,3] in place
+    (numpy f32); faces_uv [F,3,2] in atlas pixel units."""
+    faces_uv = np.ascontiguousarray(faces_uv, np.float32)
+    textures = np.ascontiguousarray(textures, np.float32)
+    assert image.dtype == np.float32 and image.flags["C_CONTIGUOUS"]
+    nf, r_in = textures.shape[0], int(np.sqrt(textures.shape[1]))
+    lib = _lib(backend)
+    if backend == "ref":
+        lib.ref_create_texture_image(_ptr(faces_uv), _ptr(textures), _ptr(image), ctypes.c_long(image.size), nf, r_in,
+                                     int(res_out), int(tile_width), ctypes.c_float(eps))
+    else:
+        rc = lib.oracle_texture_atlas(_ptr(faces_uv), _ptr(textures), _ptr(image), image.shape[0], nf, r_in,
+                                      int(res_out), int(tile_width), ctypes.c_float(eps))
+        assert rc == 0
+    return image
+
+
+def atlas_layout(num_faces, texture_res):
+    """functional/save_obj.py:10-22 with torch-1.1 integer division for `row` (LongTensor / int floors there)."""
+    tile_width = int((num_faces - 1.) ** 0.5) + 1
+    tile_height = int((num_faces - 1.) / tile_width) + 1
+    fn = np.arange(num_faces)
+    col, row = (fn % tile_width).astype(np.float32), (fn // tile_width).astype(np.float32)
+    uv = np.zeros((num_faces, 3, 2), np.float32)
+    uv[:, 0, 0] = col * texture_res + texture_res / 2
+    uv[:, 0, 1] = row * texture_res + 1
+    uv[:, 1, 0] = col * texture_res + 1
+    uv[:, 1, 1] = (row + 1) * texture_res - 1 - 1
+    uv[:, 2, 0] = (col + 1) * texture_res - 1 - 1
+    uv[:, 2, 1] = (row + 1) * texture_res - 1 - 1
+    return tile_width, tile_height, uv
+
+
+def create_texture_image(textures, texture_res=16, backend="port"):
+    """functional/save_obj.py:9-35: returns (image [H,W,3] flipped vertically, uv [F,3,2] normalised)."""
+    textures = np.ascontiguousarray(textures, np.float32)
+    tw, th, uv = atlas_layout(textures.shape[0], texture_res)
+    image = np.ones((th * texture_res, tw * texture_res, 3), np.float32)
+    texture_atlas(uv, textures, image, texture_res, tw, 1e-5, backend)
+    uv = uv.copy()
+    uv[:, :, 0] /= (image.shape[1] - 1)
+    uv[:, :, 1] /= (image.shape[0] - 1)
+    return image[::-1], uv
+
+
+def obj_text(name, vertices, faces, uv=None):
+    """The exact bytes functional/save_obj.py:55-89 writes (surface textures when uv is given)."""
+    out = ['# %s\n' % name, '#\n', '\n']
+    if uv is not None:
+        out.append('mtllib %s\n\n' % (name[:-4] + '.mtl'))
+    for v in vertices:
+        out.append('v %.8f %.8f %.8f\n' % (v[0], v[1], v[2]))
+    out.append('\n')
+    if uv is not None:
+        for t in uv.reshape(-1, 2):
+            out.append('vt %.8f %.8f\n' % (t[0], t[1]))
+        out.append('\n')
+        out.append('usemtl material_1\n')
+        for i, f in enumerate(faces):
+            out.append('f %d/%d %d/%d %d/%d\n' % (f[0] + 1, 3 * i + 1, f[1] + 1, 3 * i + 2, f[2] + 1, 3 * i + 3))
+        out.append('\n')
+    else:
+        for f in faces:
+            out.append('f %d %d %d\n' % (f[0] + 1, f[1] + 1, f[2] + 1))
+    return ''.join(out)

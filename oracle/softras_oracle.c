@@ -13,6 +13,8 @@
  *     :180-195  surface texel lookup          -> texel_index()
  *     :286-476  per-pixel forward aggregation -> oracle_raster_forward()
  *     :480-656  per-pixel analytic backward   -> oracle_raster_backward()
+ *   external/SoftRas/soft_renderer/cuda/create_texture_image_cuda_kernel.cu
+ *     :10-70    texture-atlas bake (save_obj)  -> oracle_texture_atlas()
  *
  * Work complexity is the reference's: one work item per pixel, a serial loop
  * over ALL faces in index order, no binning.  The reference instantiates its
@@ -407,6 +409,39 @@ int oracle_raster_backward(const float *faces, const float *textures, const floa
         }
         free(pf);
         free(pt);
+    }
+    return 0;
+}
+
+/* ---- create_texture_image_cuda_kernel.cu:10-70 ------------------------------
+ * One work item per atlas pixel i (row-major [height, tile_width*res_out, 3]).  Atlas cell of face fn is at
+ * (x / res_out) + (y / res_out) * tile_width; pixels of cells beyond num_faces keep the caller's fill value.
+ * faces_uv[F,3,2] are the per-face atlas triangle corners in PIXEL units (functional/save_obj.py:13-22). */
+int oracle_texture_atlas(const float *faces_uv, const float *textures, float *image, int height,
+                         int num_faces, int res_in, int res_out, int tile_width, float eps) {
+    const int width = tile_width * res_out, R = res_in;
+    if (height <= 0 || num_faces <= 0 || res_in <= 0 || res_out <= 0 || tile_width <= 0) return -1;
+    for (int i = 0; i < height * width; ++i) {
+        const int x = i % width, y = i / width;
+        const int fn = x / res_out + (y / res_out) * tile_width; /* :24-26 */
+        if (fn >= num_faces) continue;
+        const float *tex = textures + (size_t)fn * R * R * 3;
+        const float *p0 = faces_uv + (size_t)fn * 6, *p1 = p0 + 2, *p2 = p0 + 4;
+        float inv[9] = {p1[1] - p2[1], p2[0] - p1[0], p1[0] * p2[1] - p2[0] * p1[1],
+                        p2[1] - p0[1], p0[0] - p2[0], p2[0] * p0[1] - p0[0] * p2[1],
+                        p0[1] - p1[1], p1[0] - p0[0], p0[0] * p1[1] - p1[0] * p0[1]}; /* :40-43 */
+        const float den = p2[0] * (p0[1] - p1[1]) + p0[0] * (p1[1] - p2[1]) + p1[0] * (p2[1] - p0[1]);
+        for (int k = 0; k < 9; ++k) inv[k] /= (den + eps); /* :48 */
+        float w[3], w_sum = 0;
+        for (int k = 0; k < 3; ++k) {
+            w[k] = inv[3 * k + 0] * x + inv[3 * k + 1] * y + inv[3 * k + 2]; /* :54 int -> float */
+            w[k] = (float)fmax(fmin((double)w[k], 1.), 0.);                   /* dbl: :55 */
+            w_sum += w[k];
+        }
+        for (int k = 0; k < 3; ++k) w[k] /= (w_sum + eps);
+        const int w_x = (int)(w[0] * R), w_y = (int)(w[1] * R); /* :61-62 */
+        const int t = ((w[0] + w[1]) * R - w_x - w_y <= 1) ? (w_y * R + w_x) : ((R - 1 - w_y) * R + (R - 1 - w_x));
+        for (int k = 0; k < 3; ++k) image[(size_t)i * 3 + k] = tex[t * 3 + k];
     }
     return 0;
 }

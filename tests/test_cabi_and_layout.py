@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -124,6 +126,28 @@ def test_symmetric_face_ordering_matches_reference_constants():
     assert (ni4, ns4, nif4, nsf4) == (64, 1249, 64, 2528)
 
 
+def _decode_png(data):
+    """Test-side decoder for the 8-bit RGB, filter-0 PNGs io_utils.write_png emits."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, shape = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 2)
+            shape = (h, w)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(shape[0], shape[1] * 3 + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(shape[0], shape[1], 3)
+
+
 def test_checkpoint_and_obj_formats(tmp_path):
     """Reference file formats: '<label>_net_<epoch>.pth' with un-prefixed keys; tolerant load; OBJ round trip."""
     from umr_amd import io_utils
@@ -139,6 +163,14 @@ def test_checkpoint_and_obj_formats(tmp_path):
     assert "uv_sampler" not in loaded and "shape_predictor.weight" in loaded
     assert torch.equal(a.shape_predictor.weight, b.shape_predictor.weight)
     io_utils.save_obj(str(tmp_path / "m.obj"), a.get_mean_shape(), a.faces)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "save_obj.npz"))   # written by the reference
+    io_utils.save_obj(str(tmp_path / "plain.obj"), torch.from_numpy(g["verts"]), torch.from_numpy(g["faces"]))
+    assert open(tmp_path / "plain.obj", "rb").read() == g["obj_plain"].tobytes()
+    with pytest.raises(RuntimeError):                                                # atlas bake is GPU-only
+        io_utils.save_obj(str(tmp_path / "t.obj"), torch.from_numpy(g["verts"]), torch.from_numpy(g["faces"]),
+                          textures=torch.from_numpy(g["textures"]))
+    io_utils.write_png(str(tmp_path / "a.png"), g["png"])
+    assert _decode_png(open(tmp_path / "a.png", "rb").read()).tobytes() == g["png"].tobytes()
     lines = open(tmp_path / "m.obj").read().split("\n")
     assert sum(l.startswith("v ") for l in lines) == 42 and sum(l.startswith("f ") for l in lines) == 80
     assert min(int(t) for l in lines if l.startswith("f ") for t in l.split()[1:]) == 1

@@ -583,3 +583,35 @@ def test_visibility_only_kernel_matches_hard_render():
     img, p2f_b, aggr_b = fast(verts.to(DEV), faces.to(DEV), cams.to(DEV))
     assert img is None and torch.equal(aggr_a, aggr_b) and torch.equal(p2f_a, p2f_b)
     assert float(aggr_b[:, 1].max()) > 0 and float(aggr_b[:, 1].min()) == -1.0
+
+
+def test_texture_atlas_and_textured_obj_vs_reference_golden(oracle_built, tmp_path):
+    """umr_texture_atlas (csrc/atlas.hip) against the reference's own save_obj.py + atlas kernel: bit-exact atlas,
+    vt coordinates and PNG payload, byte-identical OBJ / MTL text; then full size (1280 faces, 6x6 texels) vs oracle."""
+    from oracle import softras as S
+    from umr_amd import io_utils
+    from test_cabi_and_layout import _decode_png
+    g = load_golden("save_obj.npz")
+    verts, faces = torch.from_numpy(g["verts"]), torch.from_numpy(g["faces"])
+    tex = torch.from_numpy(g["textures"]).to(DEV)
+    io_utils.save_obj(str(tmp_path / "bird.obj"), verts.to(DEV), faces.to(DEV), textures=tex, texture_res=16)
+    assert open(tmp_path / "bird.obj", "rb").read() == g["obj_textured"].tobytes()
+    assert open(tmp_path / "bird.mtl", "rb").read() == g["mtl"].tobytes()
+    assert np.array_equal(_decode_png(open(tmp_path / "bird.png", "rb").read()), g["png"])
+    img7, uv7 = io_utils.create_texture_image(torch.from_numpy(g["tex7"]).to(DEV), texture_res=8)
+    assert np.array_equal(img7, g["atlas7"]) and np.array_equal(uv7, g["uv7"])        # bit-exact (gather + layout)
+    # vertex-colour variant (save_obj.py:62-66) needs no atlas
+    io_utils.save_obj(str(tmp_path / "vc.obj"), verts, faces, textures=torch.rand(verts.shape[0], 3),
+                      texture_type="vertex")
+    assert open(tmp_path / "vc.obj").read().count("\nv ") == verts.shape[0]
+    # full size, several output resolutions incl. non-multiple-of-R ones
+    gen = torch.Generator().manual_seed(5)
+    for nf, r, res in ((1280, 6, 16), (5120, 6, 7), (333, 1, 2), (1, 4, 32)):
+        t = torch.rand(nf, r * r, 3, generator=gen)
+        o = io_utils.texture_atlas(t.to(DEV), res)
+        ref_img, ref_uv = S.create_texture_image(t.numpy(), res)
+        assert np.array_equal(t2n(o["image"])[::-1], ref_img), (nf, r, res)
+        assert np.array_equal(t2n(o["uv"]), ref_uv)
+        assert np.array_equal(t2n(o["u8"]), (ref_img.clip(0, 1) * 255).astype("uint8"))
+    with pytest.raises(RuntimeError):
+        io_utils.texture_atlas(torch.rand(4, 5, 3, device=DEV))                        # 5 texels: not a square

@@ -184,3 +184,18 @@ def test_parts_and_cossim_restatement():
     f0 = [torch.from_numpy(g["f0_0"]), torch.from_numpy(g["f0_1"])]
     f1 = [torch.from_numpy(g["f1_0"]), torch.from_numpy(g["f1_1"])]
     np.testing.assert_allclose(torch_ref.cos_sim_distance(f0, f1).numpy(), g["cos_dist"], atol=1e-6)
+
+
+def test_texture_atlas_and_obj_text_vs_reference_golden(oracle_built):
+    """save_obj golden produced by the reference's own functional/save_obj.py + its atlas kernel body."""
+    from oracle import softras as S
+    g = load_golden("save_obj.npz")
+    img, uv = S.create_texture_image(g["textures"], 16)
+    assert np.array_equal((img.clip(0, 1) * 255).astype("uint8"), g["png"])
+    a7, uv7 = S.create_texture_image(g["tex7"], 8)              # ragged grid: 7 faces in 3x3 cells, 2 cells stay 1.0
+    assert np.array_equal(a7, g["atlas7"]) and np.array_equal(uv7, g["uv7"])
+    assert S.obj_text("bird.obj", g["verts"], g["faces"], uv) == g["obj_textured"].tobytes().decode()
+    assert S.obj_text("plain.obj", g["verts"], g["faces"]) == g["obj_plain"].tobytes().decode()
+    if S.have_backend("ref"):
+        b, _ = S.create_texture_image(g["textures"], 16, backend="ref")
+        assert np.array_equal(img, b)

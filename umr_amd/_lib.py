@@ -44,6 +44,8 @@ SIGNATURES = {
     "umr_upsample2x_bilinear_backward": ([_P, _P, _L, _I, _I, _P], _I),
     "umr_dt_barrier_workspace_bytes": ([_I, _I, _I], _Z),
     "umr_dt_barrier": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P], _I),
+    "umr_texture_atlas_shape": ([_I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
+    "umr_texture_atlas": ([_P, _P, _P, _P, _I, _I, _I, _F, _P], _I),
 }
 
 _lib = None
