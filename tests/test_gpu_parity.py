@@ -594,7 +594,9 @@ def test_texture_atlas_and_textured_obj_vs_reference_golden(oracle_built, tmp_pa
     g = load_golden("save_obj.npz")
     verts, faces = torch.from_numpy(g["verts"]), torch.from_numpy(g["faces"])
     tex = torch.from_numpy(g["textures"]).to(DEV)
-    io_utils.save_obj(str(tmp_path / "bird.obj"), verts.to(DEV), faces.to(DEV), textures=tex, texture_res=16)
+    from umr_amd.mesh import Mesh                                   # the sr.Mesh.save_obj call of train_s1.py:370
+    Mesh(verts.to(DEV), faces.to(DEV), tex, texture_type="surface").save_obj(str(tmp_path / "bird.obj"),
+                                                                             save_texture=True)
     assert open(tmp_path / "bird.obj", "rb").read() == g["obj_textured"].tobytes()
     assert open(tmp_path / "bird.mtl", "rb").read() == g["mtl"].tobytes()
     assert np.array_equal(_decode_png(open(tmp_path / "bird.png", "rb").read()), g["png"])

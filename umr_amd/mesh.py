@@ -101,3 +101,45 @@ def make_faces_symmetric(verts, faces, num_indept_verts, num_sym_verts, axis=1):
         done[fid] = done[sym_fid] = True
     assert len(indept) + len(right) + len(left) == len(faces)
     return np.vstack([np.array(indept).reshape(-1, 3), np.array(right), np.array(left)]).astype(np.int64), len(indept), len(right)
+
+
+class Mesh(object):
+    """The slice of `sr.Mesh` (external/SoftRas/soft_renderer/mesh.py:11-175) the reference's training / eval
+    scripts touch when dumping visuals: a batched (vertices, faces, textures) holder with `save_obj`
+    (mesh.py:167-175; callers experiments/train_s1.py:370, train_s2.py:454, avg_uv.py:252,303,
+    nnutils/test_utils.py:139).  Rendering does not go through this class here -- `umr_amd.smr.SoftRenderer` takes
+    the tensors directly."""
+
+    def __init__(self, vertices, faces, textures=None, texture_res=1, texture_type='surface'):
+        import torch
+        as_t = lambda a, dt: torch.from_numpy(a).to(dt) if isinstance(a, np.ndarray) else a
+        self.vertices = as_t(vertices, torch.float32)
+        self.faces = as_t(faces, torch.int32)
+        if self.vertices.dim() == 2:
+            self.vertices = self.vertices[None]
+        if self.faces.dim() == 2:
+            self.faces = self.faces[None]
+        self.batch_size, self.num_vertices = self.vertices.shape[:2]
+        self.num_faces = self.faces.shape[1]
+        self.texture_type = texture_type
+        if textures is None:                                              # mesh.py:44-53: all-ones default
+            shape = (self.batch_size, self.num_faces, texture_res ** 2, 3) if texture_type == 'surface' \
+                else (self.batch_size, self.num_vertices, 3)
+            textures = torch.ones(shape, dtype=torch.float32, device=self.vertices.device)
+            self.texture_res = texture_res if texture_type == 'surface' else 1
+        else:
+            textures = as_t(textures, torch.float32)
+            if textures.dim() == 3 and texture_type == 'surface':
+                textures = textures[None]
+            if textures.dim() == 2 and texture_type == 'vertex':
+                textures = textures[None]
+            self.texture_res = int(round(textures.shape[2] ** 0.5)) if texture_type == 'surface' else 1
+        self.textures = textures
+
+    def save_obj(self, filename_obj, save_texture=False, texture_res_out=16):
+        from .io_utils import save_obj
+        if self.batch_size != 1:
+            raise ValueError('Could not save when batch size >= 1')      # message as mesh.py:169
+        save_obj(filename_obj, self.vertices[0], self.faces[0],
+                 textures=self.textures[0] if save_texture else None,
+                 texture_res=texture_res_out, texture_type=self.texture_type)
