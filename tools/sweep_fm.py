@@ -1,0 +1,32 @@
+"""GPU box: raster kernel timings (library-owned HIP events around the main kernels, umr_profile_*) at the bench's
+launch sizes for a compile-time variant of the library (used by tools/sweep_fm.sh).  One JSON line tagged argv[1]."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.microbench import bench, bench_alpha  # noqa: E402
+from umr_amd import _lib  # noqa: E402
+
+
+def timed(fn, *a, **k):
+    fn(*a, **dict(k, iters=2))                  # module load, allocator warm-up
+    _lib.profile_enable(True)
+    _lib.profile_collect(0); _lib.profile_collect(1)   # reset
+    fn(*a, **k)
+    (fms, fn_, _), (bms, bn, _) = _lib.profile_collect(0), _lib.profile_collect(1)
+    _lib.profile_enable(False)
+    return round(fms * 1e3 / max(fn_, 1), 1), round(bms * 1e3 / max(bn, 1), 1)   # us per launch: fwd, bwd
+
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "default"
+out = {"tag": tag}
+out["n16_ts36_texonly_pooled"] = timed(bench, 16, 3, 512, 36, pool=True, need_p2f=False, need_gf=False, iters=20)
+out["n16_ts36_p2f"] = timed(bench, 16, 3, 512, 36, iters=20)
+out["n16_ts1"] = timed(bench, 16, 3, 512, 1, iters=20)
+out["n128_ts36_texonly_pooled"] = timed(bench, 128, 3, 512, 36, pool=True, need_p2f=False, need_gf=False)
+out["n128_ts36"] = timed(bench, 128, 3, 512, 36)
+out["n128_ts1"] = timed(bench, 128, 3, 512, 1)
+out["alpha_n16"] = timed(bench_alpha, 16, 3, 512)
+out["alpha_n128"] = timed(bench_alpha, 128, 3, 512)
+print(json.dumps(out), flush=True)

@@ -85,6 +85,14 @@ def ptr(t):
 
 
 def stream_ptr(device=None):
+    """Current HIP stream of `device`.  Kernels are launched in the CURRENT device context (as the reference's
+    were: no device guard), so a tensor on another GPU is rejected here instead of
+    faulting inside the launch -- one process per GPU calls torch.cuda.set_device(local_rank) once."""
+    if device is not None:
+        idx = torch.device(device).index
+        if idx is not None and idx != torch.cuda.current_device():
+            raise RuntimeError("umr_amd: tensors live on cuda:%d but the current device is cuda:%d; call "
+                               "torch.cuda.set_device first" % (idx, torch.cuda.current_device()))
     return torch.cuda.current_stream(device).cuda_stream
 
 

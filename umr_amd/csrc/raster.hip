@@ -687,13 +687,25 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // 64 lanes ONCE and stores.  No global atomics, no per-(tile, face) reduction, deterministic results; the
 // face record lives in SGPRs for the whole walk.  Per-pixel state is re-read once per overlapping face
 // (~6x, L1/L2 hits: consecutive faces of a subdivided mesh are spatial neighbours and share a workgroup).
-#define FM_WAVES 4
+#ifndef FM_WAVES
+#define FM_WAVES 1   // faces (wavefronts) per workgroup of the face-major backward: 1 = finest scheduling granularity,
+                     // no straggler waves holding a CU slot (measured 1 < 2 < 4 < 8 in time)
+#endif
 #ifndef FM_RELOAD_PER_TILE
 #define FM_RELOAD_PER_TILE 1
 #endif
+#ifndef FM_TW
+#define FM_TW 4   // sub-tile width / height in pixels (8x8 = one tile per wave visit, 4x4 = four)
+#define FM_TH 4
+#endif
+#define FM_NQ (64 / (FM_TW * FM_TH))
+#ifndef FM_TEXCOPY
+#define FM_TEXCOPY 4   // private copies of a wave's LDS texel accumulators (power of two): neighbouring pixels share a
+#endif                 // texel, and same-address ds_add_f32 from one wave serialise -- spread them over copies
+#define FM_TEX_STRIDE(TS) (((TS) * 3) | 1)   // odd stride: copy c of a texel lands in another bank
 template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][TS*3]
+    extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
     const int F = A.F, IS = A.IS, TS = A.TS;
     // XCD-aware: hardware XCD = blockIdx % 8.  Each XCD owns a fixed contiguous EIGHTH of every mesh's faces
@@ -711,9 +723,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
     const bool live = fidx < F;
     const int n = nb, f = live ? fidx : 0;
     const size_t npix = (size_t)IS * IS;
-    float *my_tex = s_tex + (size_t)wave * TS * 3;
+    float *wave_tex = s_tex + (size_t)wave * FM_TEXCOPY * FM_TEX_STRIDE(TS);
+    // this lane's copy: horizontally and vertically adjacent pixels of a 4x4 / 8x8 tile get different copies
+    float *my_tex = wave_tex + ((lane ^ (lane >> 2) ^ (lane >> 4)) & (FM_TEXCOPY - 1)) * FM_TEX_STRIDE(TS);
     if (NEED_GT && TS > 1)
-        for (int j = lane; j < TS * 3; j += 64) my_tex[j] = 0.f;
+        for (int j = lane; j < FM_TEXCOPY * FM_TEX_STRIDE(TS); j += 64) wave_tex[j] = 0.f;
     float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // TS == 1 texel gradient
     if (live) {
@@ -731,20 +745,27 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
         x0 = max(x0, 0); x1 = min(x1, IS - 1); yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
         const int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;  // row = IS-1-yi
         if (x0 <= x1 && r0 <= r1) {
-            const int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = r0 >> 3, ty1 = r1 >> 3;
+            // Sub-tiles of FM_TW x FM_TH pixels, FM_NQ = 64 / (FM_TW * FM_TH) of them per wave visit: the face is
+            // wave-uniform here, so the 64 lanes need not form ONE tile -- each group of FM_TW*FM_TH lanes takes its own
+            // needed sub-tile of this face.  4x4 sub-tiles fill 74 % of their lanes with contributing pixels against
+            // 54 % for one 8x8 tile (CPU simulation of the culling, 1280-face sphere at IS = 512).
+            const int tx0 = x0 / FM_TW, tx1 = x1 / FM_TW, ty0 = r0 / FM_TH, ty1 = r1 / FM_TH;
             const bool pow2 = (IS & (IS - 1)) == 0;
             const float inv_is = 1.f / (float)IS;
             const int ntx = tx1 - tx0 + 1, ntiles = ntx * (ty1 - ty0 + 1);
             const float4 i0 = make_float4(fc.g<R_INV + 0>(), fc.g<R_INV + 1>(), fc.g<R_INV + 2>(), fc.g<R_INV + 3>());
             const float4 i1 = make_float4(fc.g<R_INV + 4>(), fc.g<R_INV + 5>(), fc.g<R_INV + 6>(), fc.g<R_INV + 7>());
             const float4 i2 = make_float4(fc.g<R_INV + 8>(), fc.g<R_K0>(), fc.g<R_K1>(), fc.g<R_K2>());
+            const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
             for (int tb = 0; tb < ntiles; tb += 64) {
-                // one lane per tile: drop tiles no pixel of which can survive (conservative), then walk the rest
+                // one lane per sub-tile: drop those no pixel of which can survive (conservative), then walk the rest
                 const int ti = tb + lane;
                 bool want = false;
+                int tpk = 0;   // packed (tx, ty) of this lane's candidate
                 if (ti < ntiles) {
                     const int ttx = tx0 + ti % ntx, tty = ty0 + ti / ntx;
-                    const int px0 = ttx * 8, px1 = min(px0 + 7, IS - 1), pr0 = tty * 8, pr1 = min(pr0 + 7, IS - 1);
+                    tpk = ttx | (tty << 16);
+                    const int px0 = ttx * FM_TW, px1 = min(px0 + FM_TW - 1, IS - 1), pr0 = tty * FM_TH, pr1 = min(pr0 + FM_TH - 1, IS - 1);
                     const float cxl = ndc_coord_fast(px0, IS, inv_is, pow2), cxh = ndc_coord_fast(px1, IS, inv_is, pow2);
                     const float cyh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), cyl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
                     want = tile_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), 0.5f * (cxh - cxl),
@@ -752,20 +773,28 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                 }
                 unsigned long long tm = __ballot(want);
                 while (tm) {
-                    const int tbit = __builtin_ctzll(tm);
-                    tm &= tm - 1;
-                    const int tsel = tb + tbit;
-                    const int tx = tx0 + tsel % ntx, ty = ty0 + tsel / ntx;
+                    // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
+                    int mine = -1;
+#pragma unroll
+                    for (int qq = 0; qq < FM_NQ; ++qq) {
+                        if (tm) {
+                            const int tbit = __builtin_ctzll(tm);
+                            tm &= tm - 1;
+                            const int e = __builtin_amdgcn_readlane(tpk, tbit);
+                            if (sub == qq) mine = e;
+                        }
+                    }
 #if FM_RELOAD_PER_TILE
-                    {   // re-fetch the record from the scalar cache every tile: keeps the 32 constants loop-VARIANT so the
+                    {   // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
                         // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop (which cost 2 waves/SIMD)
                         const float *rp = A.rec + ((size_t)n * F + f) * REC;
                         asm volatile("" : "+s"(rp));
                         load_face(fc, rp);
                     }
 #endif
-                    const int row = ty * 8 + (lane >> 3);
-                    const int xi = tx * 8 + (lane & 7);
+                    if (mine < 0) continue;
+                    const int row = (mine >> 16) * FM_TH + sl / FM_TW;
+                    const int xi = (mine & 0xffff) * FM_TW + sl % FM_TW;
                     if (xi >= IS || row >= IS) continue;
                     const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
                     const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
@@ -887,7 +916,12 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
             __syncthreads();  // every wave arrives exactly once; orders the LDS atomics before the read-out
             if (live) {
                 float *dst = A.grad_textures + ((size_t)n * F + f) * TS * 3;
-                for (int j = lane; j < TS * 3; j += 64) dst[j] += my_tex[j];
+                for (int j = lane; j < TS * 3; j += 64) {
+                    float acc = wave_tex[j];
+#pragma unroll
+                    for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
+                    dst[j] += acc;
+                }
             }
         }
     }
@@ -896,7 +930,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
 template <int RGB>
 void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
     const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
-    const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * A.TS * 3 * sizeof(float) : 0;
+    const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
     if (RGB == 2) k_raster_backward_fm<2, true, false><<<blocks, FM_WAVES * 64, 0, st>>>(A);
     else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
     else if (A.need_gf) k_raster_backward_fm<RGB, true, false><<<blocks, FM_WAVES * 64, lds, st>>>(A);
@@ -1078,7 +1112,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         ProfScope ps(st, alpha_only ? 3 : 1,
                      alpha_only ? (double)N * ((grad_is_pooled ? 5.0 : 8.0) * image_size * image_size + 72.0 * F)
                                 : (double)N * (px * image_size * image_size + (double)F * (180.0 + 24.0 * TS)));
-        const bool lds_ok = (size_t)FM_WAVES * TS * 3 * sizeof(float) <= 48 * 1024;
+        const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
         if (alpha_only) launch_backward_fm<2>(A, st);
         else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
             if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
