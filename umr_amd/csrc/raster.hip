@@ -699,10 +699,65 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 #define FM_TH 4
 #endif
 #define FM_NQ (64 / (FM_TW * FM_TH))
+#ifndef FM_TEXMERGE
+#define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2, 3 = + y^1
+#endif
 #ifndef FM_TEXCOPY
 #define FM_TEXCOPY 4   // private copies of a wave's LDS texel accumulators (power of two): neighbouring pixels share a
 #endif                 // texel, and same-address ds_add_f32 from one wave serialise -- spread them over copies
 #define FM_TEX_STRIDE(TS) (((TS) * 3) | 1)   // odd stride: copy c of a texel lands in another bank
+// Texel-gradient accumulation of the face-major backward (TS > 1): 3 ds_add_f32 per visit into the wave's LDS
+// accumulators.  Neighbouring pixels mostly fall into the same texel, and the LDS atomic pipe -- shared by every wave
+// of the CU -- saturates (SQ_WAIT_INST_LDS 21 % of wave time, the kernel 35 % slower than without the atomics).
+// So horizontally adjacent lanes holding the same texel are first summed with DPP quad permutes (the partner's value
+// is read only when the partner is active at this point: bound_ctrl off -> `old`), and only the surviving lane of
+// each run issues the atomics.  Deterministic; only the summation order differs from lane-by-lane atomics.
+__device__ __forceinline__ float dpp_f(float old, float v, const int ctrl_sel) {
+    // ctrl_sel: 0 -> quad_perm [1,0,3,2] (x^1), 1 -> quad_perm [2,3,0,1] (x^2), 2 -> row_shl:4, 3 -> row_shr:4
+    const int o = __float_as_int(old), i = __float_as_int(v);
+    int r;
+    if (ctrl_sel == 0) r = __builtin_amdgcn_update_dpp(o, i, 0xB1, 0xf, 0xf, false);
+    else if (ctrl_sel == 1) r = __builtin_amdgcn_update_dpp(o, i, 0x4E, 0xf, 0xf, false);
+    else if (ctrl_sel == 2) r = __builtin_amdgcn_update_dpp(o, i, 0x104, 0xf, 0xf, false);
+    else r = __builtin_amdgcn_update_dpp(o, i, 0x114, 0xf, 0xf, false);
+    return __int_as_float(r);
+}
+__device__ __forceinline__ int dpp_i(int old, int v, const int ctrl_sel) {
+    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(old, v, 0xB1, 0xf, 0xf, false);
+    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(old, v, 0x4E, 0xf, 0xf, false);
+    if (ctrl_sel == 2) return __builtin_amdgcn_update_dpp(old, v, 0x104, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a, float b, float c, int lane) {
+#if FM_TEXMERGE >= 1
+#pragma unroll
+    for (int step = 0; step < (FM_TEXMERGE >= 2 ? 2 : 1); ++step) {
+        const int t = dpp_i(-1, tix, step);                     // partner's texel, -1 if it is not here
+        const float oa = dpp_f(0.f, a, step), ob = dpp_f(0.f, b, step), oc = dpp_f(0.f, c, step);
+        const bool same = t == tix, keep = (lane & (1 << step)) == 0;
+        a += (same & keep) ? oa : 0.f;
+        b += (same & keep) ? ob : 0.f;
+        c += (same & keep) ? oc : 0.f;
+        tix = (same & !keep) ? -1 : tix;                        // merged into the partner: nothing left to add
+    }
+#endif
+#if FM_TEXMERGE >= 3 && FM_TW == 4
+    {   // vertical neighbour of a 4x4 sub-tile: lane + 4 within the 16-lane DPP row
+        const int td = dpp_i(-1, tix, 2), tu = dpp_i(-2, tix, 3);   // texel of the lane below (i+4) / above (i-4)
+        const float oa = dpp_f(0.f, a, 2), ob = dpp_f(0.f, b, 2), oc = dpp_f(0.f, c, 2);
+        const bool keep = (lane & 4) == 0, same = keep ? td == tix : tu == tix;
+        a += (same & keep) ? oa : 0.f;
+        b += (same & keep) ? ob : 0.f;
+        c += (same & keep) ? oc : 0.f;
+        tix = (same & !keep) ? -1 : tix;
+    }
+#endif
+    if (tix >= 0) {
+        atomicAdd(&my_tex[tix * 3], a);
+        atomicAdd(&my_tex[tix * 3 + 1], b);
+        atomicAdd(&my_tex[tix * 3 + 2], c);
+    }
+}
 template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
@@ -864,7 +919,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                         if (NEED_GT && (float)f == smax) {  // :596
                             const int tix = texel_index(q0, q1, A.R);
                             if (TS == 1) { gt0 += g0; gt1 += g1; gt2 += g2; }
-                            else { atomicAdd(&my_tex[tix * 3], g0); atomicAdd(&my_tex[tix * 3 + 1], g1); atomicAdd(&my_tex[tix * 3 + 2], g2); }
+                            else texel_accumulate(my_tex, tix, g0, g1, g2, lane);
                         }
                     } else if (fc.front() || A.double_side) {
                         const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
@@ -872,7 +927,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                         const int tix = texel_index(q0, q1, A.R);
                         if (NEED_GT) {
                             if (TS == 1) { gt0 += ps * g0; gt1 += ps * g1; gt2 += ps * g2; }
-                            else { atomicAdd(&my_tex[tix * 3], ps * g0); atomicAdd(&my_tex[tix * 3 + 1], ps * g1); atomicAdd(&my_tex[tix * 3 + 2], ps * g2); }
+                            else texel_accumulate(my_tex, tix, ps * g0, ps * g1, ps * g2, lane);
                         }
                         if (NEED_GF) {
                             const float *tx = tex_f + (size_t)tix * 3;
