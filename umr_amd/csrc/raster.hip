@@ -5,7 +5,7 @@
 //   :286-476 (forward), :480-656 (backward)
 // but the execution plan is CDNA4-native rather than "one thread per pixel looping over all faces":
 //
-//   * a 512-thread workgroup owns a 32x16 pixel block; each of its 8 wavefronts owns one 8x8 tile
+//   * a 256-thread workgroup owns a 16x16 pixel block; each of its 4 wavefronts owns one 8x8 tile
 //     (lane = pixel), so a face's per-wave data is wave-uniform and is fetched with scalar loads;
 //   * faces are binned per block IN the kernel: the block scans the compact [N,F] bbox array
 //     (coalesced float4 loads), ballots, and appends surviving face ids to an LDS list in
@@ -27,9 +27,12 @@
 
 #define REC 64         // floats per preprocessed face record
 #define LIST_CAP 2048  // LDS face list capacity (faces are processed in super-chunks of this many)
-#define BLK_W 32
-#define BLK_H 16
-#define BLK_THREADS 512
+#ifndef BLK_W
+#define BLK_W 16   // measured on MI355X (N=128, F=1280, IS=512, soft-max forward): 16x16 1.55 ms, 32x8 / 16x8 1.64,
+#define BLK_H 16   // 32x16 1.81, 32x32 2.08, 8x8 2.28 -- 4 waves share one binning pass and still schedule finely
+#endif
+#define BLK_WX (BLK_W / 8)                          // 8x8 wave tiles across / in the workgroup
+#define BLK_THREADS (BLK_WX * (BLK_H / 8) * 64)
 
 namespace {
 
@@ -332,7 +335,7 @@ __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     t.lane = threadIdx.x & 63;
     t.wave = threadIdx.x >> 6;
     const int IS = A.IS;
-    const int px0 = bx * BLK_W + (t.wave & 3) * 8, py0 = by * BLK_H + (t.wave >> 2) * 8;
+    const int px0 = bx * BLK_W + (t.wave % BLK_WX) * 8, py0 = by * BLK_H + (t.wave / BLK_WX) * 8;
     t.xi = px0 + (t.lane & 7);
     t.row = py0 + (t.lane >> 3);
     t.valid = t.xi < IS && t.row < IS;
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                 }
                 if (RGB == 1 && A.with_p2f) {  // :427-430, reduced over the 8x8 tile first
                     if (__any(wgt != 0.f)) {
-                        const float sx = wave_sum(wgt * gx), sy = wave_sum(wgt * gy), sw = wave_sum(wgt);
+                        const float sx = wave_sum_full(wgt * gx), sy = wave_sum_full(wgt * gy), sw = wave_sum_full(wgt);
                         if (t.lane < 4) {
                             const size_t o = ((size_t)t.n * F + f) * 2;
                             float *dst = t.lane < 2 ? A.p2f_info + o + t.lane : A.p2f_sum + o + (t.lane - 2);
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                     float mine = 0.f;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
-                        const float s = wave_sum(gv[k]);
+                        const float s = wave_sum_full(gv[k]);
                         if (t.lane == k) mine = s;
                     }
                     if (t.lane < 9) atomicAdd(A.grad_faces + ((size_t)t.n * F + f) * 9 + t.lane, mine);
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                 if (A.need_gt) {
                     float *gtf = A.grad_textures + ((size_t)t.n * F + f) * TS * 3;
                     if (TS == 1) {
-                        const float s0 = wave_sum(gt0), s1 = wave_sum(gt1), s2 = wave_sum(gt2);
+                        const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
                         if (t.lane < 3) atomicAdd(gtf + t.lane, t.lane == 0 ? s0 : (t.lane == 1 ? s1 : s2));
                     } else if (gt0 != 0.f || gt1 != 0.f || gt2 != 0.f) {
                         atomicAdd(gtf + tix * 3 + 0, gt0);
@@ -958,14 +961,14 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
         float mine = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const float sv = wave_sum(gv[k]);
+            const float sv = wave_sum_full(gv[k]);
             if (lane == k) mine = sv;
         }
         if (live && lane < 9) A.grad_faces[((size_t)n * F + f) * 9 + lane] += mine;
     }
     if (NEED_GT) {
         if (TS == 1) {
-            const float s0 = wave_sum(gt0), s1 = wave_sum(gt1), s2 = wave_sum(gt2);
+            const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
             if (live && lane < 3) A.grad_textures[((size_t)n * F + f) * 3 + lane] += lane == 0 ? s0 : (lane == 1 ? s1 : s2);
         } else {
             __syncthreads();  // every wave arrives exactly once; orders the LDS atomics before the read-out

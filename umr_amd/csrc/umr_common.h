@@ -15,6 +15,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Same total with DPP adds (no LDS crossbar traffic, 7 VALU instead of ~30 VALU + 6 ds_bpermute): butterfly inside each
+// 16-lane row, row_bcast:15 / row_bcast:31 across rows, total read from lane 63 into an SGPR.  REQUIRES all 64 lanes
+// active at the call (v_readlane ignores exec); summation order differs from wave_sum (both are deterministic).
+__device__ __forceinline__ float wave_sum_full(float v) {
+#define UMR_DPP_ADD(ctrl, rowmask) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rowmask, 0xf, false))
+    UMR_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    UMR_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    UMR_DPP_ADD(0x124, 0xf);   // row_ror:4
+    UMR_DPP_ADD(0x128, 0xf);   // row_ror:8   -> every lane holds its row's sum
+    UMR_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    UMR_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lanes 48..63 hold the total
+#undef UMR_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, UMR_WAVE));
