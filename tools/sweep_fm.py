@@ -9,12 +9,13 @@ from tools.microbench import bench, bench_alpha  # noqa: E402
 from umr_amd import _lib  # noqa: E402
 
 
-def timed(fn, *a, **k):
+def timed(fn, *a, ids=(0, 1), **k):
     fn(*a, **dict(k, iters=2))                  # module load, allocator warm-up
     _lib.profile_enable(True)
-    _lib.profile_collect(0); _lib.profile_collect(1)   # reset
+    for i in range(4):
+        _lib.profile_collect(i)                  # reset
     fn(*a, **k)
-    (fms, fn_, _), (bms, bn, _) = _lib.profile_collect(0), _lib.profile_collect(1)
+    (fms, fn_, _), (bms, bn, _) = _lib.profile_collect(ids[0]), _lib.profile_collect(ids[1])
     _lib.profile_enable(False)
     return round(fms * 1e3 / max(fn_, 1), 1), round(bms * 1e3 / max(bn, 1), 1)   # us per launch: fwd, bwd
 
@@ -27,6 +28,6 @@ out["n16_ts1"] = timed(bench, 16, 3, 512, 1, iters=20)
 out["n128_ts36_texonly_pooled"] = timed(bench, 128, 3, 512, 36, pool=True, need_p2f=False, need_gf=False)
 out["n128_ts36"] = timed(bench, 128, 3, 512, 36)
 out["n128_ts1"] = timed(bench, 128, 3, 512, 1)
-out["alpha_n16"] = timed(bench_alpha, 16, 3, 512)
-out["alpha_n128"] = timed(bench_alpha, 128, 3, 512)
+out["alpha_n16"] = timed(bench_alpha, 16, 3, 512, ids=(2, 3))
+out["alpha_n128"] = timed(bench_alpha, 128, 3, 512, ids=(2, 3))
 print(json.dumps(out), flush=True)

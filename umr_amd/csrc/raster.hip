@@ -230,16 +230,26 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, flo
     const int kin = (m2 < best) ? 2 : (c1 ? 1 : 0);
     // outside: region selection (:112-126), lowest priority first so the highest-priority match is applied last
     const int ob = fc.obt();
-    const float cx = ob == 0 ? fc.g<R_X0>() : (ob == 1 ? fc.g<R_X1>() : fc.g<R_X2>());
-    const float cy = ob == 0 ? fc.g<R_Y0>() : (ob == 1 ? fc.g<R_Y1>() : fc.g<R_Y2>());
+    // obtuse corner's coordinates: a wave-uniform pick among SGPRs, written with masks so that it stays three scalar
+    // and/or ops -- as nested selects the compiler turns it into a dynamically indexed vector read, which on gfx9
+    // means copying 16 SGPRs to VGPRs (8 v_mov_b64 + s_set_gpr_idx) on every face visit
+    const int mk0 = -(int)(ob == 0), mk1 = -(int)(ob == 1), mk2 = -(int)(ob == 2);
+    const float cx = __int_as_float((__float_as_int(fc.g<R_X0>()) & mk0) | (__float_as_int(fc.g<R_X1>()) & mk1) |
+                                    (__float_as_int(fc.g<R_X2>()) & mk2));
+    const float cy = __int_as_float((__float_as_int(fc.g<R_Y0>()) & mk0) | (__float_as_int(fc.g<R_Y1>()) & mk1) |
+                                    (__float_as_int(fc.g<R_Y2>()) & mk2));
     const bool ovr = (xp - cx) * fc.g<R_OX>() + (yp - cy) * fc.g<R_OY>() > 0;
-    const bool n0 = w0 <= 0, n1 = w1 <= 0, n2 = w2 <= 0;
-    int kout = n2 ? 0 : -1;
-    kout = n1 ? 2 : kout;
-    kout = n0 ? 1 : kout;
-    kout = (n0 & n1) ? (((ob == 2) & ovr) ? 1 : 2) : kout;
-    kout = (n2 & n0) ? (((ob == 1) & ovr) ? 0 : 1) : kout;
-    kout = (n1 & n2) ? (((ob == 0) & ovr) ? 2 : 0) : kout;
+    // Region code m = n0 | n1 << 1 | n2 << 2 with n_k = (w_k <= 0); the reference's if-chain (:112-126) is a table of
+    // m -- single flag: opposite edge (n0 -> 1, n1 -> 2, n2 -> 0); two flags: the vertex region between them
+    // ({n0,n1} -> 2, {n2,n0} -> 1, {n1,n2} -> 0; all three -- degenerate faces only -- ends like {n1,n2}); none: -1 --
+    // plus ONE wave-uniform exception: in the vertex region of the flagged obtuse corner `ob` the other edge is taken
+    // when the pixel lies on its far side (`ovr`).  Entries are stored +1 in 2 bits each.
+    const int m = min((w0 <= 0 ? 1 : 0) | (w1 <= 0 ? 2 : 0) | (w2 <= 0 ? 4 : 0), 6);
+    constexpr unsigned KOUT_LUT = (0u << 0) | (2u << 2) | (3u << 4) | (3u << 6) | (1u << 8) | (2u << 10) | (1u << 12);
+    const int m_ob = ob == 0 ? 6 : (ob == 1 ? 5 : (ob == 2 ? 3 : -1));   // two-flag code of the obtuse corner's region
+    const int k_ob = ob == 0 ? 2 : (ob == 1 ? 0 : 1);                     // the edge its override selects
+    int kout = (int)((KOUT_LUT >> (2 * m)) & 3u) - 1;
+    kout = ((m == m_ob) & ovr) ? k_ob : kout;
     const int ksel = inside ? kin : kout;
     const bool kvalid = ksel >= 0;  // k = -1: reference UB (index -1); defined here and in the oracle as "skip"
     const int k = max(ksel, 0);
