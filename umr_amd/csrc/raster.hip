@@ -771,6 +771,11 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
         atomicAdd(&my_tex[tix * 3 + 2], c);
     }
 }
+// Load through a wave-uniform base pointer plus a per-lane 32-bit BYTE offset: the form the backend turns into
+// `global_load_dword v, v_off, s[base:base+1]` (scalar base, no 64-bit per-lane address arithmetic).
+__device__ __forceinline__ float ld_u(const char *base, unsigned byte_off) {
+    return *(const float *)(base + byte_off);
+}
 template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
@@ -791,6 +796,14 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
     const bool live = fidx < F;
     const int n = nb, f = live ? fidx : 0;
     const size_t npix = (size_t)IS * IS;
+    // wave-uniform bases of this mesh's per-pixel planes; every per-pixel load below is base + 32-bit byte offset
+    const int H2 = IS >> 1;
+    const unsigned pst = (unsigned)(npix * sizeof(float));                      // plane stride in bytes
+    const unsigned gps = A.grad_pooled ? (unsigned)((size_t)H2 * H2 * sizeof(float)) : pst;
+    const int cplanes = RGB == 2 ? 1 : 4;
+    const char *sc_n = (const char *)(A.soft_colors + (size_t)n * cplanes * npix);
+    const char *ag_n = (const char *)(A.aggrs + (size_t)n * 2 * npix);
+    const char *gc_n = (const char *)(A.grad_colors + (size_t)n * cplanes * (A.grad_pooled ? (size_t)H2 * H2 : npix));
     float *wave_tex = s_tex + (size_t)wave * FM_TEXCOPY * FM_TEX_STRIDE(TS);
     // this lane's copy: horizontally and vertically adjacent pixels of a 4x4 / 8x8 tile get different copies
     float *my_tex = wave_tex + ((lane ^ (lane >> 2) ^ (lane >> 4)) & (FM_TEXCOPY - 1)) * FM_TEX_STRIDE(TS);
@@ -866,7 +879,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                     if (xi >= IS || row >= IS) continue;
                     const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
                     const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
-                    const size_t pn = (size_t)row * IS + xi;
+                    const unsigned pn4 = (unsigned)(row * IS + xi) * 4u;                       // byte offset in a full plane
+                    const unsigned gp4 = A.grad_pooled ? (unsigned)((row >> 1) * H2 + (xi >> 1)) * 4u : pn4;
                     // Exact tile skips from the saved forward state, before any geometry:
                     //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
                     //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
@@ -874,11 +888,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                     {
                         bool dead;
                         if (RGB == 2) {
-                            dead = A.soft_colors[(size_t)n * npix + pn] == 1.f;
+                            dead = ld_u(sc_n, pn4) == 1.f;
                         } else {
                             dead = false;
                             if (!NEED_GF) {   // (with vertex gradients both terms must vanish: too rare to pay for)
-                                const float smx = A.aggrs[((size_t)n * 2 + 1) * npix + pn];
+                                const float smx = ld_u(ag_n, pn4 + pst);
                                 const float zmin_f = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
                                                 : ((A.far_ - zmin_f) * A.r_range - smx) * A.inv_gamma < -89.f;
@@ -894,10 +908,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                             const float zq = clip_depth(u0, u1, u2, p, fc);
                             if (zq < A.near_ || zq > A.far_) continue;  // :592
                         }
-                        const float ga = A.grad_pooled
-                            ? 0.25f * A.grad_colors[((size_t)n * (IS >> 1) + (row >> 1)) * (IS >> 1) + (xi >> 1)]
-                            : A.grad_colors[(size_t)n * npix + pn];
-                        const float oa = A.soft_colors[(size_t)n * npix + pn];
+                        const float ga = (A.grad_pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
+                        const float oa = ld_u(sc_n, pn4);
                         float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
                         c_a *= p.frag * (1.f - p.frag) * (-A.nis);
                         const float k2a = 2.f * p.sign * c_a;
@@ -907,23 +919,13 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                         gv[6] += a2 * p.dx; gv[7] += a2 * p.dy;
                         continue;
                     }
-                    float g0, g1, g2, g3;
-                    if (A.grad_pooled) {
-                        const int H = IS >> 1;
-                        const float *gp = A.grad_colors + ((size_t)n * 4 * H + (row >> 1)) * H + (xi >> 1);
-                        const size_t hp = (size_t)H * H;
-                        g0 = 0.25f * gp[0]; g1 = 0.25f * gp[hp]; g2 = 0.25f * gp[2 * hp];
-                        g3 = NEED_GF ? 0.25f * gp[3 * hp] : 0.f;
-                    } else {
-                        const float *gp = A.grad_colors + (size_t)n * 4 * npix + pn;
-                        g0 = gp[0]; g1 = gp[npix]; g2 = gp[2 * npix];
-                        g3 = NEED_GF ? gp[3 * npix] : 0.f;
-                    }
-                    const float *ag = A.aggrs + (size_t)n * 2 * npix + pn;
-                    const float ssum = ag[0], smax = ag[npix];
-                    const float *sc = A.soft_colors + (size_t)n * 4 * npix + pn;
+                    const float gscale = A.grad_pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
+                    const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
+                                g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
+                    const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
+                    const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
                     float c_xy = 0.f;
-                    if (NEED_GF) c_xy = g3 * ((1.f - sc[3 * npix]) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+                    if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
                     if (zp < A.near_ || zp > A.far_) continue;  // :592
@@ -943,10 +945,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const Rast
                             else texel_accumulate(my_tex, tix, ps * g0, ps * g1, ps * g2, lane);
                         }
                         if (NEED_GF) {
-                            const float *tx = tex_f + (size_t)tix * 3;
-                            float c_rgb = g0 * (tx[0] - sc[0]);
-                            c_rgb += g1 * (tx[1] - sc[npix]);
-                            c_rgb += g2 * (tx[2] - sc[2 * npix]);
+                            const char *tx = (const char *)tex_f;
+                            const unsigned t12 = (unsigned)tix * 12u;
+                            float c_rgb = g0 * (ld_u(tx, t12) - ld_u(sc_n, pn4));
+                            c_rgb += g1 * (ld_u(tx, t12 + 4) - ld_u(sc_n, pn4 + pst));
+                            c_rgb += g2 * (ld_u(tx, t12 + 8) - ld_u(sc_n, pn4 + 2 * pst));
                             c_rgb *= ps;
                             c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
                             const float c_z = -(c_rgb * A.inv_gamma * A.r_range) * zp * zp;  // :624
