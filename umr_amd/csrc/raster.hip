@@ -172,9 +172,18 @@ __device__ __forceinline__ float ndc_coord_fast(int i, int IS, float inv_is, boo
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) v16f cv16f_t;
 
+// Load through a wave-uniform base pointer plus a per-lane 32-bit BYTE offset: the form the backend turns into
+// `global_load_dword v, v_off, s[base:base+1]` (scalar base, no 64-bit per-lane address arithmetic).
+__device__ __forceinline__ float ld_u(const char *base, unsigned byte_off) {
+    return *(const float *)(base + byte_off);
+}
+__device__ __forceinline__ float4 ld_u4(const char *base, unsigned byte_off) {
+    return *(const float4 *)(base + byte_off);
+}
+
 struct Face {  // wave-uniform: 32 SGPRs + the record's address
     v16f qa, qb;
-    const float4 *edges;  // three 32-byte edge blocks (global memory, read per lane)
+    const char *edges;    // three 32-byte edge blocks (global memory, read per lane: uniform base + k * 32)
     template <int I> __device__ __forceinline__ float g() const {
         if constexpr (I < 16) return qa[I];
         else return qb[I - 16];
@@ -188,7 +197,7 @@ struct Face {  // wave-uniform: 32 SGPRs + the record's address
 __device__ __forceinline__ void load_face(Face &fc, const float *rg) {
     cv16f_t *r = (cv16f_t *)rg;
     fc.qa = r[0]; fc.qb = r[1];
-    fc.edges = (const float4 *)(rg + R_EDGE);
+    fc.edges = (const char *)(rg + R_EDGE);
 }
 
 struct Pair {  // per-lane result of the pixel/face geometry
@@ -257,7 +266,8 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, flo
     // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
     // D ~ exp(-d^2/sigma) ~ 1e-9, amplifying rounding noise in d^2 ~20x: parity there needs the reference's
     // own noise, i.e. its own arithmetic, not just the same formula.
-    const float4 ea = fc.edges[2 * k], eb = fc.edges[2 * k + 1];  // {a0,a1,a2,a[v1]}, {den, 1/den, -, -}
+    const unsigned ko = (unsigned)k * 32u;
+    const float4 ea = ld_u4(fc.edges, ko), eb = ld_u4(fc.edges, ko + 16u);  // {a0,a1,a2,a[v1]}, {den, 1/den, -, -}
     const float tv = div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
     const bool k0 = k == 0, k1 = k == 1;
     const float tb = 1.f - tv;
@@ -490,8 +500,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                             if (zp < depth_min && inside && (A.double_side || fc.front())) {
                                 depth_min = zp;
                                 face_min = f;
-                                const float *tx = tex_n + ((size_t)f * A.TS + texel_index(q0, q1, A.R)) * 3;
-                                c0 = tx[0]; c1 = tx[1]; c2 = tx[2];
+                                const char *tf = (const char *)(tex_n + (size_t)f * A.TS * 3);   // uniform per face
+                                const unsigned t12 = (unsigned)texel_index(q0, q1, A.R) * 12u;
+                                c0 = ld_u(tf, t12); c1 = ld_u(tf, t12 + 4); c2 = ld_u(tf, t12 + 8);
                             }
                         } else if (fc.front() || A.double_side) {
                             const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
@@ -503,10 +514,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs
                             const float ez = __expf((zn - smax) * A.inv_gamma);
                             ssum = rescale * ssum + ez * p.frag;
                             wgt = ez * p.frag;
-                            const float *tx = tex_n + ((size_t)f * A.TS + texel_index(q0, q1, A.R)) * 3;
-                            c0 = rescale * c0 + wgt * tx[0];
-                            c1 = rescale * c1 + wgt * tx[1];
-                            c2 = rescale * c2 + wgt * tx[2];
+                            const char *tf = (const char *)(tex_n + (size_t)f * A.TS * 3);       // uniform per face
+                            const unsigned t12 = (unsigned)texel_index(q0, q1, A.R) * 12u;
+                            c0 = rescale * c0 + wgt * ld_u(tf, t12);
+                            c1 = rescale * c1 + wgt * ld_u(tf, t12 + 4);
+                            c2 = rescale * c2 + wgt * ld_u(tf, t12 + 8);
                         }
                     }
                 }
@@ -770,11 +782,6 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
         atomicAdd(&my_tex[tix * 3 + 1], b);
         atomicAdd(&my_tex[tix * 3 + 2], c);
     }
-}
-// Load through a wave-uniform base pointer plus a per-lane 32-bit BYTE offset: the form the backend turns into
-// `global_load_dword v, v_off, s[base:base+1]` (scalar base, no 64-bit per-lane address arithmetic).
-__device__ __forceinline__ float ld_u(const char *base, unsigned byte_off) {
-    return *(const float *)(base + byte_off);
 }
 template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 __global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
