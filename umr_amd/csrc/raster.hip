@@ -409,7 +409,13 @@ __device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4
 template <int RGB>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
                     // 2 = silhouette only: alpha plane, no depth / colour / p2f (soft_colors is then [N,IS,IS]),
                     // 3 = visibility only: the hard z-buffer's (depth, face id) planes, nothing else
-__global__ __launch_bounds__(BLK_THREADS) void k_raster_forward(const RasterArgs A) {
+// Register budget for 7 waves per SIMD: the default allocation (106 SGPRs) admits 6; the kernels are VALU-issue bound
+// with every wave stalled ~50 % of its life, so the seventh wave pays (measured: 5 < 6 < 7 ~ 8 waves, -3..6 % time).
+#ifndef FWD_WPE
+#define FWD_WPE 7
+#endif
+#define FWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(FWD_WPE, FWD_WPE)))
+__global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(const RasterArgs A) {
     __shared__ int s_list[LIST_CAP];
     __shared__ int s_wcnt[BLK_THREADS / 64];
     Tile t;
@@ -784,7 +790,11 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
     }
 }
 template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
-__global__ __launch_bounds__(FM_WAVES * 64) void k_raster_backward_fm(const RasterArgs A) {
+#ifndef BWD_WPE
+#define BWD_WPE 7
+#endif
+#define BWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BWD_WPE, BWD_WPE)))
+__global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_fm(const RasterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
     const int F = A.F, IS = A.IS, TS = A.TS;
