@@ -174,3 +174,13 @@ def test_checkpoint_and_obj_formats(tmp_path):
     lines = open(tmp_path / "m.obj").read().split("\n")
     assert sum(l.startswith("v ") for l in lines) == 42 and sum(l.startswith("f ") for l in lines) == 80
     assert min(int(t) for l in lines if l.startswith("f ") for t in l.split()[1:]) == 1
+
+
+def test_rasterize_rejects_mismatched_texture_batch():
+    """The kernels index textures by (mesh, face): a texture tensor built for another face count (e.g. the 656-face
+    symmetric texture space against the 1280-face mesh) must be refused on the host, not read out of bounds."""
+    from umr_amd.functional import SoftRasterizeFunction
+    fv = torch.zeros(2, 80, 3, 3)
+    for tex in (torch.zeros(2, 42, 4, 3), torch.zeros(1, 80, 4, 3), torch.zeros(2, 80, 4)):
+        with pytest.raises(RuntimeError, match="face_vertices must be"):
+            SoftRasterizeFunction.apply(fv, tex, 64)          # shape check precedes any device access

@@ -96,7 +96,13 @@ def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_TRACE = bool(os.environ.get("UMR_TRACE_SYNC"))   # debugging aid: name every C-ABI call and synchronise after it
+
+
 def check(rc, what):
+    if _TRACE:
+        print("[umr] %s rc=%d" % (what, rc), flush=True)
+        torch.cuda.synchronize()
     if rc != 0:
         raise RuntimeError("umr_amd: %s failed with status %d (%s)" % (
             what, rc, {-1: "rejected arguments / unsupported mode", -2: "kernel launch error"}.get(rc, "?")))

@@ -4,6 +4,7 @@ PyTorch is plumbing here: device memory (caching allocator), the current HIP str
 bookkeeping.  All arithmetic happens in libumr_hip.so; there is no CPU or eager-torch fallback.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -56,6 +57,10 @@ class SoftRasterizeFunction(Function):
         fv = _f32c(face_vertices)
         tex = _f32c(textures)
         N, F = fv.shape[:2]
+        if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] != N or tex.shape[1] != F \
+                or tex.shape[3] != 3:
+            raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N,F,TS,3]; got %s and %s"
+                               % (tuple(fv.shape), tuple(tex.shape)))     # the kernels index textures by (n, f)
         TS = tex.shape[2]
         IS = int(image_size)
         ctx.cfg = (IS, float(near), float(far), float(eps), float(sigma_val), _FUNC_DIST[dist_func],

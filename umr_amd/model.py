@@ -392,7 +392,8 @@ def build_training_step_s2(args, dev, world):
                                         device=dev)
     rc = RenderCompareS2(net.get_mean_shape().detach(), net.faces, ex["part_vertex_ids"], ex["uv_img"],
                          net.uv_sampler, args.image_size, opts.num_hypo_cams, texture_loss_type="perceptual",
-                         discriminator=ddp_disc, tex_size=opts.tex_size).to(dev)
+                         discriminator=ddp_disc, tex_size=opts.tex_size,
+                         num_sym_faces=net.texture_predictor.num_sym_faces).to(dev)      # train_s2.py:154-161
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
                            betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))
     mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
