@@ -1,0 +1,98 @@
+"""Copy the outputs of tools/refresh_profiles.sh (gpurun_out/refresh) into profiles/ and write profiles/<tag>_SUMMARY.md.
+Usage: python tools/make_summary.py [tag]   (tag default r01)"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "refresh")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+P = os.path.join(ROOT, "profiles")
+
+
+def cp(src, dst):
+    shutil.copyfile(os.path.join(SRC, src), os.path.join(P, dst))
+
+
+cp("bench_full.json", tag + "_bench_full.json")
+cp("bench_hotpath_only.json", tag + "_bench_hotpath_only.json")
+cp("bench_s2.json", tag + "_bench_s2.json")
+cp("stats/t_kernel_stats.csv", tag + "_bench_kernel_stats.csv")
+cp("traffic/traffic.json", tag + "_traffic.json")
+cp("traffic/traffic.json", "traffic.json")
+pm = os.path.join(P, tag + "_pmc")
+shutil.rmtree(pm, ignore_errors=True)
+os.makedirs(pm)
+for shape in ("ts1", "ts36"):
+    for p in ("p1", "p2"):
+        shutil.copyfile(os.path.join(SRC, "pmc_" + shape, p, "t_counter_collection.csv"),
+                        os.path.join(pm, "%s_%s_counters.csv" % (shape, p)))
+    shutil.copyfile(os.path.join(SRC, "pmc_%s.log" % shape), os.path.join(pm, "%s_report.jsonl" % shape))
+with open(os.path.join(P, tag + "_microbench.log"), "w") as f:
+    for name in ("microbench.log", "kernel_only.log"):
+        f.write("".join(l for l in open(os.path.join(SRC, name)) if "amdgpu.ids" not in l))
+
+full = json.load(open(os.path.join(SRC, "bench_full.json")))
+hot = json.load(open(os.path.join(SRC, "bench_hotpath_only.json")))
+s2 = json.load(open(os.path.join(SRC, "bench_s2.json")))
+rows = list(csv.DictReader(open(os.path.join(SRC, "stats", "t_kernel_stats.csv"))))
+steps = 15.0
+total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+ours = [r for r in rows if "(anonymous namespace)::k_" in r["Name"]]
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")[:92]
+tr = json.load(open(os.path.join(SRC, "traffic", "traffic.json")))
+L = []
+L.append("# Round 1 profile summary (1x MI355X)\n")
+L.append("All files in this directory are produced on the GPU box by `tools/refresh_profiles.sh` and copied here by "
+         "`tools/make_summary.py`.\n")
+L.append("Command behind the kernel table: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
+         "--steps 10 --warmup 5 --cpu-baseline 0` (15 steps of the full train_s1 step, bs=16).  CSV: `profiles/%s_bench_kernel_stats.csv`.\n" % tag)
+L.append("Total GPU kernel time %.1f ms = %.2f ms/step (un-profiled wall: %.2f ms/step).\n" % (total_ns / 1e6, total_ns / 1e6 / steps, full["ms_per_step"]))
+L.append("## libumr_hip.so kernels (rocprofv3 averages)\n")
+L.append("| kernel | calls/step | avg us | ms/step |\n|---|---|---|---|")
+osum = 0.0
+for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
+    ms = float(r["TotalDurationNs"]) / 1e6 / steps
+    osum += ms
+    L.append("| `%s` | %.1f | %.1f | %.3f |" % (short(r["Name"]), int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, ms))
+L.append("\nSum: %.2f ms/step of %.2f (%.0f %%); the rest is the network (MIOpen fp32 convolutions, batch-norm, GEMMs), Adam "
+         "and torch elementwise ops.\n" % (osum, total_ns / 1e6 / steps, 100 * osum / (total_ns / 1e6 / steps)))
+L.append("## Top 15 kernels overall\n")
+L.append("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:15]:
+    L.append("| `%s` | %s | %.2f | %.1f | %.1f |" % (short(r["Name"])[:80], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+rf = full["roofline"]
+L.append("\n## bench.py lines of the same build (un-profiled)\n")
+L.append("Full step (`profiles/%s_bench_full.json`): **%.0f images/s**, %.2f ms/step; roofline (texture-render raster "
+         "backward, HIP events recorded by the library on the launch stream): avg %.1f us/launch, %.0f GB/s algorithmic = "
+         "%.1f %% of 8 TB/s, PMC traffic %.1f MB/launch vs %.1f MB algorithmic; cpu_baseline %.2f images/s on %d threads.\n"
+         % (tag, full["value"], full["ms_per_step"], rf["avg_us"], rf["achieved"], 100 * rf["frac"],
+            (rf["traffic"] or 0) / 1e6, rf["alg_bytes_per_launch"] / 1e6, full["cpu_baseline"]["value"], full["cpu_baseline"]["cores"]))
+L.append("Hot path only, `--model 0` (`profiles/%s_bench_hotpath_only.json`): **%.0f images/s**, %.2f ms/step.\n" % (tag, hot["value"], hot["ms_per_step"]))
+L.append("train_s2 sequence, `--workload s2` (`profiles/%s_bench_s2.json`, 10 steps): %.0f images/s, %.1f ms/step.\n" % (tag, s2["value"], s2["ms_per_step"]))
+bk = [r for r in ours if "k_raster_backward_fm<1, false, true>" in r["Name"]]
+if bk:
+    L.append("HIP-event average vs rocprofv3 average for `k_raster_backward_fm<1, false, true>`: %.1f us vs %.1f us.\n"
+             % (rf["avg_us"], float(bk[0]["AverageNs"]) / 1e3))
+L.append("## HBM traffic (PMC, `tools/collect_traffic.sh`, separate FETCH_SIZE / WRITE_SIZE passes)\n")
+c = tr["calibration"]
+L.append("Calibration: `%s` reads %d known bytes with dword loads; FETCH_SIZE reported %.0f KB => correction factor %.3f "
+         "(the guide's 1/2 under-count on gfx950 confirmed for this access width). WRITE_SIZE taken as is.\n"
+         % (c["kernel"], c["known_read_bytes"], c["FETCH_SIZE_KB"], c["fetch_correction_factor"]))
+L.append("| kernel (N=16 launches inside bench) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch (corrected) |\n|---|---|---|---|")
+for k, v in tr["kernels"].items():
+    L.append("| `%s` | %.0f | %.0f | %.1f MB |" % (short(k), v["FETCH_SIZE_KB"], v["WRITE_SIZE_KB"], v["hbm_bytes_per_launch"] / 1e6))
+L.append("\n## Kernel timings and SQ counters\n")
+L.append("`profiles/%s_microbench.log`: torch-event timings per autograd call (incl. face setup and allocation) and, last "
+         "line, kernel-only HIP-event averages in us per launch [forward, backward] at N=16 / N=128.\n" % tag)
+L.append("`profiles/%s_pmc/`: two SQ PMC passes (N=64, TS=1 and TS=36) and the derived per-kernel report:\n\n```" % tag)
+for shape in ("ts1", "ts36"):
+    for l in open(os.path.join(SRC, "pmc_%s.log" % shape)):
+        if l.startswith("{"):
+            L.append(shape + ": " + l.strip())
+L.append("```")
+open(os.path.join(P, tag + "_SUMMARY.md"), "w").write("\n".join(L) + "\n")
+print("wrote", os.path.join(P, tag + "_SUMMARY.md"))
