@@ -731,7 +731,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 #endif
 #define FM_NQ (64 / (FM_TW * FM_TH))
 #ifndef FM_TEXMERGE
-#define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2, 3 = + y^1
+#define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2
+                       // (a third, vertical step measured slower)
 #endif
 #ifndef FM_TEXCOPY
 #define FM_TEXCOPY 4   // private copies of a wave's LDS texel accumulators (power of two): neighbouring pixels share a
@@ -763,24 +764,19 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #if FM_TEXMERGE >= 1
 #pragma unroll
     for (int step = 0; step < (FM_TEXMERGE >= 2 ? 2 : 1); ++step) {
+        // keeper = the lane of the pair with bit `step` clear.  The per-lane constants live in VGPRs (as 64-bit lane
+        // masks they were SGPR spills, restored with v_readlane every visit); multiplying the partner's value by the
+        // 0/1 weight lets the backend fuse the DPP read into one v_fmac_f32_dpp per channel.
+        const bool keep = (lane & (1 << step)) == 0;
+        const float keepf = keep ? 1.f : 0.f;
+        const int dropm = keep ? 0 : -1;
         const int t = dpp_i(-1, tix, step);                     // partner's texel, -1 if it is not here
-        const float oa = dpp_f(0.f, a, step), ob = dpp_f(0.f, b, step), oc = dpp_f(0.f, c, step);
-        const bool same = t == tix, keep = (lane & (1 << step)) == 0;
-        a += (same & keep) ? oa : 0.f;
-        b += (same & keep) ? ob : 0.f;
-        c += (same & keep) ? oc : 0.f;
-        tix = (same & !keep) ? -1 : tix;                        // merged into the partner: nothing left to add
-    }
-#endif
-#if FM_TEXMERGE >= 3 && FM_TW == 4
-    {   // vertical neighbour of a 4x4 sub-tile: lane + 4 within the 16-lane DPP row
-        const int td = dpp_i(-1, tix, 2), tu = dpp_i(-2, tix, 3);   // texel of the lane below (i+4) / above (i-4)
-        const float oa = dpp_f(0.f, a, 2), ob = dpp_f(0.f, b, 2), oc = dpp_f(0.f, c, 2);
-        const bool keep = (lane & 4) == 0, same = keep ? td == tix : tu == tix;
-        a += (same & keep) ? oa : 0.f;
-        b += (same & keep) ? ob : 0.f;
-        c += (same & keep) ? oc : 0.f;
-        tix = (same & !keep) ? -1 : tix;
+        const bool same = t == tix;
+        const float w = same ? keepf : 0.f;
+        a = fmaf(dpp_f(0.f, a, step), w, a);
+        b = fmaf(dpp_f(0.f, b, step), w, b);
+        c = fmaf(dpp_f(0.f, c, step), w, c);
+        tix |= same ? dropm : 0;                                // merged into the partner: nothing left to add
     }
 #endif
     if (tix >= 0) {
