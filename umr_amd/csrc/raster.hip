@@ -12,9 +12,11 @@
 //     ASCENDING index order (the forward's online soft-max and the p2f weights depend on visit
 //     order, reference :421-430);  each wave then filters the LDS list against its own 8x8 tile
 //     with one lane per candidate face + ballot and walks the set bits;
-//   * per-(wave, face) partial sums (p2f accumulators in forward, the 9 vertex gradients in
-//     backward) are reduced across the wavefront before touching memory: one atomic per
-//     (tile, face, component) instead of the reference's one per (pixel, face, component).
+//   * the forward's p2f accumulators are reduced across the wavefront (DPP) before touching memory: one atomic
+//     per (tile, face, component) instead of the reference's one per (pixel, face, component);
+//   * the backward is FACE-major (k_raster_backward_fm): one wavefront per face walks the face's 4x4-pixel
+//     sub-tiles four at a time, keeps the 9 vertex gradients in registers and the texel gradients in LDS, and
+//     writes each face's result once -- no global atomics at all.
 //
 // Numerics: fp32 throughout, IEEE division, no FMA contraction (-ffp-contract=off) so that the
 // branch-deciding quantities (barycentrics, distances, depth) round like the reference's
