@@ -85,6 +85,11 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * else -- what TexCycle consumes from the hard renderer (nnutils/loss_utils.py:327-328, train_s1.py:223-224).
  * soft_colors, textures, grid, p2f_* may be NULL.  Bit-identical planes to the full hard kernel. */
 #define UMR_RASTER_FACE_ID_ONLY 4
+/* flags bits 8-15: texture group G (0 = 1).  `textures` is then [N/G,F,TS,3] and view n samples textures[n / G]:
+ * K camera hypotheses of one image share one texture set, so the reference's textures.repeat(K) (70 MB at N=128,
+ * nnutils/loss_utils.py:303-306) is folded into indexing.  umr_raster_backward takes the same field in bits 8-15 of
+ * `grad_is_pooled`; grad_textures stays PER VIEW [N,F,TS,3] (the caller sums the G views, as autograd does for repeat). */
+#define UMR_RASTER_TEX_GROUP(G) (((G) & 0xff) << 8)
 /* umr_raster_backward `grad_is_pooled` is a bit field: */
 #define UMR_BWD_GRAD_POOLED 1   /* gradient arrives at the 2x2-pooled resolution */
 #define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb
@@ -121,21 +126,26 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
  *   external/SoftRas/soft_renderer/functional/face_vertices.py:4-22   gather
  *   external/SoftRas/soft_renderer/functional/look_at.py:48-60 + orthogonal.py:13-16
  *                                        (eye (0,0,eye_z), at 0, up y => z -= eye_z; scale 1)
- *   verts [N,V,3], cams [N,7] = (s, tx, ty, qw, qx, qy, qz), faces_idx [N,F,3] int32
+ *   verts [N/G,V,3], cams [N,7] = (s, tx, ty, qw, qx, qy, qz), faces_idx [N/G,F,3] int32
  *   face_pre  [N,F,9] or NULL: projected + flipped, BEFORE look_at (what Lighting sees, mesh.py:111-118)
  *   face_out  [N,F,9]: after look_at/orthogonal -- the rasterizer's `faces`
+ *   mesh_group G >= 1: view n renders mesh n / G.  G = 1 is the reference layout; G = K folds the x K repeats of
+ *   vertices and faces that MultiMaskLoss / MultiTextureLoss materialise (nnutils/loss_utils.py:260-262, 303-306:
+ *   one mesh, K camera hypotheses) into indexing.
  * -------------------------------------------------------------------------------------------*/
 int umr_project_faces_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
-                              float *face_out, int N, int V, int F, float offset_z, float eye_z,
+                              float *face_out, int N, int V, int F, float offset_z, float eye_z, int mesh_group,
                               void *stream);
 
 /* backward: grad_face_out [N,F,9] (and optional grad_face_pre, may be NULL) ->
- *   grad_verts [N,V,3] (ADDED into; caller zero-fills) and grad_cams [N,7] (overwritten).
+ *   grad_verts [N,V,3] PER VIEW (ADDED into; caller zero-fills and, for mesh_group > 1, sums the G views of a mesh)
+ *   and grad_cams [N,7] (overwritten).
  *   workspace: umr_project_workspace_bytes(N, V) bytes. */
 size_t umr_project_workspace_bytes(int N, int V);
 int umr_project_faces_backward(const float *grad_face_out, const float *grad_face_pre, const float *verts,
                                const float *cams, const int *faces_idx, float *grad_verts, float *grad_cams,
-                               int N, int V, int F, void *workspace, size_t workspace_bytes, void *stream);
+                               int N, int V, int F, int mesh_group, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* vertices only, no flip, no look_at:
  *   out_dim 2: SoftRenderer.project_points / orthographic_proj (nnutils/smr.py:76-78, geom_utils.py:60-72)

@@ -103,7 +103,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.umr_raster_forward(None, *z[1:], 1, 5, 1, 64, *tail) == -1  # NULL faces
     assert L.umr_chamfer_forward(one, one, one, one, one, one, 1, 4, 4, 5, None) == -1   # D not in {2,3}
     assert L.umr_dt_barrier(one, one, None, None, 1, 16, 16, 50.0, one, 8, None) == -1   # workspace too small
-    assert L.umr_project_faces_forward(one, one, one, None, one, 0, 4, 4, 5.0, -2.732, None) == -1
+    assert L.umr_project_faces_forward(one, one, one, None, one, 0, 4, 4, 5.0, -2.732, 1, None) == -1
     assert L.umr_debug_set(b"no_such_switch", 1) == -1
 
 
@@ -181,6 +181,6 @@ def test_rasterize_rejects_mismatched_texture_batch():
     symmetric texture space against the 1280-face mesh) must be refused on the host, not read out of bounds."""
     from umr_amd.functional import SoftRasterizeFunction
     fv = torch.zeros(2, 80, 3, 3)
-    for tex in (torch.zeros(2, 42, 4, 3), torch.zeros(1, 80, 4, 3), torch.zeros(2, 80, 4)):
+    for tex in (torch.zeros(2, 42, 4, 3), torch.zeros(3, 80, 4, 3), torch.zeros(2, 80, 4)):   # [1,80,4,3] = a group of 2
         with pytest.raises(RuntimeError, match="face_vertices must be"):
             SoftRasterizeFunction.apply(fv, tex, 64)          # shape check precedes any device access

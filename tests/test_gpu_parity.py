@@ -617,3 +617,44 @@ def test_texture_atlas_and_textured_obj_vs_reference_golden(oracle_built, tmp_pa
         assert np.array_equal(t2n(o["u8"]), (ref_img.clip(0, 1) * 255).astype("uint8"))
     with pytest.raises(RuntimeError):
         io_utils.texture_atlas(torch.rand(4, 5, 3, device=DEV))                        # 5 texels: not a square
+
+
+def test_camera_hypothesis_groups_equal_explicit_repeats():
+    """K camera hypotheses per mesh through mesh / texture GROUP indexing (vertices [B,V,3], textures [B,F,TS,3], cams
+    [B*K,7]) against the reference's layout with everything repeated K times (loss_utils.py:260-262, 303-306):
+    identical images, gradients equal up to the order in which the K views are summed."""
+    from umr_amd.smr import SoftRenderer
+    B, K = 2, 3
+    verts, faces, _, gen = scene(B, 2, seed=21)
+    _, _, cams, _ = scene(B * K, 2, seed=22)
+    F = faces.shape[1]
+    tex = torch.rand(B, F, 4, 3, generator=gen)
+    for kind in ("softmax_tex", "softmax_lit", "alpha"):
+        r = SoftRenderer(32, "softmax")
+        if kind == "softmax_tex":
+            r.ambient_light_only()
+        if kind == "alpha":
+            r.alpha_only = True
+        outs = []
+        for grouped in (True, False):
+            v = verts.to(DEV).requires_grad_(True)
+            t = tex.to(DEV).requires_grad_(True)
+            c = cams.to(DEV).requires_grad_(True)
+            if grouped:
+                img, p2f, _ = r(v, faces.to(DEV), c, None if kind == "alpha" else t)
+            else:
+                rep = lambda x: x.unsqueeze(1).repeat(1, K, *([1] * (x.dim() - 1))).view(-1, *x.shape[1:])
+                img, p2f, _ = r(rep(v), rep(faces.to(DEV)), c, None if kind == "alpha" else rep(t))
+            w = torch.linspace(0.5, 1.5, img.numel(), device=DEV).view_as(img)
+            (img * w).sum().backward()
+            outs.append((t2n(img), t2n(p2f), t2n(v.grad), t2n(c.grad), None if kind == "alpha" else t2n(t.grad)))
+        g, e = outs
+        assert np.array_equal(g[0], e[0]), kind                                          # same kernels, same inputs
+        assert np.abs(g[1] - e[1]).max() <= 1e-5, kind           # p2f: float atomics across tiles, order varies
+        assert np.abs(g[3] - e[3]).max() <= 1e-5 * np.abs(e[3]).max(), kind   # per view; vertex scatter uses float atomics
+        sv = np.abs(e[2]).max()
+        assert np.abs(g[2] - e[2]).max() <= 1e-5 * sv, kind                              # summed over K: order only
+        if g[4] is not None:
+            assert np.abs(g[4] - e[4]).max() <= 1e-5 * max(np.abs(e[4]).max(), 1e-12), kind
+    with pytest.raises(RuntimeError):
+        SoftRenderer(32, "softmax")(verts.to(DEV), faces.to(DEV), cams[:5].to(DEV), tex.to(DEV))   # 5 views, 2 meshes

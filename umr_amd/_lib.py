@@ -24,9 +24,9 @@ SIGNATURES = {
     "umr_raster_forward": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I,
                             ctypes.POINTER(ctypes.c_float), _P, _Z, _P], _I),
     "umr_raster_backward": ([_P] * 8 + [_I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P, _Z, _P], _I),
-    "umr_project_faces_forward": ([_P] * 5 + [_I, _I, _I, _F, _F, _P], _I),
+    "umr_project_faces_forward": ([_P] * 5 + [_I, _I, _I, _F, _F, _I, _P], _I),
     "umr_project_workspace_bytes": ([_I, _I], _Z),
-    "umr_project_faces_backward": ([_P] * 7 + [_I, _I, _I, _P, _Z, _P], _I),
+    "umr_project_faces_backward": ([_P] * 7 + [_I, _I, _I, _I, _P, _Z, _P], _I),
     "umr_project_points_forward": ([_P] * 3 + [_I, _I, _I, _F, _P], _I),
     "umr_project_points_backward": ([_P] * 5 + [_I, _I, _I, _P], _I),
     "umr_neg_iou_forward": ([_P, _L, _P, _P, _P, _I, _L, _P], _I),

@@ -34,13 +34,14 @@ __device__ __forceinline__ void quat_rot(const Cam &q, float x, float y, float z
 
 __global__ void k_project_faces(const float *__restrict__ verts, const float *__restrict__ cams,
                                 const int *__restrict__ faces_idx, float *__restrict__ face_pre,
-                                float *__restrict__ face_out, int N, int V, int F, float offset_z, float eye_z) {
+                                float *__restrict__ face_out, int N, int V, int F, float offset_z, float eye_z,
+                                int group) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
     if (i >= N * F * 3) return;
-    const int n = i / (F * 3);
+    const int n = i / (F * 3), m = n / group;              // view n renders mesh m = n / group (K views per mesh)
     const Cam cm = load_cam(cams, n);
-    const int vi = faces_idx[i];
-    const float *v = verts + ((size_t)n * V + vi) * 3;
+    const int vi = faces_idx[(size_t)m * F * 3 + (i - n * F * 3)];
+    const float *v = verts + ((size_t)m * V + vi) * 3;
     float r1, r2, r3;
     quat_rot(cm, v[0], v[1], v[2], r1, r2, r3);
     const float X = cm.s * r1 + cm.tx;
@@ -67,11 +68,11 @@ __global__ void k_project_points(const float *__restrict__ verts, const float *_
 // scatter-add face-corner gradients onto projected vertices: gproj[n, v, :] (zeroed beforehand)
 __global__ void k_scatter_face_grads(const float *__restrict__ g_out, const float *__restrict__ g_pre,
                                      const int *__restrict__ faces_idx, float *__restrict__ gproj, int N, int V,
-                                     int F) {
+                                     int F, int group) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
     if (i >= N * F * 3) return;
     const int n = i / (F * 3);
-    const int vi = faces_idx[i];
+    const int vi = faces_idx[(size_t)(n / group) * F * 3 + (i - n * F * 3)];
     float gx = g_out[(size_t)i * 3], gy = g_out[(size_t)i * 3 + 1], gz = g_out[(size_t)i * 3 + 2];
     if (g_pre) { gx += g_pre[(size_t)i * 3]; gy += g_pre[(size_t)i * 3 + 1]; gz += g_pre[(size_t)i * 3 + 2]; }
     float *d = gproj + ((size_t)n * V + vi) * 3;
@@ -89,9 +90,10 @@ __global__ __launch_bounds__(256) void k_project_backward(const float *__restric
                                                           const float *__restrict__ verts,
                                                           const float *__restrict__ cams,
                                                           float *__restrict__ grad_verts,
-                                                          float *__restrict__ grad_cams, int V) {
+                                                          float *__restrict__ grad_cams, int V, int group) {
     __shared__ float smem[16];
     const int n = blockIdx.x;
+    verts += (size_t)(n / group) * V * 3 - (size_t)n * V * 3;   // view n reads mesh n / group; gradients stay per view
     const Cam q = load_cam(cams, n);
     const float uu = q.a * q.a + q.b * q.b + q.c * q.c;
     const float d = q.w * q.w - uu;
@@ -147,13 +149,14 @@ __global__ __launch_bounds__(256) void k_project_backward(const float *__restric
 extern "C" {
 
 int umr_project_faces_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
-                              float *face_out, int N, int V, int F, float offset_z, float eye_z,
+                              float *face_out, int N, int V, int F, float offset_z, float eye_z, int mesh_group,
                               void *stream) {
     if (!verts || !cams || !faces_idx || !face_out || N <= 0 || V <= 0 || F <= 0) return UMR_ERR_ARG;
+    if (mesh_group < 1 || N % mesh_group) return UMR_ERR_ARG;
     if ((long long)N * F * 3 > 0x7fffffffLL) return UMR_ERR_ARG;
     const int total = N * F * 3;
     k_project_faces<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(verts, cams, faces_idx, face_pre, face_out,
-                                                                        N, V, F, offset_z, eye_z);
+                                                                        N, V, F, offset_z, eye_z, mesh_group);
     return umr_launch_status();
 }
 
@@ -161,16 +164,18 @@ size_t umr_project_workspace_bytes(int N, int V) { return N > 0 && V > 0 ? (size
 
 int umr_project_faces_backward(const float *grad_face_out, const float *grad_face_pre, const float *verts,
                                const float *cams, const int *faces_idx, float *grad_verts, float *grad_cams,
-                               int N, int V, int F, void *workspace, size_t workspace_bytes, void *stream) {
+                               int N, int V, int F, int mesh_group, void *workspace, size_t workspace_bytes,
+                               void *stream) {
     if (!grad_face_out || !verts || !cams || !faces_idx || !grad_cams || !workspace) return UMR_ERR_ARG;
     if (N <= 0 || V <= 0 || F <= 0 || (long long)N * F * 3 > 0x7fffffffLL) return UMR_ERR_ARG;
+    if (mesh_group < 1 || N % mesh_group) return UMR_ERR_ARG;
     if (workspace_bytes < umr_project_workspace_bytes(N, V)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, umr_project_workspace_bytes(N, V), st) != hipSuccess) return UMR_ERR_LAUNCH;
     const int total = N * F * 3;
     k_scatter_face_grads<<<(total + 255) / 256, 256, 0, st>>>(grad_face_out, grad_face_pre, faces_idx,
-                                                              (float *)workspace, N, V, F);
-    k_project_backward<0><<<N, 256, 0, st>>>((const float *)workspace, verts, cams, grad_verts, grad_cams, V);
+                                                              (float *)workspace, N, V, F, mesh_group);
+    k_project_backward<0><<<N, 256, 0, st>>>((const float *)workspace, verts, cams, grad_verts, grad_cams, V, mesh_group);
     return umr_launch_status();
 }
 
@@ -187,9 +192,9 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
                                 float *grad_cams, int N, int V, int out_dim, void *stream) {
     if (!grad_out || !verts || !cams || !grad_cams || N <= 0 || V <= 0) return UMR_ERR_ARG;
     if (out_dim == 2)
-        k_project_backward<1><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V);
+        k_project_backward<1><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V, 1);
     else if (out_dim == 3)
-        k_project_backward<2><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V);
+        k_project_backward<2><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V, 1);
     else
         return UMR_ERR_ARG;
     return umr_launch_status();

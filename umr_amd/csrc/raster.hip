@@ -69,6 +69,7 @@ struct RasterArgs {
     float inv_gamma;
     int double_side, with_p2f, grad_pooled, need_gf, need_gt;
     int tiles_x, tiles_y;
+    int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
 };
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
     const size_t pn = (size_t)t.row * IS + t.xi;
     const float4 *__restrict__ bbox_n = A.bbox + (size_t)t.n * F;
     const float *__restrict__ rec_n = A.rec + (size_t)t.n * F * REC;
-    const float *__restrict__ tex_n = A.textures + (size_t)t.n * F * A.TS * 3;
+    const float *__restrict__ tex_n = A.textures + (size_t)(t.n / A.tex_group) * F * A.TS * 3;
 
     float alpha = 1.f;
     float ssum = __expf(A.eps / A.gamma), smax = A.eps;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
     const size_t pn = (size_t)t.row * IS + t.xi;
     const float4 *__restrict__ bbox_n = A.bbox + (size_t)t.n * F;
     const float *__restrict__ rec_n = A.rec + (size_t)t.n * F * REC;
-    const float *__restrict__ tex_n = A.textures + (size_t)t.n * F * TS * 3;
+    const float *__restrict__ tex_n = A.textures + (size_t)(t.n / A.tex_group) * F * TS * 3;
 
     float ssum = 1.f, smax = 0.f, oc0 = 0.f, oc1 = 0.f, oc2 = 0.f, oa = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
     if (t.valid) {
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     if (live) {
         Face fc;
         load_face(fc, A.rec + ((size_t)n * F + f) * REC);
-        const float *__restrict__ tex_f = A.textures + ((size_t)n * F + f) * TS * 3;
+        const float *__restrict__ tex_f = A.textures + ((size_t)(n / A.tex_group) * F + f) * TS * 3;
         // pixel-index window of the dilated bbox, widened by one pixel; the exact per-pixel reject of the
         // reference (:536) still runs inside eval_pair, so the window only has to be conservative.
         // xp(i) = (2i + 1 - IS)/IS  <=>  i = (xp*IS + IS - 1)/2
@@ -1106,6 +1107,8 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     int R = 0;
     const bool alpha_only = (flags & UMR_RASTER_ALPHA_ONLY) != 0;
     const bool ids_only = (flags & UMR_RASTER_FACE_ID_ONLY) != 0;
+    const int tex_group = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : 1;
+    if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (alpha_only && ids_only) return UMR_ERR_ARG;
     if (ids_only && (func_id_rgb != 0 || !aggrs_info)) return UMR_ERR_ARG;
     if (!faces || (!soft_colors && !ids_only) || !workspace) return UMR_ERR_ARG;
@@ -1127,7 +1130,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.N = N; A.F = F; A.IS = image_size; A.TS = TS; A.R = R;
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;  // :332
-    A.gamma = gamma_val; A.double_side = double_side; A.with_p2f = with_p2f;
+    A.gamma = gamma_val; A.double_side = double_side; A.with_p2f = with_p2f; A.tex_group = tex_group;
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
@@ -1162,7 +1165,9 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     (void)faces_info;  // recomputed into the workspace (bit-identical: same kernel, same input)
     int R = 0;
     const bool alpha_only = (grad_is_pooled & UMR_BWD_ALPHA_ONLY) != 0;
+    const int tex_group = ((grad_is_pooled >> 8) & 0xff) ? ((grad_is_pooled >> 8) & 0xff) : 1;
     grad_is_pooled &= UMR_BWD_GRAD_POOLED;
+    if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (!faces || !soft_colors || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
     if (!alpha_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (alpha_only && (need_grad_textures || !need_grad_faces)) return UMR_ERR_ARG;
@@ -1184,6 +1189,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.gamma = gamma_val; A.double_side = double_side;
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
+    A.tex_group = tex_group;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     const int total = N * F;

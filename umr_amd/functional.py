@@ -57,10 +57,12 @@ class SoftRasterizeFunction(Function):
         fv = _f32c(face_vertices)
         tex = _f32c(textures)
         N, F = fv.shape[:2]
-        if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] != N or tex.shape[1] != F \
-                or tex.shape[3] != 3:
-            raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N,F,TS,3]; got %s and %s"
-                               % (tuple(fv.shape), tuple(tex.shape)))     # the kernels index textures by (n, f)
+        if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] < 1 or N % tex.shape[0] \
+                or N // tex.shape[0] > 255 or tex.shape[1] != F or tex.shape[3] != 3:
+            raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N or N/G,F,TS,3]; got "
+                               "%s and %s" % (tuple(fv.shape), tuple(tex.shape)))   # kernels index textures by (n//G, f)
+        G = N // tex.shape[0]     # G views share one texture set (the reference repeats textures x K, loss_utils.py:303-306)
+        ctx.tex_group = G
         TS = tex.shape[2]
         IS = int(image_size)
         ctx.cfg = (IS, float(near), float(far), float(eps), float(sigma_val), _FUNC_DIST[dist_func],
@@ -81,8 +83,8 @@ class SoftRasterizeFunction(Function):
         (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
         rc = L.umr_raster_forward(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_info),
                                   ptr(p2f_sum), ptr(soft_colors), ptr(pooled), N, F, TS, IS_, near_, far_, eps_,
-                                  sig, fd, de, gam, frgb, fal, fsm, ds, 0 if need_p2f else 1, bg, ptr(ws), ws_bytes,
-                                  _lib.stream_ptr(dev))
+                                  sig, fd, de, gam, frgb, fal, fsm, ds, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
+                                  ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "umr_raster_forward")
         p2f = p2f_info / p2f_sum.clamp_min(1e-12)  # functional/soft_rasterize.py:73
         ctx.save_for_backward(fv, tex, soft_colors, aggrs_info)
@@ -99,17 +101,20 @@ class SoftRasterizeFunction(Function):
         TS = tex.shape[2]
         need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32) if need_gf else None
-        grad_textures = torch.zeros_like(tex) if need_gt else None
+        G = ctx.tex_group
+        grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32) if need_gt else None   # per view
         g = grad_soft_colors.to(torch.float32).contiguous()
         ws_bytes = L.umr_raster_workspace_bytes(N, F)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
         rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
-                                   ptr(grad_textures), ptr(g), 1 if ctx.pool else 0, 1 if need_gf else 0,
+                                   ptr(grad_textures), ptr(g), (1 if ctx.pool else 0) | (G << 8), 1 if need_gf else 0,
                                    1 if need_gt else 0, N, F, TS, IS_, near_, far_, eps_, sig, fd, de, gam, frgb,
                                    fal, fsm, ds, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "umr_raster_backward")
         gf = grad_faces.view(ctx.fv_shape) if need_gf else None
+        if need_gt and G > 1:
+            grad_textures = grad_textures.view(N // G, G, F, TS, 3).sum(1)   # autograd of the reference's repeat
         return (gf, grad_textures) + (None,) * 15
 
 
@@ -195,20 +200,26 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
 
 
 class ProjectFacesFunction(Function):
-    """verts [N,V,3], cams [N,7], faces [N,F,3] int32 -> (face_pre [N,F,3,3], face_out [N,F,3,3]).
-    Fuses geom_utils.orthographic_proj_withz + smr.Render's y flip + face_vertices + LookAt/orthogonal."""
+    """verts [N/G,V,3], cams [N,7], faces [N/G,F,3] int32 -> (face_pre [N,F,3,3], face_out [N,F,3,3]).
+    Fuses geom_utils.orthographic_proj_withz + smr.Render's y flip + face_vertices + LookAt/orthogonal.
+    G = N_cams / N_meshes >= 1 camera hypotheses per mesh: view n renders mesh n // G, i.e. the layout of
+    `vs.unsqueeze(1).repeat(1, K, 1, 1).view(B*K, V, 3)` (nnutils/loss_utils.py:260-262) without the copies."""
 
     @staticmethod
     def forward(ctx, verts, cams, faces_idx, offset_z, eye_z, want_pre):
         L = _lib.lib()
         dev = verts.device
         v, c = _f32c(verts), _f32c(cams)
-        N, V = v.shape[:2]
+        M, V = v.shape[:2]
+        N = c.shape[0]
         F = faces_idx.shape[1]
+        if N % M or faces_idx.shape[0] != M:
+            raise RuntimeError("project_faces: %d cameras for %d meshes / %d face sets" % (N, M, faces_idx.shape[0]))
+        G = N // M
         face_out = torch.empty(N, F, 3, 3, device=dev, dtype=torch.float32)
         face_pre = torch.empty(N, F, 3, 3, device=dev, dtype=torch.float32) if want_pre else None
         rc = L.umr_project_faces_forward(ptr(v), ptr(c), ptr(faces_idx), ptr(face_pre), ptr(face_out), N, V, F,
-                                         float(offset_z), float(eye_z), _lib.stream_ptr(dev))
+                                         float(offset_z), float(eye_z), G, _lib.stream_ptr(dev))
         _lib.check(rc, "umr_project_faces_forward")
         ctx.save_for_backward(v, c, faces_idx)
         ctx.want_pre = want_pre
@@ -221,17 +232,21 @@ class ProjectFacesFunction(Function):
         L = _lib.lib()
         v, c, faces_idx = ctx.saved_tensors
         dev = v.device
-        N, V = v.shape[:2]
+        M, V = v.shape[:2]
+        N = c.shape[0]
+        G = N // M
         F = faces_idx.shape[1]
         g_out = g_out.to(torch.float32).contiguous()
         g_pre = g_pre.to(torch.float32).contiguous() if (ctx.want_pre and g_pre is not None) else None
-        grad_verts = torch.zeros_like(v) if ctx.needs_input_grad[0] else None
+        grad_verts = torch.zeros(N, V, 3, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         grad_cams = torch.empty_like(c)
         ws_bytes = L.umr_project_workspace_bytes(N, V)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         rc = L.umr_project_faces_backward(ptr(g_out), ptr(g_pre), ptr(v), ptr(c), ptr(faces_idx), ptr(grad_verts),
-                                          ptr(grad_cams), N, V, F, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+                                          ptr(grad_cams), N, V, F, G, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "umr_project_faces_backward")
+        if grad_verts is not None and G > 1:
+            grad_verts = grad_verts.view(M, G, V, 3).sum(1)      # what autograd does for the reference's repeat
         return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None, None, None
 
 

@@ -75,10 +75,10 @@ class MultiMaskLoss(nn.Module):
     def forward(self, vs, fs, cams_all_hypo, cam_probs, masks_gt):
         bs = vs.size(0)
         K = self.num_hypo_cams
-        pred_vs = vs.unsqueeze(1).repeat(1, K, 1, 1).view(-1, vs.size(1), 3)
-        faces = fs.unsqueeze(1).repeat(1, K, 1, 1).view(-1, fs.size(1), 3)
+        # the reference materialises vs / fs K times (:260-262); here the K hypotheses of image b are views
+        # b*K .. b*K+K-1 of mesh b (mesh_group indexing in the projection kernel), gradients summed over them
         cams_all_hypo_flat = cams_all_hypo.view(-1, 7)
-        pred, _, _ = self.renderer.forward(pred_vs, faces, cams_all_hypo_flat)
+        pred, _, _ = self.renderer.forward(vs, fs, cams_all_hypo_flat)
         mask_all_hypo = pred[:, 3, :, :]
         masks = masks_gt.unsqueeze(1).repeat(1, K, 1, 1).view(-1, self.image_size, self.image_size)
         loss = neg_iou_loss(mask_all_hypo, masks, avg=False)
@@ -212,11 +212,10 @@ class MultiTextureLoss(nn.Module):
     def forward(self, vs, fs, cams_all_hypo, cam_probs, proj_cam, rgbs, masks_gt, masks_pred, tx, tex_flow,
                 dts_barrier):
         bs, K = vs.size(0), self.num_hypo_cams
-        pred_vs = vs.unsqueeze(1).repeat(1, K, 1, 1).view(-1, vs.size(1), 3)
-        faces = fs.unsqueeze(1).repeat(1, K, 1, 1).view(-1, fs.size(1), 3)
-        tex = tx.unsqueeze(1).repeat(1, K, 1, 1, 1).view(-1, tx.size(1), tx.size(2), 3)
+        # :303-306 repeats vertices, faces and the [B,F,36,3] texels K times (70 MB at B*K = 128); folded into
+        # mesh / texture group indexing of the kernels instead
         cams_all_hypo_flat = cams_all_hypo.view(-1, 7)
-        texture_rgba, _, _ = self.renderer.forward(pred_vs.detach(), faces, cams_all_hypo_flat, tex)
+        texture_rgba, _, _ = self.renderer.forward(vs.detach(), fs, cams_all_hypo_flat, tx)
         texture_pred = texture_rgba[:, 0:3, :, :]
         imgs = rgbs.unsqueeze(1).repeat(1, K, 1, 1, 1).view(-1, 3, self.image_size, self.image_size)
         masks_gt = masks_gt.unsqueeze(1).repeat(1, K, 1, 1).view(-1, self.image_size, self.image_size)

@@ -68,31 +68,37 @@ class SoftRenderer(torch.nn.Module):
 
     def forward(self, vertices, faces, cams, textures=None):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
-        textures None | [N,F,TS,3]."""
+        textures None | [N,F,TS,3].
+        K camera hypotheses per mesh without the reference's x K repeats (loss_utils.py:260-262, 303-306): pass
+        vertices / faces as [N/K,...] and / or textures as [N/K,F,TS,3] with cams [N,7] ordered mesh-major
+        (view n = mesh n // K); outputs are per view, gradients come back summed over the K views."""
         faces = faces.int().contiguous()                                  # smr.py:81
+        N = cams.shape[0]
         if self.ids_only and self.render_type == 'hard':
             with torch.no_grad():
                 _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
                 size = self.img_size * (2 if self.anti_aliasing else 1)
                 aggr = UF.visibility(face_out, size, self.near, self.far, True, self.eps, self.sigma_val, self.dist_eps,
                                      self.gamma_val)
-            return None, aggr.new_zeros(faces.shape[0], faces.shape[1], 2), aggr   # hard p2f is identically 0
+            return None, aggr.new_zeros(N, faces.shape[1], 2), aggr                # hard p2f is identically 0
         if self.alpha_only:
             _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
             size = self.img_size * (2 if self.anti_aliasing else 1)
             alpha = UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
                                                 self.dist_eps, self.gamma_val, self.anti_aliasing)
-            N, S = alpha.shape[0], alpha.shape[1]
+            S = alpha.shape[1]
             bg = alpha.new_tensor(self.background_color).view(1, 3, 1, 1).expand(N, 3, S, S)
             imgs = torch.cat([bg, alpha.unsqueeze(1)], dim=1)
             return imgs, alpha.new_zeros(N, faces.shape[1], 2), None
         directional = self.light_intensity_directional != 0
         face_pre, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z,
                                                            directional)
-        N, F = faces.shape[:2]
+        F = faces.shape[1]
         if textures is None:                                              # mesh.py:46-50
-            textures = torch.ones(N, F, 1, 3, dtype=torch.float32, device=vertices.device)
+            textures = torch.ones(1 if not directional else N, F, 1, 3, dtype=torch.float32, device=vertices.device)
         if directional:
+            if textures.shape[0] != N:                                    # per-view lighting needs per-view texels
+                textures = textures.repeat_interleave(N // textures.shape[0], dim=0)
             textures = textures * self._light(face_pre)[:, :, None, :]
         elif self.light_intensity_ambient != 1 or any(c != 1 for c in self.light_color):
             textures = textures * (self.light_intensity_ambient * textures.new_tensor(self.light_color))
