@@ -788,7 +788,9 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
         atomicAdd(&my_tex[tix * 3 + 2], c);
     }
 }
-template <int RGB, bool NEED_GF, bool NEED_GT>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
+template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
+// COMMON = the production case (gradient arrives 2x2-pooled, power-of-two image, double-sided faces) as compile-time
+// facts: the wave-uniform flags otherwise live as 64-bit lane masks in SGPRs that spill (v_readlane per visit)
 #ifndef BWD_WPE
 #define BWD_WPE 7
 #endif
@@ -797,6 +799,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
     const int F = A.F, IS = A.IS, TS = A.TS;
+    const bool pooled = COMMON ? true : (A.grad_pooled != 0);
+    const bool two_sided = COMMON ? true : (A.double_side != 0);
     // XCD-aware: hardware XCD = blockIdx % 8.  Each XCD owns a fixed contiguous EIGHTH of every mesh's faces
     // (index-neighbouring faces of a subdivided mesh are spatial neighbours), so the per-pixel state its waves
     // re-read (~6x) covers 1/8 of the screen and stays in that XCD's 4 MB L2, and all 8 XCDs share every mesh
@@ -815,11 +819,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     // wave-uniform bases of this mesh's per-pixel planes; every per-pixel load below is base + 32-bit byte offset
     const int H2 = IS >> 1;
     const unsigned pst = (unsigned)(npix * sizeof(float));                      // plane stride in bytes
-    const unsigned gps = A.grad_pooled ? (unsigned)((size_t)H2 * H2 * sizeof(float)) : pst;
+    const unsigned gps = pooled ? (unsigned)((size_t)H2 * H2 * sizeof(float)) : pst;
     const int cplanes = RGB == 2 ? 1 : 4;
     const char *sc_n = (const char *)(A.soft_colors + (size_t)n * cplanes * npix);
     const char *ag_n = (const char *)(A.aggrs + (size_t)n * 2 * npix);
-    const char *gc_n = (const char *)(A.grad_colors + (size_t)n * cplanes * (A.grad_pooled ? (size_t)H2 * H2 : npix));
+    const char *gc_n = (const char *)(A.grad_colors + (size_t)n * cplanes * (pooled ? (size_t)H2 * H2 : npix));
     float *wave_tex = s_tex + (size_t)wave * FM_TEXCOPY * FM_TEX_STRIDE(TS);
     // this lane's copy: horizontally and vertically adjacent pixels of a 4x4 / 8x8 tile get different copies
     float *my_tex = wave_tex + ((lane ^ (lane >> 2) ^ (lane >> 4)) & (FM_TEXCOPY - 1)) * FM_TEX_STRIDE(TS);
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
             // needed sub-tile of this face.  4x4 sub-tiles fill 74 % of their lanes with contributing pixels against
             // 54 % for one 8x8 tile (CPU simulation of the culling, 1280-face sphere at IS = 512).
             const int tx0 = x0 / FM_TW, tx1 = x1 / FM_TW, ty0 = r0 / FM_TH, ty1 = r1 / FM_TH;
-            const bool pow2 = (IS & (IS - 1)) == 0;
+            const bool pow2 = COMMON ? true : ((IS & (IS - 1)) == 0);
             const float inv_is = 1.f / (float)IS;
             const int ntx = tx1 - tx0 + 1, ntiles = ntx * (ty1 - ty0 + 1);
             const float4 i0 = make_float4(fc.g<R_INV + 0>(), fc.g<R_INV + 1>(), fc.g<R_INV + 2>(), fc.g<R_INV + 3>());
@@ -896,7 +900,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                     const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
                     const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
                     const unsigned pn4 = (unsigned)(row * IS + xi) * 4u;                       // byte offset in a full plane
-                    const unsigned gp4 = A.grad_pooled ? (unsigned)((row >> 1) * H2 + (xi >> 1)) * 4u : pn4;
+                    const unsigned gp4 = pooled ? (unsigned)((row >> 1) * H2 + (xi >> 1)) * 4u : pn4;
                     // Exact tile skips from the saved forward state, before any geometry:
                     //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
                     //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             const float zq = clip_depth(u0, u1, u2, p, fc);
                             if (zq < A.near_ || zq > A.far_) continue;  // :592
                         }
-                        const float ga = (A.grad_pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
+                        const float ga = (pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
                         const float oa = ld_u(sc_n, pn4);
                         float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
                         c_a *= p.frag * (1.f - p.frag) * (-A.nis);
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                         gv[6] += a2 * p.dx; gv[7] += a2 * p.dy;
                         continue;
                     }
-                    const float gscale = A.grad_pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
+                    const float gscale = pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
                     const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
                                 g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
                     const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             if (TS == 1) { gt0 += g0; gt1 += g1; gt2 += g2; }
                             else texel_accumulate(my_tex, tix, g0, g1, g2, lane);
                         }
-                    } else if (fc.front() || A.double_side) {
+                    } else if (two_sided || fc.front()) {
                         const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
                         const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
                         const int tix = texel_index(q0, q1, A.R);
@@ -1014,14 +1018,20 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     }
 }
 
-template <int RGB>
-void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
+template <int RGB, bool COMMON>
+void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
     const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
     const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
-    if (RGB == 2) k_raster_backward_fm<2, true, false><<<blocks, FM_WAVES * 64, 0, st>>>(A);
-    else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
-    else if (A.need_gf) k_raster_backward_fm<RGB, true, false><<<blocks, FM_WAVES * 64, lds, st>>>(A);
-    else k_raster_backward_fm<RGB, false, true><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    if (RGB == 2) k_raster_backward_fm<2, true, false, COMMON><<<blocks, FM_WAVES * 64, 0, st>>>(A);
+    else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else if (A.need_gf) k_raster_backward_fm<RGB, true, false, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else k_raster_backward_fm<RGB, false, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+}
+template <int RGB>
+void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
+    const bool common = A.grad_pooled && A.double_side && (A.IS & (A.IS - 1)) == 0;
+    if (common) launch_backward_fm2<RGB, true>(A, st);
+    else launch_backward_fm2<RGB, false>(A, st);
 }
 
 bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int TS, int *R) {
