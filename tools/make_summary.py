@@ -73,9 +73,9 @@ L.append("Full step (`profiles/%s_bench_full.json`): **%.0f images/s**, %.2f ms/
             (rf["traffic"] or 0) / 1e6, rf["alg_bytes_per_launch"] / 1e6, full["cpu_baseline"]["value"], full["cpu_baseline"]["cores"]))
 L.append("Hot path only, `--model 0` (`profiles/%s_bench_hotpath_only.json`): **%.0f images/s**, %.2f ms/step.\n" % (tag, hot["value"], hot["ms_per_step"]))
 L.append("train_s2 sequence, `--workload s2` (`profiles/%s_bench_s2.json`, 10 steps): %.0f images/s, %.1f ms/step.\n" % (tag, s2["value"], s2["ms_per_step"]))
-bk = [r for r in ours if "k_raster_backward_fm<1, false, true>" in r["Name"]]
+bk = [r for r in ours if "k_raster_backward_fm<1, false, true" in r["Name"]]
 if bk:
-    L.append("HIP-event average vs rocprofv3 average for `k_raster_backward_fm<1, false, true>`: %.1f us vs %.1f us.\n"
+    L.append("HIP-event average vs rocprofv3 average for `k_raster_backward_fm<1, false, true, ...>`: %.1f us vs %.1f us.\n"
              % (rf["avg_us"], float(bk[0]["AverageNs"]) / 1e3))
 L.append("## HBM traffic (PMC, `tools/collect_traffic.sh`, separate FETCH_SIZE / WRITE_SIZE passes)\n")
 c = tr["calibration"]

@@ -409,7 +409,7 @@ __device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int RGB>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
+template <int RGB, bool P2F, bool TWO_SIDED>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
                     // 2 = silhouette only: alpha plane, no depth / colour / p2f (soft_colors is then [N,IS,IS]),
                     // 3 = visibility only: the hard z-buffer's (depth, face id) planes, nothing else
 // Register budget for 7 waves per SIMD: the default allocation (106 SGPRs) admits 6; the kernels are VALU-issue bound
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
         }
         if (RGB == 1) {
             c0 *= ssum; c1 *= ssum; c2 *= ssum;
-            if (A.with_p2f) { gx = A.grid[pn * 2]; gy = A.grid[pn * 2 + 1]; }
+            if (P2F) { gx = A.grid[pn * 2]; gy = A.grid[pn * 2 + 1]; }
         }
     }
 
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     const bool incl = (w0 <= 1) & (w0 >= 0) & (w1 <= 1) & (w1 >= 0) & (w2 <= 1) & (w2 >= 0);
                     const bool strict = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
                     const bool cand = inb & incl & t.valid & (strict | (w0 <= 0) | (w1 <= 0) | (w2 <= 0)) &
-                                      (A.double_side | fc.front());
+                                      (TWO_SIDED | fc.front());
                     if (__any(cand)) {
                         Pair pw; pw.w0 = w0; pw.w1 = w1; pw.w2 = w2;
                         float q0, q1, q2;
@@ -506,14 +506,14 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     if (!(zp < A.near_ || zp > A.far_)) {
                         if (RGB == 0) {
                             const bool inside = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
-                            if (zp < depth_min && inside && (A.double_side || fc.front())) {
+                            if (zp < depth_min && inside && (TWO_SIDED || fc.front())) {
                                 depth_min = zp;
                                 face_min = f;
                                 const char *tf = (const char *)(tex_n + (size_t)f * A.TS * 3);   // uniform per face
                                 const unsigned t12 = (unsigned)texel_index(q0, q1, A.R) * 12u;
                                 c0 = ld_u(tf, t12); c1 = ld_u(tf, t12 + 4); c2 = ld_u(tf, t12 + 8);
                             }
-                        } else if (fc.front() || A.double_side) {
+                        } else if (TWO_SIDED || fc.front()) {
                             const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
                             float rescale = 1.f;
                             if (zn > smax) {
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                         }
                     }
                 }
-                if (RGB == 1 && A.with_p2f) {  // :427-430, reduced over the 8x8 tile first
+                if (RGB == 1 && P2F) {  // :427-430, reduced over the 8x8 tile first
                     if (__any(wgt != 0.f)) {
                         const float sx = wave_sum_full(wgt * gx), sy = wave_sum_full(wgt * gy), sw = wave_sum_full(wgt);
                         if (t.lane < 4) {
@@ -1156,10 +1156,22 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                      alpha_only ? (double)N * (4.0 * image_size * image_size + 36.0 * F)
                      : ids_only ? (double)N * (8.0 * image_size * image_size + 36.0 * F)
                                 : (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
-        if (ids_only) k_raster_forward<3><<<blocks, BLK_THREADS, 0, st>>>(A);
-        else if (alpha_only) k_raster_forward<2><<<blocks, BLK_THREADS, 0, st>>>(A);
-        else if (func_id_rgb == 0) k_raster_forward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
-        else k_raster_forward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+        // p2f accumulation and face culling are compile-time: as run-time flags they cost SGPRs in every variant
+        if (ids_only) {
+            if (double_side) k_raster_forward<3, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+            else k_raster_forward<3, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else if (alpha_only) {
+            k_raster_forward<2, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);   // alpha does not look at the side
+        } else if (func_id_rgb == 0) {
+            if (double_side) k_raster_forward<0, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+            else k_raster_forward<0, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else if (with_p2f) {
+            if (double_side) k_raster_forward<1, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+            else k_raster_forward<1, true, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else {
+            if (double_side) k_raster_forward<1, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+            else k_raster_forward<1, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+        }
     }
     return umr_launch_status();
 }
