@@ -74,7 +74,17 @@ L.append("Full step (`profiles/%s_bench_full.json`): **%.0f images/s**, %.2f ms/
 L.append("Hot path only, `--model 0` (`profiles/%s_bench_hotpath_only.json`): **%.0f images/s**, %.2f ms/step.\n" % (tag, hot["value"], hot["ms_per_step"]))
 L.append("train_s2 sequence, `--workload s2` (`profiles/%s_bench_s2.json`, 10 steps): %.0f images/s, %.1f ms/step.\n" % (tag, s2["value"], s2["ms_per_step"]))
 bk = [r for r in ours if "k_raster_backward_fm<1, false, true" in r["Name"]]
-if bk:
+tsum = os.path.join(SRC, "raster_trace_summary.json")
+if os.path.exists(tsum):
+    shutil.copyfile(tsum, os.path.join(P, tag + "_raster_trace_summary.json"))
+    tj = json.load(open(tsum))
+    kk = [k for k in tj if "k_raster_backward_fm<1, false, true" in k]
+    if kk:
+        L.append("HIP-event average (timed steps, un-profiled run) vs rocprofv3 for `%s`: %.1f us vs %.1f us over the same "
+                 "last 10 steps of the profiled run (%.1f us over all 15 incl. warm-up, when the untrained network's "
+                 "geometry differs); `profiles/%s_raster_trace_summary.json`.\n"
+                 % (kk[0].split("(")[0], rf["avg_us"], tj[kk[0]]["avg_us_last10steps"], tj[kk[0]]["avg_us_all"], tag))
+elif bk:
     L.append("HIP-event average vs rocprofv3 average for `k_raster_backward_fm<1, false, true, ...>`: %.1f us vs %.1f us.\n"
              % (rf["avg_us"], float(bk[0]["AverageNs"]) / 1e3))
 L.append("## HBM traffic (PMC, `tools/collect_traffic.sh`, separate FETCH_SIZE / WRITE_SIZE passes)\n")

@@ -16,5 +16,23 @@ python tools/microbench.py --alpha >> "$O/microbench.log" 2>&1
 python tools/sweep_fm.py kernel_only > "$O/kernel_only.log" 2>&1
 tools/pmc_raster.sh "$O/pmc_ts36" 64 3 512 36 > "$O/pmc_ts36.log" 2>&1
 tools/pmc_raster.sh "$O/pmc_ts1" 64 3 512 1 > "$O/pmc_ts1.log" 2>&1
+python - "$O" <<'PY'
+import csv, glob, json, sys, collections
+# per raster kernel: rocprofv3 duration averaged over the LAST 10 dispatches (= the timed steps of the stats run)
+out = sys.argv[1]
+d = collections.defaultdict(list)
+for fn in glob.glob(out + "/stats/*kernel_trace.csv"):
+    for r in csv.DictReader(open(fn)):
+        if "k_raster" in r["Kernel_Name"]:
+            d[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+rep = {}
+for k, v in d.items():
+    v.sort()
+    per_step = max(1, len(v) // 15)
+    last = [x[1] for x in v[-10 * per_step:]]
+    rep[k.replace("(anonymous namespace)::", "")] = {"dispatches": len(v), "avg_us_all": sum(x[1] for x in v) / len(v) / 1e3,
+                                                      "avg_us_last10steps": sum(last) / len(last) / 1e3}
+json.dump(rep, open(out + "/raster_trace_summary.json", "w"), indent=1)
+PY
 find "$O" -name "*.csv" -size +3M -delete      # keep the merged-back payload small (per-dispatch traces)
 ls -la "$O"
