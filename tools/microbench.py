@@ -1,7 +1,6 @@
 """Kernel micro-benchmark (GPU box): times umr_raster_forward/backward with HIP events at the shapes of
 SURVEY.md section 8d and prints algorithmic GB/s per kernel."""
 import json
-import math
 import sys
 
 import torch

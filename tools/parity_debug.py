@@ -1,7 +1,6 @@
 """Debug aid (GPU box): where does the HIP forward differ from a raster golden?"""
 import os, sys
 import numpy as np
-import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_golden

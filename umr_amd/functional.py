@@ -4,7 +4,6 @@ PyTorch is plumbing here: device memory (caching allocator), the current HIP str
 bookkeeping.  All arithmetic happens in libumr_hip.so; there is no CPU or eager-torch fallback.
 """
 import ctypes
-import os
 import math
 
 import torch

@@ -1,6 +1,5 @@
 """Geometry helpers with the reference's names and argument meaning (nnutils/geom_utils.py),
 backed by HIP kernels (umr_amd/csrc/geometry.hip, losses.hip)."""
-import torch
 
 from . import functional as UF
 

@@ -12,7 +12,6 @@ torchvision is not available here, so the ResNet-18 trunk (cub_mesh.py:53-74) is
 with random initialisation (the pretrained weights are not obtainable offline).  Parameter shapes follow the
 reference, so the gradient all-reduce volume (~85 M fp32) is the reference's.
 """
-import math
 from types import SimpleNamespace
 
 import numpy as np

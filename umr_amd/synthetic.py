@@ -1,6 +1,5 @@
 """Seeded synthetic inputs of the CUB-shaped workload: the dataset, SCOPS maps and
 pretrained weights of the reference are not distributed, so benchmarks and step-level tests use these."""
-import numpy as np
 import torch
 
 from .mesh import create_sphere
