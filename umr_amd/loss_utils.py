@@ -5,7 +5,6 @@ import torch
 import torch.nn as nn
 
 from . import functional as UF
-from . import geom_utils
 from .chamfer_python import distChamfer
 from .smr import SoftRenderer
 
