@@ -171,7 +171,7 @@ def main():
                                % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
                                   "; MeshNet fwd/bwd + RCCL all-reduce + Adam" if use_model else "; network excluded"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "includes_network": use_model,
-                   "final_loss": float(loss)},
+                   "final_loss": float(loss.detach())},
         "roofline": {"bound": "hbm", "kernel": "k_raster_backward", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "launches": b_n, "avg_us": (1e3 * b_ms / b_n) if b_n else None,

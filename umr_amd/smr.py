@@ -53,15 +53,25 @@ class SoftRenderer(torch.nn.Module):
         """smr.py:76-78 -> [N,V,2]."""
         return UF.ProjectPointsFunction.apply(verts, cams, 2, 0.0)
 
+    def _const(self, ref, values):
+        """Small device constant (light colour / direction, background), uploaded once per (device, value): building
+        it from a Python list on every call is a pageable host-to-device copy that synchronises the stream and cannot
+        be captured in a HIP graph."""
+        key = (ref.device, tuple(float(v) for v in values))
+        cache = self.__dict__.setdefault("_const_cache", {})
+        if key not in cache:
+            cache[key] = torch.tensor(key[1], dtype=torch.float32, device=ref.device)
+        return cache[key]
+
     def _light(self, face_pre):
         """lighting.py:50-57 (surface mode): ambient + directional * relu(n.d) per face -> [N,F,3]."""
-        col = face_pre.new_tensor(self.light_color)[None, None, :]
+        col = self._const(face_pre, self.light_color)[None, None, :]
         light = self.light_intensity_ambient * col
         if self.light_intensity_directional != 0:
             v10 = face_pre[:, :, 0] - face_pre[:, :, 1]
             v12 = face_pre[:, :, 2] - face_pre[:, :, 1]
             n = torch.nn.functional.normalize(torch.cross(v12, v10, dim=2), p=2, dim=2, eps=1e-6)
-            d = face_pre.new_tensor(self.light_direction)[None, None, :]
+            d = self._const(face_pre, self.light_direction)[None, None, :]
             cosine = torch.relu(torch.sum(n * d, dim=2))
             light = light + self.light_intensity_directional * (col * cosine[:, :, None])
         return light
@@ -87,7 +97,7 @@ class SoftRenderer(torch.nn.Module):
             alpha = UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
                                                 self.dist_eps, self.gamma_val, self.anti_aliasing)
             S = alpha.shape[1]
-            bg = alpha.new_tensor(self.background_color).view(1, 3, 1, 1).expand(N, 3, S, S)
+            bg = self._const(alpha, self.background_color).view(1, 3, 1, 1).expand(N, 3, S, S)
             imgs = torch.cat([bg, alpha.unsqueeze(1)], dim=1)
             return imgs, alpha.new_zeros(N, faces.shape[1], 2), None
         directional = self.light_intensity_directional != 0
@@ -101,7 +111,7 @@ class SoftRenderer(torch.nn.Module):
                 textures = textures.repeat_interleave(N // textures.shape[0], dim=0)
             textures = textures * self._light(face_pre)[:, :, None, :]
         elif self.light_intensity_ambient != 1 or any(c != 1 for c in self.light_color):
-            textures = textures * (self.light_intensity_ambient * textures.new_tensor(self.light_color))
+            textures = textures * (self.light_intensity_ambient * self._const(textures, self.light_color))
         size = self.img_size * (2 if self.anti_aliasing else 1)          # rasterizer.py:43
         return UF.soft_rasterize(face_out, textures, size, self.background_color, self.near, self.far, True,
                                  self.eps, self.sigma_val, 'euclidean', self.dist_eps, self.gamma_val,
