@@ -414,10 +414,8 @@ template <int RGB, bool P2F, bool TWO_SIDED>  // 0 = hard z-buffer colour (:408-
                     // 3 = visibility only: the hard z-buffer's (depth, face id) planes, nothing else
 // Register budget for 7 waves per SIMD: the default allocation (106 SGPRs) admits 6; the kernels are VALU-issue bound
 // with every wave stalled ~50 % of its life, so the seventh wave pays (measured: 5 < 6 < 7 ~ 8 waves, -3..6 % time).
-#ifndef FWD_WPE
-#define FWD_WPE 7
-#endif
-#define FWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(FWD_WPE, FWD_WPE)))
+// (the forward variants without p2f accumulators fit 8 waves and gain another 2-5 %; with p2f 8 is slower)
+#define FWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(P2F ? 7 : 8, P2F ? 7 : 8)))
 __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(const RasterArgs A) {
     __shared__ int s_list[LIST_CAP];
     __shared__ int s_wcnt[BLK_THREADS / 64];
@@ -885,14 +883,15 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             if (sub == qq) mine = e;
                         }
                     }
-#if FM_RELOAD_PER_TILE
-                    {   // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
-                        // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop (which cost 2 waves/SIMD)
+                    if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2) {
+                        // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
+                        // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop.  Only for the variants that
+                        // also carry the 9 vertex-gradient accumulators and the colour path (measured 4-6 % faster with
+                        // the re-fetch there, 1-5 % slower for the texel-only and silhouette kernels)
                         const float *rp = A.rec + ((size_t)n * F + f) * REC;
                         asm volatile("" : "+s"(rp));
                         load_face(fc, rp);
                     }
-#endif
                     if (mine < 0) continue;
                     const int row = (mine >> 16) * FM_TH + sl / FM_TW;
                     const int xi = (mine & 0xffff) * FM_TW + sl % FM_TW;
