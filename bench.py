@@ -131,6 +131,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step_fn()
+    host_dt = time.perf_counter() - t0          # time to ENQUEUE the steps (host side); dt below includes the drain
     barrier()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
@@ -171,6 +172,7 @@ def main():
                                % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
                                   "; MeshNet fwd/bwd + RCCL all-reduce + Adam" if use_model else "; network excluded"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "includes_network": use_model,
+                   "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
                    "final_loss": float(loss.detach())},
         "roofline": {"bound": "hbm", "kernel": "k_raster_backward", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -85,15 +85,19 @@ def ptr(t):
 
 
 def stream_ptr(device=None):
-    """Current HIP stream of `device`.  Kernels are launched in the CURRENT device context (as the reference's
-    were: no device guard), so a tensor on another GPU is rejected here instead of
-    faulting inside the launch -- one process per GPU calls torch.cuda.set_device(local_rank) once."""
-    if device is not None:
-        idx = torch.device(device).index
-        if idx is not None and idx != torch.cuda.current_device():
-            raise RuntimeError("umr_amd: tensors live on cuda:%d but the current device is cuda:%d; call "
-                               "torch.cuda.set_device first" % (idx, torch.cuda.current_device()))
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw handle of the current HIP stream of `device`.  Kernels are launched in the CURRENT device context (as the
+    reference's were: no device guard), so a tensor on another GPU is rejected here
+    instead of faulting inside the launch -- one process per GPU calls torch.cuda.set_device(local_rank) once.
+    Uses torch's C accessors: torch.cuda.current_stream() costs ~8 us of Python per call, and the render-and-compare
+    path makes ~30 C-ABI calls per step."""
+    cur = torch._C._cuda_getDevice()
+    idx = cur if device is None else torch.device(device).index
+    if idx is None:
+        idx = cur
+    if idx != cur:
+        raise RuntimeError("umr_amd: tensors live on cuda:%d but the current device is cuda:%d; call "
+                           "torch.cuda.set_device first" % (idx, cur))
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 _TRACE = bool(os.environ.get("UMR_TRACE_SYNC"))   # debugging aid: name every C-ABI call and synchronise after it
