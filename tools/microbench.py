@@ -21,7 +21,7 @@ def bench(N, subdiv, IS, TS, rgb="softmax", iters=10, need_gf=True, need_gt=True
     H = IS // 2 if pool else IS
     g = torch.randn(N, 4, H, H, device=dev)
     args = (IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, rgb, 'prod', 'surface', pool, need_p2f)
-    tf = tb = 0.0
+    tfs, tbs = [], []
     for it in range(iters + 2):
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         fv.grad = None; tex.grad = None
@@ -33,8 +33,9 @@ def bench(N, subdiv, IS, TS, rgb="softmax", iters=10, need_gf=True, need_gt=True
         e2.record()
         torch.cuda.synchronize()
         if it >= 2:
-            tf += e0.elapsed_time(e1); tb += e1.elapsed_time(e2)
-    tf /= iters; tb /= iters
+            tfs.append(e0.elapsed_time(e1)); tbs.append(e1.elapsed_time(e2))
+    tf, tb = sorted(tfs)[len(tfs) // 2], sorted(tbs)[len(tbs) // 2]   # median: an allocator growth inside one iteration
+                                                                       # (hipMalloc) would otherwise skew the mean
     fwd_bytes = N * (24 * IS * IS + F * (36 + 12 * TS + 16))
     bwd_bytes = N * (40 * IS * IS + F * (180 + 24 * TS))
     return dict(N=N, F=F, IS=IS, TS=TS, rgb=rgb, pool=pool, fwd_ms=round(tf, 4), bwd_ms=round(tb, 4),
@@ -59,7 +60,7 @@ def bench_alpha(N, subdiv, IS, iters=10, pool=True):
     fv = fv.detach().requires_grad_(True)
     H = IS // 2 if pool else IS
     g = torch.randn(N, H, H, device=dev)
-    tf = tb = 0.0
+    tfs, tbs = [], []
     for it in range(iters + 2):
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         fv.grad = None
@@ -70,8 +71,9 @@ def bench_alpha(N, subdiv, IS, iters=10, pool=True):
         e2.record()
         torch.cuda.synchronize()
         if it >= 2:
-            tf += e0.elapsed_time(e1); tb += e1.elapsed_time(e2)
-    return dict(kind="alpha_only", N=N, IS=IS, fwd_us_per_mesh=round(tf / iters * 1e3 / N, 2), bwd_us_per_mesh=round(tb / iters * 1e3 / N, 2))
+            tfs.append(e0.elapsed_time(e1)); tbs.append(e1.elapsed_time(e2))
+    tf, tb = sorted(tfs)[len(tfs) // 2], sorted(tbs)[len(tbs) // 2]
+    return dict(kind="alpha_only", N=N, IS=IS, fwd_us_per_mesh=round(tf * 1e3 / N, 2), bwd_us_per_mesh=round(tb * 1e3 / N, 2))
 
 
 if __name__ == "__main__" and "--alpha" in sys.argv:
