@@ -147,6 +147,12 @@ int umr_project_faces_backward(const float *grad_face_out, const float *grad_fac
                                int N, int V, int F, int mesh_group, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* Camera rotated about the y axis by angle_deg [B] degrees: geom_utils.rotate_cam(cam, angle, axis=[0,1,0])
+ * (nnutils/geom_utils.py:167-193, a per-sample numpy / cv2.Rodrigues / quaternion_from_matrix round trip through the
+ * host in the reference; call sites experiments/train_s1.py:233, train_s2.py:257).  cam, out [B,7]; forward only
+ * (both call sites detach the camera).  out = [s, tx, ty, q'] with q' = q_y(angle) (x) q, unit norm, q'_w >= 0. */
+int umr_rotate_cam_y(const float *cam, const float *angle_deg, float *out, int B, void *stream);
+
 /* vertices only, no flip, no look_at:
  *   out_dim 2: SoftRenderer.project_points / orthographic_proj (nnutils/smr.py:76-78, geom_utils.py:60-72)
  *              out [N,V,2] = (s R(q) X)[:2] + t

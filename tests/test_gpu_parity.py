@@ -658,3 +658,23 @@ def test_camera_hypothesis_groups_equal_explicit_repeats():
             assert np.abs(g[4] - e[4]).max() <= 1e-5 * max(np.abs(e[4]).max(), 1e-12), kind
     with pytest.raises(RuntimeError):
         SoftRenderer(32, "softmax")(verts.to(DEV), faces.to(DEV), cams[:5].to(DEV), tex.to(DEV))   # 5 views, 2 meshes
+
+
+def test_rotate_cam_y_kernel_vs_quaternion_product():
+    """umr_rotate_cam_y against the torch formulation it replaces (q_y(angle) (x) q, renormalised, w >= 0)."""
+    import math
+    from umr_amd.train_step import rotate_cam_y
+    gen = torch.Generator().manual_seed(9)
+    cam = torch.cat([torch.rand(33, 3, generator=gen), torch.nn.functional.normalize(torch.randn(33, 4, generator=gen), dim=1)], 1)
+    ang = (torch.rand(33, generator=gen) * 720 - 360)
+    half = ang * (math.pi / 360.0)
+    rw, ry = torch.cos(half), torch.sin(half)
+    qw, qx, qy, qz = cam[:, 3], cam[:, 4], cam[:, 5], cam[:, 6]
+    q = torch.stack([rw * qw - ry * qy, rw * qx + ry * qz, rw * qy + ry * qw, rw * qz - ry * qx], 1)
+    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    q = torch.where(q[:, :1] < 0, -q, q)
+    want = torch.cat([cam[:, :3], q], 1)
+    got = rotate_cam_y(cam.to(DEV), ang.to(DEV)).cpu()
+    assert torch.allclose(got, want, atol=2e-6), (got - want).abs().max()
+    with pytest.raises(RuntimeError):
+        rotate_cam_y(cam.to(DEV).requires_grad_(True), ang.to(DEV))

@@ -27,6 +27,7 @@ SIGNATURES = {
     "umr_project_faces_forward": ([_P] * 5 + [_I, _I, _I, _F, _F, _I, _P], _I),
     "umr_project_workspace_bytes": ([_I, _I], _Z),
     "umr_project_faces_backward": ([_P] * 7 + [_I, _I, _I, _I, _P, _Z, _P], _I),
+    "umr_rotate_cam_y": ([_P, _P, _P, _I, _P], _I),
     "umr_project_points_forward": ([_P] * 3 + [_I, _I, _I, _F, _P], _I),
     "umr_project_points_backward": ([_P] * 5 + [_I, _I, _I, _P], _I),
     "umr_neg_iou_forward": ([_P, _L, _P, _P, _P, _I, _L, _P], _I),

@@ -79,6 +79,25 @@ __global__ void k_scatter_face_grads(const float *__restrict__ g_out, const floa
     atomicAdd(d, gx); atomicAdd(d + 1, gy); atomicAdd(d + 2, gz);
 }
 
+// geom_utils.rotate_cam (nnutils/geom_utils.py:167-193) for the y axis: new_q = q_y(angle) (x) q, renormalised, w >= 0
+// representative (what transformations.quaternion_from_matrix(isprecise=True) returns).  One thread per camera; the
+// torch formulation was ~20 elementwise launches for [B,7] values.
+__global__ void k_rotate_cam_y(const float *__restrict__ cam, const float *__restrict__ angle_deg,
+                               float *__restrict__ out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const float *c = cam + (size_t)i * 7;
+    const float half = angle_deg[i] * 0.008726646259971648f;   // pi / 360
+    const float rw = cosf(half), ry = sinf(half);
+    const float qw = c[3], qx = c[4], qy = c[5], qz = c[6];
+    float nw = rw * qw - ry * qy, nx = rw * qx + ry * qz, ny = rw * qy + ry * qw, nz = rw * qz - ry * qx;
+    const float nrm = fmaxf(sqrtf(nw * nw + nx * nx + ny * ny + nz * nz), 1e-12f);
+    nw /= nrm; nx /= nrm; ny /= nrm; nz /= nrm;
+    if (nw < 0.f) { nw = -nw; nx = -nx; ny = -ny; nz = -nz; }
+    float *o = out + (size_t)i * 7;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = nw; o[4] = nx; o[5] = ny; o[6] = nz;
+}
+
 // One block per mesh.  With M(q) = (w^2-|u|^2) I + 2 u u^T + 2 w [u]x  and  P = s M X + t:
 //   dL/dX = s M^T g,  dL/ds = sum g.(M X),  dL/dt = sum g_xy,
 //   dL/dw = 2 s sum [ w (g.X) + g.(u x X) ],
@@ -197,6 +216,12 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
         k_project_backward<2><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V, 1);
     else
         return UMR_ERR_ARG;
+    return umr_launch_status();
+}
+
+int umr_rotate_cam_y(const float *cam, const float *angle_deg, float *out, int B, void *stream) {
+    if (!cam || !angle_deg || !out || B <= 0) return UMR_ERR_ARG;
+    k_rotate_cam_y<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(cam, angle_deg, out, B);
     return umr_launch_status();
 }
 

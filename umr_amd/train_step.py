@@ -5,7 +5,6 @@ Mirrors `ShapenetTrainer.forward` of the reference from the point where the netw
 every render / sampling / reduction on the way is a HIP kernel (umr_amd/csrc).  Per image this is
 4 raster forwards (mask :199, texture :217, hard :223, GAN view :235) and 3 raster backwards.
 """
-import math
 
 import torch
 import torch.nn as nn
@@ -29,21 +28,31 @@ class S1Weights:
 
 def rotate_cam_y(cam, angle_deg):
     """geom_utils.rotate_cam (nnutils/geom_utils.py:167-193) for axis=[0,1,0] without the per-sample
-    numpy / cv2.Rodrigues / host round trip: new_q = q_y(angle) (x) q, on device.
-    cam [B,7] = [s,tx,ty,qw,qx,qy,qz]; angle_deg [B]."""
-    half = angle_deg.to(cam.dtype) * (math.pi / 360.0)
-    rw, ry = torch.cos(half), torch.sin(half)
-    qw, qx, qy, qz = cam[:, 3], cam[:, 4], cam[:, 5], cam[:, 6]
-    # (rw, 0, ry, 0) (x) (qw, qx, qy, qz)
-    nw = rw * qw - ry * qy
-    nx = rw * qx + ry * qz
-    ny = rw * qy + ry * qw
-    nz = rw * qz - ry * qx
-    q = torch.stack([nw, nx, ny, nz], 1)
-    # quaternion_from_matrix(isprecise=True) returns the w>=0 representative of a unit quaternion
-    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)
-    q = torch.where(q[:, :1] < 0, -q, q)
-    return torch.cat([cam[:, :3], q], 1)
+    numpy / cv2.Rodrigues / host round trip: new_q = q_y(angle) (x) q, renormalised, w >= 0 (one kernel,
+    umr_rotate_cam_y).  cam [B,7] = [s,tx,ty,qw,qx,qy,qz]; angle_deg [B].  Forward only: the reference rotates a
+    detached camera at both call sites (train_s1.py:233, train_s2.py:257)."""
+    if cam.requires_grad or angle_deg.requires_grad:
+        raise RuntimeError("rotate_cam_y is not differentiable; detach the camera (as the reference does)")
+    from . import _lib
+    c = cam.to(torch.float32).contiguous()
+    a = angle_deg.to(torch.float32).contiguous()
+    out = torch.empty_like(c)
+    _lib.check(_lib.lib().umr_rotate_cam_y(_lib.ptr(c), _lib.ptr(a), _lib.ptr(out), c.shape[0], _lib.stream_ptr(c.device)),
+               "umr_rotate_cam_y")
+    return out
+
+
+def weighted_total(module, terms, weights):
+    """sum_k weights[k] * terms[k] as ONE stack + ONE dot product (and their two backward kernels) instead of a
+    multiply and an add per term in each direction: the step's wall time equals its host enqueue time, so every
+    elementwise launch on scalars costs ~10 us of it.  `weights`: list of (name, python float); the weight vector is
+    uploaded once per device and cached on `module`."""
+    vals = torch.stack([terms[k].reshape(()) for k, _ in weights])
+    cache = module.__dict__.setdefault("_wvec_cache", {})
+    key = (vals.device, tuple(float(v) for _, v in weights))
+    if key not in cache:
+        cache[key] = torch.tensor(key[1], dtype=vals.dtype, device=vals.device)
+    return torch.dot(vals, cache[key])
 
 
 class RenderCompareS1(nn.Module):
@@ -118,10 +127,10 @@ class RenderCompareS1(nn.Module):
             terms["gan"] = nn.functional.binary_cross_entropy_with_logits(gan_preds.view(-1), labels)
         else:  # keep the render + its backward in the step even without a discriminator network
             terms["gan"] = pred_unseen[:, 3].mean()
-        total = terms["mask"] * w.mask_loss_wt + terms["triangle"] * w.triangle_reg_wt \
-            + terms["flatten"] * w.flatten_reg_wt + terms["ori"] * w.ori_reg_wt + terms["deform"] * w.deform_reg_wt \
-            + terms["tex"] * w.tex_loss_wt + terms["tex_dt"] * w.tex_dt_loss_wt \
-            + terms["tex_cycle"] * w.tex_cycle_loss_wt + terms["gan"] * w.gan_loss_wt
+        total = weighted_total(self, terms, [
+            ("mask", w.mask_loss_wt), ("triangle", w.triangle_reg_wt), ("flatten", w.flatten_reg_wt),
+            ("ori", w.ori_reg_wt), ("deform", w.deform_reg_wt), ("tex", w.tex_loss_wt), ("tex_dt", w.tex_dt_loss_wt),
+            ("tex_cycle", w.tex_cycle_loss_wt), ("gan", w.gan_loss_wt)])                              # train_s1.py:247-257
         return total, terms
 
 
@@ -206,8 +215,9 @@ class RenderCompareS2(nn.Module):
         corr = self.corr_loss_fn(rep(batch["head_points"]), rep(batch["belly_points"]), rep(batch["back_points"]),
                                  rep(batch["neck_points"]), rep(mean_shape), cams_all_hypo.reshape(-1, 7), avg=False)
         t["corr"] = (corr.view(B, K) * cam_probs.detach()).sum(dim=1).mean()                        # :313-314
-        total = t["mask"] * w.mask_loss_wt + t["triangle"] * w.triangle_reg_wt + t["flatten"] * w.flatten_reg_wt \
-            + t["deform"] * w.deform_reg_wt + t["tex"] * w.tex_loss_wt + t["tex_dt"] * w.tex_dt_loss_wt \
-            + t["tex_cycle"] * w.tex_cycle_loss_wt + t["gan"] * w.gan_loss_wt + t["cam_div"] * w.ent_loss_wt \
-            + t["part"] * w.prob_loss_wt + t["corr"] * w.vertex_loss_wt
+        total = weighted_total(self, t, [
+            ("mask", w.mask_loss_wt), ("triangle", w.triangle_reg_wt), ("flatten", w.flatten_reg_wt),
+            ("deform", w.deform_reg_wt), ("tex", w.tex_loss_wt), ("tex_dt", w.tex_dt_loss_wt),
+            ("tex_cycle", w.tex_cycle_loss_wt), ("gan", w.gan_loss_wt), ("cam_div", w.ent_loss_wt),
+            ("part", w.prob_loss_wt), ("corr", w.vertex_loss_wt)])                                    # train_s2.py:300-316
         return total, t
