@@ -42,6 +42,14 @@ def rotate_cam_y(cam, angle_deg):
     return out
 
 
+def gan_labels(module, B, device):
+    """[1]*B + [0]*B real/fake targets of the mask discriminator (train_s1.py:240-241), built once per (B, device)."""
+    cache = module.__dict__.setdefault("_label_cache", {})
+    if (B, device) not in cache:
+        cache[(B, device)] = torch.cat((torch.ones(B, device=device), torch.zeros(B, device=device)))
+    return cache[(B, device)]
+
+
 def weighted_total(module, terms, weights):
     """sum_k weights[k] * terms[k] as ONE stack + ONE dot product (and their two backward kernels) instead of a
     multiply and an add per term in each direction: the step's wall time equals its host enqueue time, so every
@@ -122,7 +130,7 @@ class RenderCompareS1(nn.Module):
         pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, random_cams)
         if self.discriminator is not None:
             pred = torch.cat((pred_seen.detach(), pred_unseen))
-            labels = torch.cat((torch.ones(B, device=pred.device), torch.zeros(B, device=pred.device)))
+            labels = gan_labels(self, B, pred.device)
             gan_preds = self.discriminator(pred[:, 3].unsqueeze(1))
             terms["gan"] = nn.functional.binary_cross_entropy_with_logits(gan_preds.view(-1), labels)
         else:  # keep the render + its backward in the step even without a discriminator network
@@ -202,7 +210,7 @@ class RenderCompareS2(nn.Module):
         pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, random_cams, tex.detach())            # :260
         if self.discriminator is not None:
             pred = torch.cat((batch["random_imgs"], pred_unseen[:, 0:3]))
-            labels = torch.cat((torch.ones(B, device=pred.device), torch.zeros(B, device=pred.device)))
+            labels = gan_labels(self, B, pred.device)
             t["gan"] = nn.functional.binary_cross_entropy_with_logits(self.discriminator(pred).view(-1), labels)
         else:
             t["gan"] = pred_unseen[:, 0:3].mean()
