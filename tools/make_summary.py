@@ -81,8 +81,9 @@ if os.path.exists(tsum):
     kk = [k for k in tj if "k_raster_backward_fm<1, false, true" in k]
     if kk:
         L.append("HIP-event average (timed steps, un-profiled run) vs rocprofv3 for `%s`: %.1f us vs %.1f us over the same "
-                 "last 10 steps of the profiled run (%.1f us over all 15 incl. warm-up); the two runs differ by clock state -- the "
-                 "step is host-enqueue bound, so the GPU idles between launches; `profiles/%s_raster_trace_summary.json`.\n"
+                 "last 10 steps of the profiled run (%.1f us over all 15 incl. warm-up); `profiles/%s_raster_trace_summary.json`. "
+                 "Differences of a few %% between the two runs are clock state (the step is close to host-enqueue "
+                 "bound, so the GPU idles between launches) and box-to-box spread.\n"
                  % (kk[0].split("(")[0], rf["avg_us"], tj[kk[0]]["avg_us_last10steps"], tj[kk[0]]["avg_us_all"], tag))
 elif bk:
     L.append("HIP-event average vs rocprofv3 average for `k_raster_backward_fm<1, false, true, ...>`: %.1f us vs %.1f us.\n"
