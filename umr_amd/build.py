@@ -23,9 +23,8 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "umr_common.h"),
-                                                      os.path.join(HERE, "..", "include", "umr_hip.h"),
-                                                      os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
+        os.path.join(HERE, "..", "include", "umr_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,462 @@
+// raster_backward.h -- backward kernels (included by raster.hip only): k_raster_backward_fm, the face-major kernel that
+// runs in production, and k_raster_backward, the pixel-major variant kept for A/B runs and very large TS.
+#pragma once
+#include "raster_core.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+template <int RGB>
+__global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArgs A) {
+    __shared__ int s_list[LIST_CAP];
+    __shared__ int s_wcnt[BLK_THREADS / 64];
+    Tile t;
+    tile_setup(t, A);
+    const int F = A.F, IS = A.IS, TS = A.TS;
+    const size_t npix = (size_t)IS * IS;
+    const size_t pn = (size_t)t.row * IS + t.xi;
+    const float4 *__restrict__ bbox_n = A.bbox + (size_t)t.n * F;
+    const float *__restrict__ rec_n = A.rec + (size_t)t.n * F * REC;
+    const float *__restrict__ tex_n = A.textures + (size_t)(t.n / A.tex_group) * F * TS * 3;
+
+    float ssum = 1.f, smax = 0.f, oc0 = 0.f, oc1 = 0.f, oc2 = 0.f, oa = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (t.valid) {
+        const float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
+        ssum = ag[0]; smax = ag[npix];
+        const float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
+        oc0 = sc[0]; oc1 = sc[npix]; oc2 = sc[2 * npix]; oa = sc[3 * npix];
+        if (A.grad_pooled) {  // avg_pool2d backward fused: every pixel of a 2x2 cell sees g/4
+            const int H = IS >> 1;
+            const float *gp = A.grad_colors + ((size_t)t.n * 4 * H + (t.row >> 1)) * H + (t.xi >> 1);
+            const size_t hp = (size_t)H * H;
+            g0 = 0.25f * gp[0]; g1 = 0.25f * gp[hp]; g2 = 0.25f * gp[2 * hp]; g3 = 0.25f * gp[3 * hp];
+        } else {
+            const float *gp = A.grad_colors + (size_t)t.n * 4 * npix + pn;
+            g0 = gp[0]; g1 = gp[npix]; g2 = gp[2 * npix]; g3 = gp[3 * npix];
+        }
+    }
+
+    for (int f0 = 0; f0 < F; f0 += LIST_CAP) {
+        const int f1 = min(F, f0 + LIST_CAP);
+        if (f0 > 0) __syncthreads();
+        const int count = build_list(s_list, s_wcnt, bbox_n, f0, f1, t);
+        if (!t.wave_on) continue;
+        for (int base = 0; base < count; base += 64) {
+            const int li = base + t.lane;
+            const int fcand = li < count ? s_list[li] : -1;
+            bool hit = false;
+            if (fcand >= 0) {
+                const float4 bb = bbox_n[fcand];
+                hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
+                if (hit) {  // one lane per candidate face: exact-ish tile/triangle test
+                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_INV);
+                    hit = tile_may_hit(q[0], q[1], q[2], 0.5f * (t.wxlo + t.wxhi), 0.5f * (t.wylo + t.wyhi),
+                                       0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr);
+                }
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int f = __builtin_amdgcn_readlane(fcand, b);
+                Face fc;
+                load_face(fc, rec_n + (size_t)f * REC);
+                float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // texture gradient of this lane (at texel tix)
+                int tix = 0;
+                bool contrib = false;
+                Pair p;
+                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis)) {
+                    float c_xy = g3 * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+                    float q0, q1, q2;
+                    const float zp = clip_depth(q0, q1, q2, p, fc);
+                    if (!(zp < A.near_ || zp > A.far_)) {  // :592 -- drops the alpha term as well
+                        contrib = true;
+                        if (RGB == 0) {
+                            if ((float)f == smax) {  // :596
+                                tix = texel_index(q0, q1, A.R);
+                                gt0 = g0; gt1 = g1; gt2 = g2;
+                            }
+                        } else if (fc.front() || A.double_side) {
+                            const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
+                            const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
+                            tix = texel_index(q0, q1, A.R);
+                            const float *tx = tex_n + ((size_t)f * TS + tix) * 3;
+                            gt0 = ps * g0; gt1 = ps * g1; gt2 = ps * g2;
+                            float c_rgb = g0 * (tx[0] - oc0);
+                            c_rgb += g1 * (tx[1] - oc1);
+                            c_rgb += g2 * (tx[2] - oc2);
+                            c_rgb *= ps;
+                            c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
+                            const float c_z = -(c_rgb * A.inv_gamma * A.r_range) * zp * zp;  // :624
+                            gv[2] = c_z * q0 * fc.g<R_RZ0>() * fc.g<R_RZ0>();
+                            gv[5] = c_z * q1 * fc.g<R_RZ1>() * fc.g<R_RZ1>();
+                            gv[8] = c_z * q2 * fc.g<R_RZ2>() * fc.g<R_RZ2>();
+                        }
+                        c_xy *= p.frag * (1.f - p.frag) * (-A.nis);  // :632
+                        const float k2 = 2.f * p.sign * c_xy;        // :640
+                        const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
+                        gv[0] = b0 * p.dx; gv[1] = b0 * p.dy;
+                        gv[3] = b1 * p.dx; gv[4] = b1 * p.dy;
+                        gv[6] = b2 * p.dx; gv[7] = b2 * p.dy;
+                    }
+                }
+                if (!__any(contrib)) continue;
+                if (A.need_gf) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float s = wave_sum_full(gv[k]);
+                        if (t.lane == k) mine = s;
+                    }
+                    if (t.lane < 9) atomicAdd(A.grad_faces + ((size_t)t.n * F + f) * 9 + t.lane, mine);
+                }
+                if (A.need_gt) {
+                    float *gtf = A.grad_textures + ((size_t)t.n * F + f) * TS * 3;
+                    if (TS == 1) {
+                        const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
+                        if (t.lane < 3) atomicAdd(gtf + t.lane, t.lane == 0 ? s0 : (t.lane == 1 ? s1 : s2));
+                    } else if (gt0 != 0.f || gt1 != 0.f || gt2 != 0.f) {
+                        atomicAdd(gtf + tix * 3 + 0, gt0);
+                        atomicAdd(gtf + tix * 3 + 1, gt1);
+                        atomicAdd(gtf + tix * 3 + 2, gt2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Face-major backward.  Given the saved per-pixel forward state, every (pixel, face) contribution to
+// the gradient is independent (:531-655), so the loop nest can be turned inside out: ONE WAVEFRONT PER
+// FACE walks the 8x8 pixel tiles under that face's dilated bounding box, accumulates the 9 vertex
+// gradients in registers (texel gradients in a per-wave LDS array) across all tiles, reduces across the
+// 64 lanes ONCE and stores.  No global atomics, no per-(tile, face) reduction, deterministic results; the
+// face record lives in SGPRs for the whole walk.  Per-pixel state is re-read once per overlapping face
+// (~6x, L1/L2 hits: consecutive faces of a subdivided mesh are spatial neighbours and share a workgroup).
+#ifndef FM_WAVES
+#define FM_WAVES 1   // faces (wavefronts) per workgroup of the face-major backward: 1 = finest scheduling granularity,
+                     // no straggler waves holding a CU slot (measured 1 < 2 < 4 < 8 in time)
+#endif
+#ifndef FM_RELOAD_PER_TILE
+#define FM_RELOAD_PER_TILE 1
+#endif
+#ifndef FM_TW
+#define FM_TW 4   // sub-tile width / height in pixels (8x8 = one tile per wave visit, 4x4 = four)
+#define FM_TH 4
+#endif
+#define FM_NQ (64 / (FM_TW * FM_TH))
+#ifndef FM_TEXMERGE
+#define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2
+                       // (a third, vertical step measured slower)
+#endif
+#ifndef FM_TEXCOPY
+#define FM_TEXCOPY 4   // private copies of a wave's LDS texel accumulators (power of two): neighbouring pixels share a
+#endif                 // texel, and same-address ds_add_f32 from one wave serialise -- spread them over copies
+#define FM_TEX_STRIDE(TS) (((TS) * 3) | 1)   // odd stride: copy c of a texel lands in another bank
+// Texel-gradient accumulation of the face-major backward (TS > 1): 3 ds_add_f32 per visit into the wave's LDS
+// accumulators.  Neighbouring pixels mostly fall into the same texel, and the LDS atomic pipe -- shared by every wave
+// of the CU -- saturates (SQ_WAIT_INST_LDS 21 % of wave time, the kernel 35 % slower than without the atomics).
+// So horizontally adjacent lanes holding the same texel are first summed with DPP quad permutes (the partner's value
+// is read only when the partner is active at this point: bound_ctrl off -> `old`), and only the surviving lane of
+// each run issues the atomics.  Deterministic; only the summation order differs from lane-by-lane atomics.
+__device__ __forceinline__ float dpp_f(float old, float v, const int ctrl_sel) {
+    // ctrl_sel: 0 -> quad_perm [1,0,3,2] (x^1), 1 -> quad_perm [2,3,0,1] (x^2), 2 -> row_shl:4, 3 -> row_shr:4
+    const int o = __float_as_int(old), i = __float_as_int(v);
+    int r;
+    if (ctrl_sel == 0) r = __builtin_amdgcn_update_dpp(o, i, 0xB1, 0xf, 0xf, false);
+    else if (ctrl_sel == 1) r = __builtin_amdgcn_update_dpp(o, i, 0x4E, 0xf, 0xf, false);
+    else if (ctrl_sel == 2) r = __builtin_amdgcn_update_dpp(o, i, 0x104, 0xf, 0xf, false);
+    else r = __builtin_amdgcn_update_dpp(o, i, 0x114, 0xf, 0xf, false);
+    return __int_as_float(r);
+}
+__device__ __forceinline__ int dpp_i(int old, int v, const int ctrl_sel) {
+    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(old, v, 0xB1, 0xf, 0xf, false);
+    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(old, v, 0x4E, 0xf, 0xf, false);
+    if (ctrl_sel == 2) return __builtin_amdgcn_update_dpp(old, v, 0x104, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a, float b, float c, int lane) {
+#if FM_TEXMERGE >= 1
+#pragma unroll
+    for (int step = 0; step < (FM_TEXMERGE >= 2 ? 2 : 1); ++step) {
+        // keeper = the lane of the pair with bit `step` clear.  The per-lane constants live in VGPRs (as 64-bit lane
+        // masks they were SGPR spills, restored with v_readlane every visit); multiplying the partner's value by the
+        // 0/1 weight lets the backend fuse the DPP read into one v_fmac_f32_dpp per channel.
+        const bool keep = (lane & (1 << step)) == 0;
+        const float keepf = keep ? 1.f : 0.f;
+        const int dropm = keep ? 0 : -1;
+        const int t = dpp_i(-1, tix, step);                     // partner's texel, -1 if it is not here
+        const bool same = t == tix;
+        const float w = same ? keepf : 0.f;
+        a = fmaf(dpp_f(0.f, a, step), w, a);
+        b = fmaf(dpp_f(0.f, b, step), w, b);
+        c = fmaf(dpp_f(0.f, c, step), w, c);
+        tix |= same ? dropm : 0;                                // merged into the partner: nothing left to add
+    }
+#endif
+    if (tix >= 0) {
+        atomicAdd(&my_tex[tix * 3], a);
+        atomicAdd(&my_tex[tix * 3 + 1], b);
+        atomicAdd(&my_tex[tix * 3 + 2], c);
+    }
+}
+template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
+// COMMON = the production case (gradient arrives 2x2-pooled, power-of-two image, double-sided faces) as compile-time
+// facts: the wave-uniform flags otherwise live as 64-bit lane masks in SGPRs that spill (v_readlane per visit)
+#ifndef BWD_WPE
+#define BWD_WPE 7
+#endif
+#define BWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BWD_WPE, BWD_WPE)))
+__global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_fm(const RasterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
+    const int F = A.F, IS = A.IS, TS = A.TS;
+    const bool pooled = COMMON ? true : (A.grad_pooled != 0);
+    const bool two_sided = COMMON ? true : (A.double_side != 0);
+    // XCD-aware: hardware XCD = blockIdx % 8.  Each XCD owns a fixed contiguous EIGHTH of every mesh's faces
+    // (index-neighbouring faces of a subdivided mesh are spatial neighbours), so the per-pixel state its waves
+    // re-read (~6x) covers 1/8 of the screen and stays in that XCD's 4 MB L2, and all 8 XCDs share every mesh
+    // (balance at small N).  Measured fabric reads: 47 MB/mesh round-robin -> ~20 MB/mesh (11.8 MB algorithmic).
+    const int fblocks = (F + FM_WAVES - 1) / FM_WAVES;   // blocks per mesh (grid = N * fblocks)
+    int nb = blockIdx.x / fblocks, fb = blockIdx.x % fblocks;
+    if (fblocks % 8 == 0 && (A.N * fblocks) % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = fblocks >> 3;
+        nb = slot / per;
+        fb = xcd * per + slot % per;
+    }
+    const int fidx = fb * FM_WAVES + wave;
+    const bool live = fidx < F;
+    const int n = nb, f = live ? fidx : 0;
+    const size_t npix = (size_t)IS * IS;
+    // wave-uniform bases of this mesh's per-pixel planes; every per-pixel load below is base + 32-bit byte offset
+    const int H2 = IS >> 1;
+    const unsigned pst = (unsigned)(npix * sizeof(float));                      // plane stride in bytes
+    const unsigned gps = pooled ? (unsigned)((size_t)H2 * H2 * sizeof(float)) : pst;
+    const int cplanes = RGB == 2 ? 1 : 4;
+    const char *sc_n = (const char *)(A.soft_colors + (size_t)n * cplanes * npix);
+    const char *ag_n = (const char *)(A.aggrs + (size_t)n * 2 * npix);
+    const char *gc_n = (const char *)(A.grad_colors + (size_t)n * cplanes * (pooled ? (size_t)H2 * H2 : npix));
+    float *wave_tex = s_tex + (size_t)wave * FM_TEXCOPY * FM_TEX_STRIDE(TS);
+    // this lane's copy: horizontally and vertically adjacent pixels of a 4x4 / 8x8 tile get different copies
+    float *my_tex = wave_tex + ((lane ^ (lane >> 2) ^ (lane >> 4)) & (FM_TEXCOPY - 1)) * FM_TEX_STRIDE(TS);
+    if (NEED_GT && TS > 1)
+        for (int j = lane; j < FM_TEXCOPY * FM_TEX_STRIDE(TS); j += 64) wave_tex[j] = 0.f;
+    float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // TS == 1 texel gradient
+    if (live) {
+        Face fc;
+        load_face(fc, A.rec + ((size_t)n * F + f) * REC);
+        const float *__restrict__ tex_f = A.textures + ((size_t)(n / A.tex_group) * F + f) * TS * 3;
+        // pixel-index window of the dilated bbox, widened by one pixel; the exact per-pixel reject of the
+        // reference (:536) still runs inside eval_pair, so the window only has to be conservative.
+        // xp(i) = (2i + 1 - IS)/IS  <=>  i = (xp*IS + IS - 1)/2
+        const float h = 0.5f * IS;
+        int x0 = (int)floorf(fc.g<R_XLO>() * h + h - 0.5f) - 1, x1 = (int)ceilf(fc.g<R_XHI>() * h + h - 0.5f) + 1;
+        int yi0 = (int)floorf(fc.g<R_YLO>() * h + h - 0.5f) - 1, yi1 = (int)ceilf(fc.g<R_YHI>() * h + h - 0.5f) + 1;
+        // NaN / inf bounds: comparisons below fail safe to the full image (the reference would visit all pixels)
+        if (!(fc.g<R_XLO>() == fc.g<R_XLO>() && fc.g<R_XHI>() == fc.g<R_XHI>() && fc.g<R_YLO>() == fc.g<R_YLO>() && fc.g<R_YHI>() == fc.g<R_YHI>())) { x0 = 0; x1 = IS - 1; yi0 = 0; yi1 = IS - 1; }
+        x0 = max(x0, 0); x1 = min(x1, IS - 1); yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
+        const int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;  // row = IS-1-yi
+        if (x0 <= x1 && r0 <= r1) {
+            // Sub-tiles of FM_TW x FM_TH pixels, FM_NQ = 64 / (FM_TW * FM_TH) of them per wave visit: the face is
+            // wave-uniform here, so the 64 lanes need not form ONE tile -- each group of FM_TW*FM_TH lanes takes its own
+            // needed sub-tile of this face.  4x4 sub-tiles fill 74 % of their lanes with contributing pixels against
+            // 54 % for one 8x8 tile (CPU simulation of the culling, 1280-face sphere at IS = 512).
+            const int tx0 = x0 / FM_TW, tx1 = x1 / FM_TW, ty0 = r0 / FM_TH, ty1 = r1 / FM_TH;
+            const bool pow2 = COMMON ? true : ((IS & (IS - 1)) == 0);
+            const float inv_is = 1.f / (float)IS;
+            const int ntx = tx1 - tx0 + 1, ntiles = ntx * (ty1 - ty0 + 1);
+            const float4 i0 = make_float4(fc.g<R_INV + 0>(), fc.g<R_INV + 1>(), fc.g<R_INV + 2>(), fc.g<R_INV + 3>());
+            const float4 i1 = make_float4(fc.g<R_INV + 4>(), fc.g<R_INV + 5>(), fc.g<R_INV + 6>(), fc.g<R_INV + 7>());
+            const float4 i2 = make_float4(fc.g<R_INV + 8>(), fc.g<R_K0>(), fc.g<R_K1>(), fc.g<R_K2>());
+            const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
+            for (int tb = 0; tb < ntiles; tb += 64) {
+                // one lane per sub-tile: drop those no pixel of which can survive (conservative), then walk the rest
+                const int ti = tb + lane;
+                bool want = false;
+                int tpk = 0;   // packed (tx, ty) of this lane's candidate
+                if (ti < ntiles) {
+                    const int ttx = tx0 + ti % ntx, tty = ty0 + ti / ntx;
+                    tpk = ttx | (tty << 16);
+                    const int px0 = ttx * FM_TW, px1 = min(px0 + FM_TW - 1, IS - 1), pr0 = tty * FM_TH, pr1 = min(pr0 + FM_TH - 1, IS - 1);
+                    const float cxl = ndc_coord_fast(px0, IS, inv_is, pow2), cxh = ndc_coord_fast(px1, IS, inv_is, pow2);
+                    const float cyh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), cyl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
+                    want = tile_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), 0.5f * (cxh - cxl),
+                                        0.5f * (cyh - cyl), A.thr);
+                }
+                unsigned long long tm = __ballot(want);
+                while (tm) {
+                    // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
+                    int mine = -1;
+#pragma unroll
+                    for (int qq = 0; qq < FM_NQ; ++qq) {
+                        if (tm) {
+                            const int tbit = __builtin_ctzll(tm);
+                            tm &= tm - 1;
+                            const int e = __builtin_amdgcn_readlane(tpk, tbit);
+                            if (sub == qq) mine = e;
+                        }
+                    }
+                    if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2) {
+                        // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
+                        // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop.  Only for the variants that
+                        // also carry the 9 vertex-gradient accumulators and the colour path (measured 4-6 % faster with
+                        // the re-fetch there, 1-5 % slower for the texel-only and silhouette kernels)
+                        const float *rp = A.rec + ((size_t)n * F + f) * REC;
+                        asm volatile("" : "+s"(rp));
+                        load_face(fc, rp);
+                    }
+                    if (mine < 0) continue;
+                    const int row = (mine >> 16) * FM_TH + sl / FM_TW;
+                    const int xi = (mine & 0xffff) * FM_TW + sl % FM_TW;
+                    if (xi >= IS || row >= IS) continue;
+                    const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
+                    const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                    const unsigned pn4 = (unsigned)(row * IS + xi) * 4u;                       // byte offset in a full plane
+                    const unsigned gp4 = pooled ? (unsigned)((row >> 1) * H2 + (xi >> 1)) * 4u : pn4;
+                    // Exact tile skips from the saved forward state, before any geometry:
+                    //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
+                    //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
+                    //    is >= 89 gamma behind the pixel's soft-max maximum (hard mode: the face is not the winner).
+                    {
+                        bool dead;
+                        if (RGB == 2) {
+                            dead = ld_u(sc_n, pn4) == 1.f;
+                        } else {
+                            dead = false;
+                            if (!NEED_GF) {   // (with vertex gradients both terms must vanish: too rare to pay for)
+                                const float smx = ld_u(ag_n, pn4 + pst);
+                                const float zmin_f = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
+                                dead = RGB == 0 ? (float)f != smx
+                                                : ((A.far_ - zmin_f) * A.r_range - smx) * A.inv_gamma < -89.f;
+                            }
+                        }
+                        if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;
+                    }
+                    Pair p;
+                    if (!eval_pair(p, fc, xp, yp, A.threshold, A.nis)) continue;
+                    if (RGB == 2) {  // silhouette: d alpha only (:584, :632-642); soft_colors/grad are [N,IS,IS] | [N,H,H]
+                        if (!fc.depth_in_range()) {
+                            float u0, u1, u2;
+                            const float zq = clip_depth(u0, u1, u2, p, fc);
+                            if (zq < A.near_ || zq > A.far_) continue;  // :592
+                        }
+                        const float ga = (pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
+                        const float oa = ld_u(sc_n, pn4);
+                        float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
+                        c_a *= p.frag * (1.f - p.frag) * (-A.nis);
+                        const float k2a = 2.f * p.sign * c_a;
+                        const float a0 = k2a * p.b0, a1 = k2a * p.b1, a2 = k2a * p.b2;
+                        gv[0] += a0 * p.dx; gv[1] += a0 * p.dy;
+                        gv[3] += a1 * p.dx; gv[4] += a1 * p.dy;
+                        gv[6] += a2 * p.dx; gv[7] += a2 * p.dy;
+                        continue;
+                    }
+                    const float gscale = pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
+                    const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
+                                g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
+                    const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
+                    const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
+                    float c_xy = 0.f;
+                    if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+                    float q0, q1, q2;
+                    const float zp = clip_depth(q0, q1, q2, p, fc);
+                    if (zp < A.near_ || zp > A.far_) continue;  // :592
+                    float gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+                    if (RGB == 0) {
+                        if (NEED_GT && (float)f == smax) {  // :596
+                            const int tix = texel_index(q0, q1, A.R);
+                            if (TS == 1) { gt0 += g0; gt1 += g1; gt2 += g2; }
+                            else texel_accumulate(my_tex, tix, g0, g1, g2, lane);
+                        }
+                    } else if (two_sided || fc.front()) {
+                        const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
+                        const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
+                        const int tix = texel_index(q0, q1, A.R);
+                        if (NEED_GT) {
+                            if (TS == 1) { gt0 += ps * g0; gt1 += ps * g1; gt2 += ps * g2; }
+                            else texel_accumulate(my_tex, tix, ps * g0, ps * g1, ps * g2, lane);
+                        }
+                        if (NEED_GF) {
+                            const char *tx = (const char *)tex_f;
+                            const unsigned t12 = (unsigned)tix * 12u;
+                            float c_rgb = g0 * (ld_u(tx, t12) - ld_u(sc_n, pn4));
+                            c_rgb += g1 * (ld_u(tx, t12 + 4) - ld_u(sc_n, pn4 + pst));
+                            c_rgb += g2 * (ld_u(tx, t12 + 8) - ld_u(sc_n, pn4 + 2 * pst));
+                            c_rgb *= ps;
+                            c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
+                            const float c_z = -(c_rgb * A.inv_gamma * A.r_range) * zp * zp;  // :624
+                            gz0 = c_z * q0 * fc.g<R_RZ0>() * fc.g<R_RZ0>();
+                            gz1 = c_z * q1 * fc.g<R_RZ1>() * fc.g<R_RZ1>();
+                            gz2 = c_z * q2 * fc.g<R_RZ2>() * fc.g<R_RZ2>();
+                        }
+                    }
+                    if (NEED_GF) {
+                        c_xy *= p.frag * (1.f - p.frag) * (-A.nis);  // :632
+                        const float k2 = 2.f * p.sign * c_xy;        // :640
+                        const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
+                        gv[0] += b0 * p.dx; gv[1] += b0 * p.dy; gv[2] += gz0;
+                        gv[3] += b1 * p.dx; gv[4] += b1 * p.dy; gv[5] += gz1;
+                        gv[6] += b2 * p.dx; gv[7] += b2 * p.dy; gv[8] += gz2;
+                    }
+                }
+            }
+        }
+    }
+    if (NEED_GF) {
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float sv = wave_sum_full(gv[k]);
+            if (lane == k) mine = sv;
+        }
+        if (live && lane < 9) A.grad_faces[((size_t)n * F + f) * 9 + lane] += mine;
+    }
+    if (NEED_GT) {
+        if (TS == 1) {
+            const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
+            if (live && lane < 3) A.grad_textures[((size_t)n * F + f) * 3 + lane] += lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+        } else {
+            __syncthreads();  // every wave arrives exactly once; orders the LDS atomics before the read-out
+            if (live) {
+                float *dst = A.grad_textures + ((size_t)n * F + f) * TS * 3;
+                for (int j = lane; j < TS * 3; j += 64) {
+                    float acc = wave_tex[j];
+#pragma unroll
+                    for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
+                    dst[j] += acc;
+                }
+            }
+        }
+    }
+}
+
+template <int RGB, bool COMMON>
+void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
+    const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
+    const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
+    if (RGB == 2) k_raster_backward_fm<2, true, false, COMMON><<<blocks, FM_WAVES * 64, 0, st>>>(A);
+    else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else if (A.need_gf) k_raster_backward_fm<RGB, true, false, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else k_raster_backward_fm<RGB, false, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+}
+template <int RGB>
+void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
+    const bool common = A.grad_pooled && A.double_side && (A.IS & (A.IS - 1)) == 0;
+    if (common) launch_backward_fm2<RGB, true>(A, st);
+    else launch_backward_fm2<RGB, false>(A, st);
+}
+
+bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int TS, int *R) {
+    if (func_id_dist != 2 || func_id_alpha != 2 || texture_sample_type != 0) return false;
+    if (func_id_rgb != 0 && func_id_rgb != 1) return false;
+    int r = 1;
+    while (r * r < TS) ++r;
+    if (r * r != TS) return false;
+    *R = r;
+    return true;
+}
+
+}  // namespace

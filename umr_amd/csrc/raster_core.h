@@ -1,0 +1,388 @@
+// raster_core.h -- shared device code of the soft rasterizer (included by raster.hip only): record layout, per-face
+// preprocessing, the pixel/face geometry core (eval_pair), depth / texel helpers, tile culling and the forward's
+// in-kernel binning.  See raster.hip for the execution plan and the reference line numbers.
+#pragma once
+#include "umr_common.h"
+
+#define REC 64         // floats per preprocessed face record
+#define LIST_CAP 2048  // LDS face list capacity (faces are processed in super-chunks of this many)
+#ifndef BLK_W
+#define BLK_W 16   // measured on MI355X (N=128, F=1280, IS=512, soft-max forward): 16x16 1.55 ms, 32x8 / 16x8 1.64,
+#define BLK_H 16   // 32x16 1.81, 32x32 2.08, 8x8 2.28 -- 4 waves share one binning pass and still schedule finely
+#endif
+#define BLK_WX (BLK_W / 8)                          // 8x8 wave tiles across / in the workgroup
+#define BLK_THREADS (BLK_WX * (BLK_H / 8) * 64)
+
+namespace {
+
+// Record layout (floats) written by k_face_setup: 256 bytes per face.
+//   [0,32)  wave-uniform part, fetched with 2 x s_load_dwordx16 into SGPRs
+//   [32,56) three 32-byte edge blocks {a0, a1, a2, a[v1], den, RN(1/den), -, -}; a lane reads ONLY the block
+//           of its nearest edge (per-lane address, 2 x global_load_dwordx4, L1-resident)
+enum { R_XLO = 0, R_XHI = 1, R_YLO = 2, R_YHI = 3, R_X0 = 4, R_Y0 = 5, R_X1 = 6, R_Y1 = 7, R_X2 = 8, R_Y2 = 9,
+       R_Z0 = 10, R_Z1 = 11, R_Z2 = 12, R_RZ0 = 13, R_RZ1 = 14, R_RZ2 = 15,
+       R_INV = 16, R_K0 = 25, R_K1 = 26, R_K2 = 27, R_FLAGS = 28, R_FRONT = 29, R_OX = 30, R_OY = 31,
+       R_EDGE = 32 };
+
+struct RasterArgs {
+    const float4 *bbox;   // [N*F] (xlo, xhi, ylo, yhi) = bbox dilated by sqrt(threshold)
+    const float *rec;     // [N*F*REC]
+    const float *textures;
+    const float *grid;
+    float *aggrs;
+    float *p2f_info;
+    float *p2f_sum;
+    float *soft_colors;
+    float *pooled;
+    // backward only
+    const float *grad_colors;
+    float *grad_faces;
+    float *grad_textures;
+    int N, F, IS, TS, R;
+    float near_, far_, eps, sigma, threshold, gamma;
+    float thr;        // sqrt(threshold)
+    float nis;        // -1/sigma
+    float r_range;    // RN(1/(far-near))
+    float inv_gamma;
+    int double_side, with_p2f, grad_pooled, need_gf, need_gt;
+    int tiles_x, tiles_y;
+    int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
+    int bg_arg;       // background passed by value: soft_colors arrives uninitialised
+    float bg0, bg1, bg2;
+};
+
+// ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
+__global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
+                             float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
+                             float near_, float far_) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float *f = faces + (size_t)i * 9;
+    const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
+    float adj[9] = {y1 - y2, x2 - x1, x1 * y2 - x2 * y1,
+                    y2 - y0, x0 - x2, x2 * y0 - x0 * y2,
+                    y0 - y1, x1 - x0, x0 * y1 - x1 * y0};
+    float det = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+    det = det > 0 ? fmaxf(det, 1e-10f) : fminf(det, -1e-10f);
+    float inv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv[k] = adj[k] / det;
+    const float px[3] = {x0, x1, x2}, py[3] = {y0, y1, y2};
+    float sym[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sym[j * 3 + k] = px[j] * px[k] + py[j] * py[k] + 1.f;
+    int obt = -1;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {  // first obtuse corner wins (:273-281)
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        if ((px[k1] - px[k]) * (px[k2] - px[k]) + (py[k1] - py[k]) * (py[k2] - py[k]) < 0) obt = k;
+    }
+    if (faces_info) {
+        float *fi = faces_info + (size_t)i * 27;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { fi[k] = inv[k]; fi[9 + k] = sym[k]; }
+        fi[18] = obt == 0 ? 1.f : 0.f; fi[19] = obt == 1 ? 1.f : 0.f; fi[20] = obt == 2 ? 1.f : 0.f;
+    }
+    const float xlo = fminf(fminf(x0, x1), x2) - thr, xhi = fmaxf(fmaxf(x0, x1), x2) + thr;
+    const float ylo = fminf(fminf(y0, y1), y2) - thr, yhi = fmaxf(fmaxf(y0, y1), y2) + thr;
+    bbox[i] = make_float4(xlo, xhi, ylo, yhi);
+    // ---- packed record: three 64-byte lines, fetched by the raster kernels with 3 x s_load_dwordx16 ----
+    float *r = rec + (size_t)i * REC;
+    r[R_XLO] = xlo; r[R_XHI] = xhi; r[R_YLO] = ylo; r[R_YHI] = yhi;
+    r[R_X0] = x0; r[R_Y0] = y0; r[R_X1] = x1; r[R_Y1] = y1; r[R_X2] = x2; r[R_Y2] = y2;
+    r[R_Z0] = z0; r[R_Z1] = z1; r[R_Z2] = z2;
+    r[R_RZ0] = 1.f / z0; r[R_RZ1] = 1.f / z1; r[R_RZ2] = 1.f / z2;  // correctly rounded (Markstein division)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[R_INV + k] = inv[k];
+    // squared height of corner c over its opposite edge: inside the triangle the squared distance to that
+    // edge's line is w_c^2 K_c -- used only to PICK the nearest edge (:99), the distance itself is then
+    // evaluated with the reference's own formula
+    const float det_raw = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int a = (c + 1) % 3, b = (c + 2) % 3;
+        const float ex = px[a] - px[b], ey = py[a] - py[b];
+        r[R_K0 + c] = det_raw * det_raw / fmaxf(ex * ex + ey * ey, 1e-30f);
+    }
+    // depth chain may use reciprocal-multiply division only when every z is an ordinary positive number
+    const bool sane = z0 > 1e-20f && z1 > 1e-20f && z2 > 1e-20f && z0 < 1e20f && z1 < 1e20f && z2 < 1e20f;
+    // bit 3: every vertex depth strictly inside (near, far) => the interpolated depth (a convex combination of the
+    // 1/z_k with positive clipped weights) can never be rejected by the depth-range test (:404, :592)
+    const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
+    const bool inrange = sane && zmin > near_ * 1.0001f && zmax < far_ * 0.9999f;
+    // bits 0-1: obtuse corner + 1 (0 = none); bit 2: slow division path
+    r[R_FLAGS] = __int_as_float((obt + 1) | (sane ? 0 : 4) | (inrange ? 8 : 0));
+    r[R_FRONT] = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1.f : 0.f;  // :42-44
+    // vector of the obtuse-corner override test (:116,:119,:122): corner k -> p_{k+2} - p_k
+    const int ob = obt < 0 ? 0 : obt;
+    r[R_OX] = px[(ob + 2) % 3] - px[ob];
+    r[R_OY] = py[(ob + 2) % 3] - py[ob];
+    // edge e = (e, e+1): a_e[j] = sym[e][j] - sym[e+1][j] (:82-84,:133-135); den_e = a_e[e] - a_e[e+1]
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int e1 = (e + 1) % 3;
+        float a[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] = sym[3 * e + j] - sym[3 * e1 + j];
+        const float den = a[e] - a[e1];
+        float *eb = r + R_EDGE + 8 * e;
+        eb[0] = a[0]; eb[1] = a[1]; eb[2] = a[2]; eb[3] = a[e1];
+        eb[4] = den; eb[5] = 1.f / den; eb[6] = 0.f; eb[7] = 0.f;
+    }
+#pragma unroll
+    for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
+}
+
+__device__ __forceinline__ float ndc_coord(int i, int IS) {  // (2i + 1 - IS) / IS, evaluated in double (:325-326)
+    return (float)((2.0 * i + 1.0 - IS) / IS);
+}
+
+// Same value without fp64 when IS is a power of two (every BASELINE config): 2i+1-IS is an exact small
+// integer and the division is an exponent shift, so float arithmetic is exact -- provably identical bits.
+__device__ __forceinline__ float ndc_coord_fast(int i, int IS, float inv_is, bool pow2) {
+    return pow2 ? (float)(2 * i + 1 - IS) * inv_is : ndc_coord(i, IS);
+}
+
+// The record address is wave-uniform (face id comes from v_readlane / the wave id); reading it through the
+// constant address space makes the backend emit s_load_dwordx16 (scalar cache, SGPR operands) instead of
+// 64-lane broadcast vector loads.  Three explicit 64-byte vector loads issue back to back and are waited for
+// once.  Safe: the records are written by k_face_setup in an EARLIER launch.
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) v16f cv16f_t;
+
+// Load through a wave-uniform base pointer plus a per-lane 32-bit BYTE offset: the form the backend turns into
+// `global_load_dword v, v_off, s[base:base+1]` (scalar base, no 64-bit per-lane address arithmetic).
+__device__ __forceinline__ float ld_u(const char *base, unsigned byte_off) {
+    return *(const float *)(base + byte_off);
+}
+__device__ __forceinline__ float4 ld_u4(const char *base, unsigned byte_off) {
+    return *(const float4 *)(base + byte_off);
+}
+
+struct Face {  // wave-uniform: 32 SGPRs + the record's address
+    v16f qa, qb;
+    const char *edges;    // three 32-byte edge blocks (global memory, read per lane: uniform base + k * 32)
+    template <int I> __device__ __forceinline__ float g() const {
+        if constexpr (I < 16) return qa[I];
+        else return qb[I - 16];
+    }
+    __device__ __forceinline__ int obt() const { return (__float_as_int(g<R_FLAGS>()) & 3) - 1; }
+    __device__ __forceinline__ bool front() const { return g<R_FRONT>() != 0.f; }
+    __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
+    __device__ __forceinline__ bool depth_in_range() const { return (__float_as_int(g<R_FLAGS>()) & 8) != 0; }
+};
+
+__device__ __forceinline__ void load_face(Face &fc, const float *rg) {
+    cv16f_t *r = (cv16f_t *)rg;
+    fc.qa = r[0]; fc.qb = r[1];
+    fc.edges = (const char *)(rg + R_EDGE);
+}
+
+struct Pair {  // per-lane result of the pixel/face geometry
+    float w0, w1, w2;   // unclipped barycentrics
+    float b0, b1, b2;   // barycentrics of the closest boundary point (the reference's t + w, :640)
+    float dx, dy, sign, frag;
+};
+
+// RN(1/b) for ordinary b: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_nr(float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r, 1.f), r, r);
+}
+// a/b given r ~ RN(1/b): Markstein's correction -> correctly rounded quotient for ordinary operands
+__device__ __forceinline__ float div_r(float a, float b, float r) {
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+
+// bbox reject (:355), barycentric (:25-29), euclidean distance (:63-152), threshold reject (:382),
+// sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
+__device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, float yp, float threshold,
+                                          float neg_inv_sigma) {
+    // Written branch-free (predicates + selects): per-lane divergence would otherwise cost ~80 scalar
+    // exec-mask instructions per face visit.  Dead lanes compute garbage that the returned predicate masks.
+    const bool inb = !((xp > fc.g<R_XHI>()) | (xp < fc.g<R_XLO>()) | (yp > fc.g<R_YHI>()) | (yp < fc.g<R_YLO>()));
+    // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
+    // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
+    const float w0 = (fc.g<R_INV + 0>() * xp + fc.g<R_INV + 1>() * yp) + fc.g<R_INV + 2>();
+    const float w1 = (fc.g<R_INV + 3>() * xp + fc.g<R_INV + 4>() * yp) + fc.g<R_INV + 5>();
+    const float w2 = (fc.g<R_INV + 6>() * xp + fc.g<R_INV + 7>() * yp) + fc.g<R_INV + 8>();
+    p.w0 = w0; p.w1 = w1; p.w2 = w2;
+    const bool inside = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
+    // inside: nearest edge LINE, first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
+    // corner k+2 and its squared distance is w_c^2 K_c
+    const float m0 = w2 * w2 * fc.g<R_K2>(), m1 = w0 * w0 * fc.g<R_K0>(), m2 = w1 * w1 * fc.g<R_K1>();
+    const bool c1 = m1 < m0;
+    const float best = c1 ? m1 : m0;
+    const int kin = (m2 < best) ? 2 : (c1 ? 1 : 0);
+    // outside: region selection (:112-126), lowest priority first so the highest-priority match is applied last
+    const int ob = fc.obt();
+    // obtuse corner's coordinates: a wave-uniform pick among SGPRs, written with masks so that it stays three scalar
+    // and/or ops -- as nested selects the compiler turns it into a dynamically indexed vector read, which on gfx9
+    // means copying 16 SGPRs to VGPRs (8 v_mov_b64 + s_set_gpr_idx) on every face visit
+    const int mk0 = -(int)(ob == 0), mk1 = -(int)(ob == 1), mk2 = -(int)(ob == 2);
+    const float cx = __int_as_float((__float_as_int(fc.g<R_X0>()) & mk0) | (__float_as_int(fc.g<R_X1>()) & mk1) |
+                                    (__float_as_int(fc.g<R_X2>()) & mk2));
+    const float cy = __int_as_float((__float_as_int(fc.g<R_Y0>()) & mk0) | (__float_as_int(fc.g<R_Y1>()) & mk1) |
+                                    (__float_as_int(fc.g<R_Y2>()) & mk2));
+    const bool ovr = (xp - cx) * fc.g<R_OX>() + (yp - cy) * fc.g<R_OY>() > 0;
+    // Region code m = n0 | n1 << 1 | n2 << 2 with n_k = (w_k <= 0); the reference's if-chain (:112-126) is a table of
+    // m -- single flag: opposite edge (n0 -> 1, n1 -> 2, n2 -> 0); two flags: the vertex region between them
+    // ({n0,n1} -> 2, {n2,n0} -> 1, {n1,n2} -> 0; all three -- degenerate faces only -- ends like {n1,n2}); none: -1 --
+    // plus ONE wave-uniform exception: in the vertex region of the flagged obtuse corner `ob` the other edge is taken
+    // when the pixel lies on its far side (`ovr`).  Entries are stored +1 in 2 bits each.
+    const int m = min((w0 <= 0 ? 1 : 0) | (w1 <= 0 ? 2 : 0) | (w2 <= 0 ? 4 : 0), 6);
+    constexpr unsigned KOUT_LUT = (0u << 0) | (2u << 2) | (3u << 4) | (3u << 6) | (1u << 8) | (2u << 10) | (1u << 12);
+    const int m_ob = ob == 0 ? 6 : (ob == 1 ? 5 : (ob == 2 ? 3 : -1));   // two-flag code of the obtuse corner's region
+    const int k_ob = ob == 0 ? 2 : (ob == 1 ? 0 : 1);                     // the edge its override selects
+    int kout = (int)((KOUT_LUT >> (2 * m)) & 3u) - 1;
+    kout = ((m == m_ob) & ovr) ? k_ob : kout;
+    const int ksel = inside ? kin : kout;
+    const bool kvalid = ksel >= 0;  // k = -1: reference UB (index -1); defined here and in the oracle as "skip"
+    const int k = max(ksel, 0);
+    // t[v0] = (w . a - a[v1]) / (a[v0] - a[v1]) in the reference's operation order (:86,:137); IEEE-exact
+    // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
+    // D ~ exp(-d^2/sigma) ~ 1e-9, amplifying rounding noise in d^2 ~20x: parity there needs the reference's
+    // own noise, i.e. its own arithmetic, not just the same formula.
+    const unsigned ko = (unsigned)k * 32u;
+    const float4 ea = ld_u4(fc.edges, ko), eb = ld_u4(fc.edges, ko + 16u);  // {a0,a1,a2,a[v1]}, {den, 1/den, -, -}
+    const float tv = div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
+    const bool k0 = k == 0, k1 = k == 1;
+    const float tb = 1.f - tv;
+    const float ba = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f);  // unclamped inside (:86-88), clamped outside (:142-145)
+    const float bb = inside ? tb : fminf(fmaxf(tb, 0.f), 1.f);
+    const float b0 = k0 ? ba : (k1 ? 0.f : bb);
+    const float b1 = k0 ? bb : (k1 ? ba : 0.f);
+    const float b2 = k0 ? 0.f : (k1 ? bb : ba);
+    const float t0 = b0 - w0, t1 = b1 - w1, t2 = b2 - w2;
+    const float dx = (t0 * fc.g<R_X0>() + t1 * fc.g<R_X1>()) + t2 * fc.g<R_X2>();  // :95-96, :148-149
+    const float dy = (t0 * fc.g<R_Y0>() + t1 * fc.g<R_Y1>()) + t2 * fc.g<R_Y2>();
+    const float dis = dx * dx + dy * dy;
+    p.b0 = b0; p.b1 = b1; p.b2 = b2; p.dx = dx; p.dy = dy;
+    p.sign = inside ? 1.f : -1.f;
+    // 1 / (1 + exp(-sign * dis / sigma))
+    const float e = __expf((inside ? dis : -dis) * neg_inv_sigma);
+    p.frag = __builtin_amdgcn_rcpf(1.f + e);
+    return inb & kvalid & (inside | !(dis >= threshold));  // rejects of :355, :382
+}
+
+// barycentric_clip (:54-59) + perspective-correct depth (:403).  The soft-max weights are exp(zn/gamma) with
+// gamma = 1e-4: one ulp of zn moves a weight by ~7e-4, so this chain reproduces the reference's IEEE
+// divisions to the last bit (Markstein-corrected reciprocal multiplies; plain IEEE when z is degenerate).
+__device__ __forceinline__ float clip_depth(float &c0, float &c1, float &c2, const Pair &p, const Face &fc) {
+    c0 = fmaxf(fminf(p.w0, 1.f - 1e-5f), 1e-5f);
+    c1 = fmaxf(fminf(p.w1, 1.f - 1e-5f), 1e-5f);
+    c2 = fmaxf(fminf(p.w2, 1.f - 1e-5f), 1e-5f);
+    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+    if (fc.slow()) {
+        c0 /= s; c1 /= s; c2 /= s;
+        return 1.f / (c0 / fc.g<R_Z0>() + c1 / fc.g<R_Z1>() + c2 / fc.g<R_Z2>());
+    }
+    const float rs = rcp_nr(s);
+    c0 = div_r(c0, s, rs); c1 = div_r(c1, s, rs); c2 = div_r(c2, s, rs);
+    const float x = (div_r(c0, fc.g<R_Z0>(), fc.g<R_RZ0>()) + div_r(c1, fc.g<R_Z1>(), fc.g<R_RZ1>())) + div_r(c2, fc.g<R_Z2>(), fc.g<R_RZ2>());
+    const float rx = rcp_nr(x);
+    return fmaf(fmaf(-x, rx, 1.f), rx, rx);
+}
+
+__device__ __forceinline__ int texel_index(float c0, float c1, int R) {  // :180-189
+    if (R == 1) return 0;
+    const int wx = (int)(c0 * R), wy = (int)(c1 * R);
+    if ((c0 + c1) * R - wx - wy <= 1) return wy * R + wx;
+    return (R - 1 - wy) * R + (R - 1 - wx);
+}
+
+
+// Conservative "can any pixel centre of this tile survive the reference's rejects?" test.  A pixel whose
+// perpendicular distance to the outer side of ONE edge line exceeds sqrt(threshold) is outside the triangle and
+// farther than the threshold from it (whatever edge the reference's region logic picks, its clamped closest
+// point is at least that far), so it is rejected at :382.  w_c is affine in the pixel position, so its maximum
+// over the tile is w_c(centre) + hx |dw_c/dx| + hy |dw_c/dy|; signed distance = w_c * h_c with h_c^2 = K_c.
+// NaN / degenerate faces (K_c = 0) never cull.  1e-3 (in barycentric units) absorbs rounding.
+__device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, const float4 i2, float cx, float cy,
+                                             float hx, float hy, float thr) {
+    // i0 = inv[0..3], i1 = inv[4..7], i2 = {inv[8], K0, K1, K2}
+    const float w0 = fmaf(i0.x, cx, fmaf(i0.y, cy, i0.z)) + (hx * fabsf(i0.x) + hy * fabsf(i0.y));
+    const float w1 = fmaf(i0.w, cx, fmaf(i1.x, cy, i1.y)) + (hx * fabsf(i0.w) + hy * fabsf(i1.x));
+    const float w2 = fmaf(i1.z, cx, fmaf(i1.w, cy, i2.x)) + (hx * fabsf(i1.z) + hy * fabsf(i1.w));
+    const bool out = w0 < -(thr * __frsqrt_rn(i2.y)) - 1e-3f || w1 < -(thr * __frsqrt_rn(i2.z)) - 1e-3f ||
+                     w2 < -(thr * __frsqrt_rn(i2.w)) - 1e-3f;
+    return !out;
+}
+
+// XCD-aware work mapping: hardware places workgroup b on XCD b % 8; give each XCD a contiguous
+// run of (mesh, tile) work items so one mesh's face records stay in one L2.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+    return (total % 8 == 0) ? (b % 8) * (total / 8) + b / 8 : b;
+}
+
+struct Tile {
+    int n, lane, wave, xi, row;
+    bool valid, wave_on;
+    float xp, yp;
+    float bxlo, bxhi, bylo, byhi;  // block bounds (pixel centres)
+    float wxlo, wxhi, wylo, wyhi;  // wave tile bounds
+};
+
+__device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
+    const int total = A.N * A.tiles_x * A.tiles_y;
+    int wid = xcd_remap(blockIdx.x, total);
+    const int bx = wid % A.tiles_x; wid /= A.tiles_x;
+    const int by = wid % A.tiles_y;
+    t.n = wid / A.tiles_y;
+    t.lane = threadIdx.x & 63;
+    t.wave = threadIdx.x >> 6;
+    const int IS = A.IS;
+    const int px0 = bx * BLK_W + (t.wave % BLK_WX) * 8, py0 = by * BLK_H + (t.wave / BLK_WX) * 8;
+    t.xi = px0 + (t.lane & 7);
+    t.row = py0 + (t.lane >> 3);
+    t.valid = t.xi < IS && t.row < IS;
+    t.wave_on = px0 < IS && py0 < IS;
+    // pixel centres: exact float path when IS is a power of two (12 fp64 divisions per thread otherwise -- they
+    // were 40 % of the silhouette kernel's VALU instructions)
+    const bool pow2 = (IS & (IS - 1)) == 0;
+    const float inv_is = 1.f / (float)IS;
+    t.xp = ndc_coord_fast(t.xi, IS, inv_is, pow2);
+    t.yp = ndc_coord_fast(IS - 1 - t.row, IS, inv_is, pow2);
+    t.bxlo = ndc_coord_fast(bx * BLK_W, IS, inv_is, pow2);
+    t.bxhi = ndc_coord_fast(min(bx * BLK_W + BLK_W - 1, IS - 1), IS, inv_is, pow2);
+    t.byhi = ndc_coord_fast(IS - 1 - by * BLK_H, IS, inv_is, pow2);
+    t.bylo = ndc_coord_fast(IS - 1 - min(by * BLK_H + BLK_H - 1, IS - 1), IS, inv_is, pow2);
+    t.wxlo = ndc_coord_fast(px0, IS, inv_is, pow2);
+    t.wxhi = ndc_coord_fast(min(px0 + 7, IS - 1), IS, inv_is, pow2);
+    t.wyhi = ndc_coord_fast(IS - 1 - py0, IS, inv_is, pow2);
+    t.wylo = ndc_coord_fast(IS - 1 - min(py0 + 7, IS - 1), IS, inv_is, pow2);
+}
+
+// Block-level binning of faces [f0, f1) into the LDS list, ascending order.  Returns the count.
+__device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4 *__restrict__ bbox_n, int f0,
+                                          int f1, const Tile &t) {
+    int count = 0;
+    for (int c = f0; c < f1; c += BLK_THREADS) {
+        const int f = c + (int)threadIdx.x;
+        bool pass = false;
+        if (f < f1) {
+            const float4 bb = bbox_n[f];
+            // same predicate as the per-pixel reject, applied to the block's extreme pixel centres
+            pass = !(t.bxlo > bb.y || t.bxhi < bb.x || t.bylo > bb.w || t.byhi < bb.z);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (t.lane == 0) s_wcnt[t.wave] = __popcll(m);
+        __syncthreads();
+        int base = count, tot = 0;
+#pragma unroll
+        for (int w = 0; w < BLK_THREADS / 64; ++w) {
+            const int cw = s_wcnt[w];
+            if (w < t.wave) base += cw;
+            tot += cw;
+        }
+        if (pass) s_list[base + __popcll(m & ((1ull << t.lane) - 1ull))] = f;
+        count += tot;
+        __syncthreads();
+    }
+    return count;
+}
+
+}  // namespace
