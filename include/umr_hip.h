@@ -85,11 +85,11 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * else -- what TexCycle consumes from the hard renderer (nnutils/loss_utils.py:327-328, train_s1.py:223-224).
  * soft_colors, textures, grid, p2f_* may be NULL.  Bit-identical planes to the full hard kernel. */
 #define UMR_RASTER_FACE_ID_ONLY 4
-/* flags bits 8-15: texture group G (0 = 1).  `textures` is then [N/G,F,TS,3] and view n samples textures[n / G]:
+/* flags bits 8-23: texture group G (0 = 1).  `textures` is then [N/G,F,TS,3] and view n samples textures[n / G]:
  * K camera hypotheses of one image share one texture set, so the reference's textures.repeat(K) (70 MB at N=128,
- * nnutils/loss_utils.py:303-306) is folded into indexing.  umr_raster_backward takes the same field in bits 8-15 of
+ * nnutils/loss_utils.py:303-306) is folded into indexing.  umr_raster_backward takes the same field in bits 8-23 of
  * `grad_is_pooled`; grad_textures stays PER VIEW [N,F,TS,3] (the caller sums the G views, as autograd does for repeat). */
-#define UMR_RASTER_TEX_GROUP(G) (((G) & 0xff) << 8)
+#define UMR_RASTER_TEX_GROUP(G) (((G) & 0xffff) << 8)
 /* umr_raster_backward `grad_is_pooled` is a bit field: */
 #define UMR_BWD_GRAD_POOLED 1   /* gradient arrives at the 2x2-pooled resolution */
 #define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb

@@ -104,7 +104,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     int R = 0;
     const bool alpha_only = (flags & UMR_RASTER_ALPHA_ONLY) != 0;
     const bool ids_only = (flags & UMR_RASTER_FACE_ID_ONLY) != 0;
-    const int tex_group = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : 1;
+    const int tex_group = ((flags >> 8) & 0xffff) ? ((flags >> 8) & 0xffff) : 1;
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (alpha_only && ids_only) return UMR_ERR_ARG;
     if (ids_only && (func_id_rgb != 0 || !aggrs_info)) return UMR_ERR_ARG;
@@ -174,7 +174,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     (void)faces_info;  // recomputed into the workspace (bit-identical: same kernel, same input)
     int R = 0;
     const bool alpha_only = (grad_is_pooled & UMR_BWD_ALPHA_ONLY) != 0;
-    const int tex_group = ((grad_is_pooled >> 8) & 0xff) ? ((grad_is_pooled >> 8) & 0xff) : 1;
+    const int tex_group = ((grad_is_pooled >> 8) & 0xffff) ? ((grad_is_pooled >> 8) & 0xffff) : 1;
     grad_is_pooled &= UMR_BWD_GRAD_POOLED;
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (!faces || !soft_colors || !grad_soft_colors || !workspace) return UMR_ERR_ARG;

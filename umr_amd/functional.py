@@ -57,7 +57,7 @@ class SoftRasterizeFunction(Function):
         tex = _f32c(textures)
         N, F = fv.shape[:2]
         if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] < 1 or N % tex.shape[0] \
-                or N // tex.shape[0] > 255 or tex.shape[1] != F or tex.shape[3] != 3:
+                or N // tex.shape[0] > 65535 or tex.shape[1] != F or tex.shape[3] != 3:
             raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N or N/G,F,TS,3]; got "
                                "%s and %s" % (tuple(fv.shape), tuple(tex.shape)))   # kernels index textures by (n//G, f)
         G = N // tex.shape[0]     # G views share one texture set (the reference repeats textures x K, loss_utils.py:303-306)
