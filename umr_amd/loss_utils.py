@@ -268,6 +268,10 @@ class part_matching_loss(nn.Module):
         # one 3-channel one-hot texture per part; expanded per call instead of stored batch_size times (:360-363)
         for i in range(1, 5):
             self.register_buffer("stex%d" % i, stex_one_hot[:, :, :, i].unsqueeze(-1).repeat(1, 1, 1, 3))
+        # parts 1-3 as the three colour channels of ONE texture set: the reference renders each part separately with its
+        # one-hot replicated over r, g, b "because the renderer can only render 3-channel images" (:357-359) -- four
+        # renders of identical geometry; channel k of one render of (part1, part2, part3) is the same image
+        self.register_buffer("stex123", stex_one_hot[:, :, :, 1:4].contiguous(), persistent=False)
         self.renderer = SoftRenderer(im_size, "softmax")
         self.renderer.ambient_light_only()
         self.renderer.need_p2f = False
@@ -277,11 +281,11 @@ class part_matching_loss(nn.Module):
 
     def forward(self, verts, faces, cams, part_segs, cam_probs=None, avg=True):
         bs = verts.size(0)
-        projs = []
-        for i in range(1, 5):
-            stex = getattr(self, "stex%d" % i).expand(bs, -1, -1, -1).contiguous()
-            proj, _, _ = self.renderer(verts, faces, cams, stex)
-            projs.append(torch.mean(proj[:, 0:3, :, :], dim=1).unsqueeze(1))
+        # two renders instead of four (:385-397), textures shared by the whole batch through group indexing instead of
+        # being expanded to [bs,F,36,3]; mean over three identical channels (:386) == the channel
+        proj_a, _, _ = self.renderer(verts, faces, cams, self.stex123)
+        proj_b, _, _ = self.renderer(verts, faces, cams, self.stex4)
+        projs = [proj_a[:, 0:1], proj_a[:, 1:2], proj_a[:, 2:3], proj_b[:, 0:1]]
         bg = torch.full((bs, 1, self.im_size, self.im_size), 0.1, device=verts.device)
         proj = torch.cat([bg] + projs, dim=1)
         centers_proj = batch_get_centers(torch.softmax(proj, dim=1)[:, 1:, :, :])
