@@ -147,6 +147,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 #define FM_TH 4
 #endif
 #define FM_NQ (64 / (FM_TW * FM_TH))
+#ifndef FM_VCONST
+#define FM_VCONST 1
+#endif
 #ifndef FM_TEXMERGE
 #define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2
                        // (a third, vertical step measured slower)
@@ -215,6 +218,16 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     const int F = A.F, IS = A.IS, TS = A.TS;
     const bool pooled = COMMON ? true : (A.grad_pooled != 0);
     const bool two_sided = COMMON ? true : (A.double_side != 0);
+    // Wave-uniform float constants of the visit body, held in VGPRs on purpose: with the 32-float face record in SGPRs
+    // the scalar file is full, and every constant the allocator spills comes back as a v_readlane (VALU) per visit.
+    // As VALU operands they are as cheap from a VGPR.  (#define FM_VCONST 0 keeps them scalar for A/B.)
+#if FM_VCONST
+#define FM_V(x) ({ float v_; asm volatile("v_mov_b32 %0, %1" : "=v"(v_) : "s"(x)); v_; })
+#else
+#define FM_V(x) (x)
+#endif
+    const float c_near = FM_V(A.near_), c_far = FM_V(A.far_), c_rr = FM_V(A.r_range), c_ig = FM_V(A.inv_gamma);
+    const float c_thr2 = FM_V(A.threshold), c_nis = FM_V(A.nis);
     // XCD-aware: hardware XCD = blockIdx % 8.  Each XCD owns a fixed contiguous EIGHTH of every mesh's faces
     // (index-neighbouring faces of a subdivided mesh are spatial neighbours), so the per-pixel state its waves
     // re-read (~6x) covers 1/8 of the screen and stays in that XCD's 4 MB L2, and all 8 XCDs share every mesh
@@ -330,23 +343,23 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                                 const float smx = ld_u(ag_n, pn4 + pst);
                                 const float zmin_f = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
-                                                : ((A.far_ - zmin_f) * A.r_range - smx) * A.inv_gamma < -89.f;
+                                                : ((c_far - zmin_f) * c_rr - smx) * c_ig < -89.f;
                             }
                         }
                         if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;
                     }
                     Pair p;
-                    if (!eval_pair(p, fc, xp, yp, A.threshold, A.nis)) continue;
+                    if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis)) continue;
                     if (RGB == 2) {  // silhouette: d alpha only (:584, :632-642); soft_colors/grad are [N,IS,IS] | [N,H,H]
                         if (!fc.depth_in_range()) {
                             float u0, u1, u2;
                             const float zq = clip_depth(u0, u1, u2, p, fc);
-                            if (zq < A.near_ || zq > A.far_) continue;  // :592
+                            if (zq < c_near || zq > c_far) continue;  // :592
                         }
                         const float ga = (pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
                         const float oa = ld_u(sc_n, pn4);
                         float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
-                        c_a *= p.frag * (1.f - p.frag) * (-A.nis);
+                        c_a *= p.frag * (1.f - p.frag) * (-c_nis);
                         const float k2a = 2.f * p.sign * c_a;
                         const float a0 = k2a * p.b0, a1 = k2a * p.b1, a2 = k2a * p.b2;
                         gv[0] += a0 * p.dx; gv[1] += a0 * p.dy;
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                     if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
-                    if (zp < A.near_ || zp > A.far_) continue;  // :592
+                    if (zp < c_near || zp > c_far) continue;  // :592
                     float gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
                     if (RGB == 0) {
                         if (NEED_GT && (float)f == smax) {  // :596
@@ -372,8 +385,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             else texel_accumulate(my_tex, tix, g0, g1, g2, lane);
                         }
                     } else if (two_sided || fc.front()) {
-                        const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
-                        const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
+                        const float zn = div_r(c_far - zp, c_far - c_near, c_rr);
+                        const float ps = p.frag * __expf((zn - smax) * c_ig) * __builtin_amdgcn_rcpf(ssum);  // :608
                         const int tix = texel_index(q0, q1, A.R);
                         if (NEED_GT) {
                             if (TS == 1) { gt0 += ps * g0; gt1 += ps * g1; gt2 += ps * g2; }
@@ -387,14 +400,14 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             c_rgb += g2 * (ld_u(tx, t12 + 8) - ld_u(sc_n, pn4 + 2 * pst));
                             c_rgb *= ps;
                             c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
-                            const float c_z = -(c_rgb * A.inv_gamma * A.r_range) * zp * zp;  // :624
+                            const float c_z = -(c_rgb * c_ig * c_rr) * zp * zp;  // :624
                             gz0 = c_z * q0 * fc.g<R_RZ0>() * fc.g<R_RZ0>();
                             gz1 = c_z * q1 * fc.g<R_RZ1>() * fc.g<R_RZ1>();
                             gz2 = c_z * q2 * fc.g<R_RZ2>() * fc.g<R_RZ2>();
                         }
                     }
                     if (NEED_GF) {
-                        c_xy *= p.frag * (1.f - p.frag) * (-A.nis);  // :632
+                        c_xy *= p.frag * (1.f - p.frag) * (-c_nis);  // :632
                         const float k2 = 2.f * p.sign * c_xy;        // :640
                         const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
                         gv[0] += b0 * p.dx; gv[1] += b0 * p.dy; gv[2] += gz0;
