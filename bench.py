@@ -2,19 +2,22 @@
 """bench.py -- train images/sec of the UMR render-and-compare hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or
+    plain `python bench.py --gpus N`, which re-launches itself that way: one process per GPU, RCCL)
 
 One "step" = one pass of the hot path over one batch of synthetic CUB-shaped input per GPU:
 BASELINE.json configs[1] = train_s1, bs=16 per GPU, 256x256 images (512x512 internal raster),
 642-vertex / 1280-face mesh: 4 raster forwards + 3 raster backwards per image plus every geometric /
 image loss, forward and backward, producing gradients for vertices, cameras and texture flow
-(umr_amd/train_step.py mirrors experiments/train_s1.py:177-265).  With --model (default when the
-model module is present) the ResNet-18 MeshNet forward/backward, the RCCL gradient all-reduce and the
-Adam step are inside the timed region too.  Inputs are resident in HBM before the clock starts.
+(umr_amd/train_step.py mirrors experiments/train_s1.py:177-265, texture term = the AlexNet perceptual distance of
+train_s1.py:150).  With --model (default when the model module is present) the ResNet-18 MeshNet forward/backward,
+the RCCL gradient all-reduce (N > 1) and the Adam step are inside the timed region too.  Inputs are resident in HBM
+before the clock starts.
 
-Prints ONE JSON line (rank 0) with `roofline` (raster-backward kernel, HIP events recorded by
-libumr_hip.so on the launch stream during the timed steps) and `cpu_baseline` (the CPU oracle =
-reference algorithm, brute force, OpenMP over all host cores, on a bounded sample; rank 0, N=1 only).
+Prints ONE JSON line (rank 0) with `roofline` (raster-backward kernel: HIP events recorded by libumr_hip.so on the
+launch stream in a separate short pass AFTER the timed steps, so the event bookkeeping is not in `value`) and
+`cpu_baseline` (the CPU oracle = reference algorithm, brute force, OpenMP over all host cores, on a bounded sample;
+rank 0, N=1 only).
 """
 import argparse
 import json
@@ -46,26 +49,44 @@ def parse():
                     help="debug: create a 1-rank RCCL process group and wrap the model in DDP even when --gpus 1")
     ap.add_argument("--workload", default="s1", choices=["s1", "s2"],
                     help="s1 = BASELINE configs[1] (headline); s2 = train_s2 sequence of configs[2]/[3] (8 camera hypotheses)")
+    ap.add_argument("--epoch", type=int, default=0, help="train_s1 epoch (gates the symmetry / deformation terms)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="untimed steps with kernel events for `roofline`")
+    ap.add_argument("--master-port", type=int, default=29511)
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: start one rank per GPU of this node under
+    torch.distributed.run (RCCL rendezvous on 127.0.0.1) and pass its exit status on.  Rank 0 prints the JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def cpu_baseline(args, n_images):
-    """The reference algorithm on host cores: oracle/ (C raster, OpenMP over all cores + torch-CPU losses),
-    same train_s1 sequence, bounded sample of `n_images` images of the same workload."""
-    from oracle import softras
+    """The reference algorithm on host cores: oracle/ (C raster, OpenMP over all cores + torch-CPU losses incl. the
+    AlexNet perceptual texture term), same train_s1 sequence, bounded sample of `n_images` images of the same workload."""
+    from oracle import softras, torch_ref
     from oracle.train_step_ref import RenderCompareS1Ref
+    from umr_amd.perceptual import PNet
     from umr_amd.synthetic import make_s1_inputs
     cores = softras.max_threads()
     torch.set_num_threads(cores)
     tv, faces, outputs, batch = make_s1_inputs(n_images, args.image_size, args.subdivide, seed=1, device="cpu")
-    step = RenderCompareS1Ref(tv, faces, args.image_size, n_threads=cores)
+    step = RenderCompareS1Ref(tv, faces, args.image_size, n_threads=cores, epoch=getattr(args, "epoch", 0),
+                              texture_loss=torch_ref.PerceptualTextureLoss(PNet().state_dict()))
     t0 = time.perf_counter()
     total, _ = step(outputs, batch)
     total.backward()
     dt = time.perf_counter() - t0
     return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d image(s) of the same train_s1 step (4 raster fwd + 3 bwd per image + losses, fwd+bwd), "
-                      "%.1f s wall; network excluded on the CPU side" % (n_images, dt)}
+            "sample": "%d image(s) of the same train_s1 step (4 raster fwd + 3 bwd per image + all losses incl. the AlexNet "
+                      "perceptual texture term, fwd+bwd), %.1f s wall; MeshNet / discriminator / Adam excluded on the CPU "
+                      "side" % (n_images, dt)}
 
 
 def main():
@@ -73,17 +94,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (see module docstring)")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" = RCCL on ROCm
 
     from umr_amd import _lib
@@ -103,7 +124,9 @@ def main():
         from umr_amd.model import build_training_step
         step_fn = build_training_step(tv, faces, args, dev, 2 if args.force_ddp else world)
     else:
-        rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size).to(dev)
+        from umr_amd.perceptual import PerceptualTextureLoss
+        rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size, texture_loss=PerceptualTextureLoss(dev),
+                             epoch=args.epoch).to(dev)
         leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
 
         def step_fn():
@@ -126,23 +149,42 @@ def main():
     for _ in range(args.warmup):
         step_fn()
     barrier()
-    _lib.profile_enable(True)
-    _lib.profile_collect(0); _lib.profile_collect(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step_fn()
     host_dt = time.perf_counter() - t0          # time to ENQUEUE the steps (host side); dt below includes the drain
     barrier()
     dt = time.perf_counter() - t0
+    # roofline pass: the same steps again, untimed, with the library recording a HIP-event pair around every raster
+    # main kernel on its launch stream (event creation / bookkeeping stays out of `value`)
+    _lib.profile_enable(True)
+    for k in range(4):
+        _lib.profile_collect(k)
+    for _ in range(max(1, args.profile_steps)):
+        step_fn()
+    barrier()
     _lib.profile_enable(False)
-    b_ms, b_n, b_bytes = _lib.profile_collect(1)
-    f_ms, f_n, f_bytes = _lib.profile_collect(0)
+    prof = {k: _lib.profile_collect(k) for k in range(4)}   # 0 fwd, 1 bwd, 2 silhouette/id fwd, 3 silhouette bwd
+    b_ms, b_n, b_bytes = prof[1]
+    f_ms, f_n, f_bytes = prof[0]
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # evidence that the gradient exchange happened: after DDP's all-reduce every rank holds the same averaged
+    # gradients, so sum|g| agrees across ranks to the last bit (spread 0.0); reported with the rank count
+    grad_info = {}
+    model = getattr(step_fn, "model", None)
+    if model is not None:
+        gs = [p.grad.detach().double().abs().sum() for p in model.parameters() if p.grad is not None]
+        cs = torch.stack(gs).sum().reshape(1) if gs else torch.zeros(1, device=dev, dtype=torch.float64)
+        lo, hi = cs.clone(), cs.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        grad_info = {"grad_abs_sum": float(cs.item()), "grad_abs_sum_spread_over_ranks": float((hi - lo).item())}
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
@@ -150,7 +192,6 @@ def main():
         return
 
     images = args.batch * world * args.steps
-    achieved = (b_bytes / 1e9) / (b_ms / 1e3) if b_ms > 0 else 0.0
     # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
     # this very command, tools/collect_traffic.sh); bench.py cannot run the profiler on itself, so the committed
     # per-launch figure is attached when it was measured for the same workload, else null.
@@ -160,26 +201,44 @@ def main():
         tj = json.load(open(tpath))
         if args.workload == "s1" and tj.get("workload") == [args.batch, args.image_size, args.subdivide, bool(use_model)]:
             traffic = tj.get("raster_backward_bytes_per_launch")
+    rccl = {}
+    if world > 1 or args.force_ddp:
+        import torch.distributed as dist
+        rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+    rccl.update(grad_info)
+    net_note = ("; MeshNet fwd/bwd + %sAdam" % ("RCCL gradient all-reduce over %d ranks + " % world if world > 1 else "")
+                if use_model else "; network excluded")
+    if args.workload == "s1":
+        wl = ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: 4 raster fwd + 3 bwd per image (mask + "
+              "unseen-view silhouettes, textured soft-max render with p2f, hard visibility render) + IoU / AlexNet-perceptual "
+              "texture / texture-dt / tex-cycle / Laplacian / flatten / GAN losses, fwd+bwd, epoch %d%s"
+              % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], args.epoch, net_note))
+    else:
+        wl = ("train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: 20 raster fwd + 19 bwd per "
+              "image (8 mask, 8 texture, 1 visibility, 1 unseen view, 2 part renders carrying the reference's 4) + mask / "
+              "AlexNet-perceptual texture / tex-cycle / part / chamfer losses, fwd+bwd%s"
+              % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], net_note))
+
+    def kernel_line(k):
+        ms, n, nbytes = prof[k]
+        gbs = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        return {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": n, "avg_us": (1e3 * ms / n) if n else None,
+                "alg_bytes_per_launch": (nbytes / n) if n else None}
+
     out = {
         "metric": METRIC, "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: 4 raster fwd + 3 bwd "
-                                "per image + IoU/texture/tex-cycle/Laplacian/flatten losses, fwd+bwd%s"
-                                if args.workload == "s1" else
-                                "train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: 22 raster "
-                                "fwd + 21 bwd per image + mask/perceptual-texture/tex-cycle/part/chamfer losses, fwd+bwd%s")
-                               % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
-                                  "; MeshNet fwd/bwd + RCCL all-reduce + Adam" if use_model else "; network excluded"),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "includes_network": use_model,
-                   "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
-                   "final_loss": float(loss.detach())},
-        "roofline": {"bound": "hbm", "kernel": "k_raster_backward", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "launches": b_n, "avg_us": (1e3 * b_ms / b_n) if b_n else None,
-                     "alg_bytes_per_launch": (b_bytes / b_n) if b_n else None,
-                     "forward_kernel": {"achieved": (f_bytes / 1e9) / (f_ms / 1e3) if f_ms > 0 else 0.0,
-                                        "launches": f_n, "avg_us": (1e3 * f_ms / f_n) if f_n else None}},
+        "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                        "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+                        "final_loss": float(loss.detach())}, **rccl),
+        # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
+        # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the
+        # variant touches, once) / its mean HIP-event duration over the profile pass.
+        "roofline": dict({"bound": "hbm", "kernel": "k_raster_backward_fm (textured render)", "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "traffic": traffic}, **kernel_line(1),
+                         forward_kernel=kernel_line(0), silhouette_forward=kernel_line(2),
+                         silhouette_backward=kernel_line(3)),
     }
     want_cpu = (world == 1 and args.workload == "s1") if args.cpu_baseline < 0 else bool(args.cpu_baseline)
     if want_cpu:

@@ -32,6 +32,8 @@ extern "C" {
 
 /* library / build identification: returns e.g. "umr_hip 0.1 gfx950" */
 const char *umr_version(void);
+/* hash of the sources this binary was compiled from (umr_amd/build.py:source_hash); "unknown" for ad-hoc builds */
+const char *umr_build_id(void);
 
 /* Optional kernel timing for benchmarks.  While enabled, every raster main-kernel launch is bracketed by
  * library-owned HIP events recorded on the launch stream.  umr_profile_collect(which) waits for the
@@ -147,6 +149,24 @@ int umr_project_faces_backward(const float *grad_face_out, const float *grad_fac
                                int N, int V, int F, int mesh_group, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* The same projection with the per-face surface light of sr.Lighting folded in (external/SoftRas/soft_renderer/
+ * lighting.py:50-57 = ambient_lighting.py:17 + directional_lighting.py:26-27 on mesh.py:111-118's face normals):
+ *   light_out [N,F,3] = ambient * color + directional * color * relu(n . direction),
+ *   n = normalize(cross(p2 - p1, p0 - p1), eps 1e-6) on the pre-look_at corners (light_out may be NULL = skip).
+ * color / direction: HOST float[3] (NULL = (1,1,1) / (0,1,0), the renderer.py:58-60 defaults).  The caller multiplies
+ * textures [N,F,TS,3] by light_out[:, :, None, :] (lighting.py:56).
+ * backward: grad_light [N,F,3] (may be NULL) is chained through the normal into the corner gradients; it needs
+ *   face_out as written by the forward. */
+int umr_project_faces_lit_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
+                                  float *face_out, float *light_out, int N, int V, int F, float offset_z, float eye_z,
+                                  int mesh_group, float light_ambient, float light_directional, const float *light_color3,
+                                  const float *light_direction3, void *stream);
+int umr_project_faces_lit_backward(const float *grad_face_out, const float *grad_face_pre, const float *grad_light,
+                                   const float *face_out, const float *verts, const float *cams, const int *faces_idx,
+                                   float *grad_verts, float *grad_cams, int N, int V, int F, int mesh_group,
+                                   float light_directional, const float *light_color3, const float *light_direction3,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* Camera rotated about the y axis by angle_deg [B] degrees: geom_utils.rotate_cam(cam, angle, axis=[0,1,0])
  * (nnutils/geom_utils.py:167-193, a per-sample numpy / cv2.Rodrigues / quaternion_from_matrix round trip through the
  * host in the reference; call sites experiments/train_s1.py:233, train_s2.py:257).  cam, out [B,7]; forward only
@@ -228,6 +248,50 @@ int umr_flatten_backward(const float *x, const int *quads, const float *grad_los
  *   mask must arrive zero-filled.
  * -------------------------------------------------------------------------------------------*/
 int umr_visible_face_mask(const float *face_ids, float *mask, int B, long P, int F, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Perceptual distance head.  Replaces the torch chain of
+ *   external/PerceptualSimilarity/models/networks_basic.py:42-64 (PNet.forward after the feature taps: sum over taps of
+ *   1 - cos_sim) and external/PerceptualSimilarity/util/util.py:71-83 (normalize_tensor with eps 1e-10, channel dot
+ *   product, mean over x then y), reached from nnutils/loss_utils.py:128-150 (PerceptualTextureLoss) through
+ *   nnutils/perceptual_loss.py:38-57.  The dense convolutions producing the taps stay on MIOpen.
+ *     ntaps <= UMR_COS_MAX_TAPS feature pairs; tap t: f0[t], f1[t] are [N, C[t], P[t]] (P = X*Y, NCHW contiguous)
+ *     val [N] = sum_t ( 1 - mean_p  <f0,f1>_p / ((|f0|_p + eps)(|f1|_p + eps)) )          (overwritten)
+ *   backward: g0[t] / g1[t] (either array, or single entries, may be NULL) are overwritten with
+ *     grad_val[n] * d val[n] / d f; a zero feature vector gets d|f|/df := 0 (torch: NaN).
+ *   f0/f1/g0/g1/C/P are HOST arrays of length ntaps (device pointers inside).
+ *   workspace: umr_cos_sim_workspace_bytes(); forward writes per-pixel statistics there that backward reads.
+ * -------------------------------------------------------------------------------------------*/
+#define UMR_COS_MAX_TAPS 8
+#define UMR_COS_CHUNKS 16
+size_t umr_cos_sim_workspace_bytes(int ntaps, int N, const int *P);
+int umr_cos_sim_forward(int ntaps, const float *const *f0, const float *const *f1, const int *C, const int *P, int N,
+                        float eps, float *val, void *workspace, size_t workspace_bytes, void *stream);
+int umr_cos_sim_backward(int ntaps, const float *const *f0, const float *const *f1, float *const *g0, float *const *g1,
+                         const int *C, const int *P, int N, float eps, const float *grad_val, const void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part-matching reductions.  Replaces everything after the part renders in nnutils/loss_utils.py:399-440
+ * (part_matching_loss.forward, loss_type 'mse') including nnutils/scops_utils.py:12-54 (batch_get_centers):
+ *   proj = [background (const), p1, p2, p3, p4] with p1..p3 = channels 0..2 of render_a, p4 = channel 0 of render_b
+ *          (both [B,4,H,W], the renderer's output; the reference renders each part three times over, :357-397)
+ *   l_lm[b]  = sum_{c=1..4} | centroid(softmax(proj)_c) - centroid(softmax(part_segs)_c) |^2      (centroids of the
+ *              maps + center_eps, normalised to sum 1, coordinates col/H*2-1, row/W*2-1 as scops_utils.py:12-16)
+ *   l_eqv[b] = sum_{c=0..4} sum_pixels w_c (proj_c / max(max_p proj_c, 1e-5) - part_c / max(max_p part_c, 1e-5))^2
+ * The caller forms (mean(l_eqv)/(5 H W) + mean(l_lm)/8) / 4 (avg=True) or the cam-prob weighted sums (avg=False).
+ * backward: grad_render_a / grad_render_b [B,4,H,W] must arrive zero-filled; planes 0..2 of a and plane 0 of b are
+ *   overwritten with d(sum_b g_eqv[b] l_eqv[b] + g_lm[b] l_lm[b])/d render, the max term routed to the first arg-max.
+ * workspace: umr_part_match_workspace_bytes(B, H, W); forward leaves the statistics there that backward reads.
+ * -------------------------------------------------------------------------------------------*/
+size_t umr_part_match_workspace_bytes(int B, int H, int W);
+int umr_part_match_forward(const float *render_a, const float *render_b, const float *part_segs, int B, int H, int W,
+                           const float *weights5, float background, float center_eps, float *l_eqv, float *l_lm,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int umr_part_match_backward(const float *render_a, const float *render_b, const float *part_segs, int B, int H, int W,
+                            const float *weights5, float background, float center_eps, const float *grad_l_eqv,
+                            const float *grad_l_lm, float *grad_render_a, float *grad_render_b, const void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Barrier distance transform.  Replaces utils/image.py:130-141 (compute_dt_barrier), two scipy EDTs per image per

@@ -176,9 +176,74 @@ def gen_save_obj(lib):
     print("save_obj golden:", captured["png"].shape, len(obj_tex), "bytes of OBJ")
 
 
+def gen_part_loss_and_cos_grads(loss_utils, ps_spec):
+    """(viii) tests/golden/part_loss_and_cos_grads.npz, run by `python oracle/gen_golden.py --only part_cos`:
+      * part_matching_loss.forward (nnutils/loss_utils.py:380-440) UNBOUND on a stand-in `self` that carries only what
+        forward reads (renderer -> queued images, the stex buffers it passes through, proj, weights, loss_type): the class
+        constructor needs scipy.misc.imread and the undistributed SCOPS template, forward itself is plain torch.  The
+        "renders" are random images so every reduction after them is exercised, with one part invisible in one sample
+        (max < 1e-5 branch, :418-419); values and gradients wrt the rgb-mean planes for avg=True and the cam_probs path;
+      * util.cos_sim (external/PerceptualSimilarity/util/util.py:71-83) summed as PNet.forward does
+        (networks_basic.py:50-58): values and autograd gradients wrt both feature stacks."""
+    torch.Tensor.get_device = lambda self: "cpu"            # :411 `.to(cam_probs.get_device())` on a GPU-less host
+    g = torch.Generator().manual_seed(20260926)
+    B, H = 4, 32
+    imgs = [torch.rand(B, 4, H, H, generator=g) * torch.rand(B, 1, 1, 1, generator=g) for _ in range(4)]
+    imgs[2][1, 0:3] = 0.0                                     # part 3 invisible in sample 1
+    imgs = [i.requires_grad_(True) for i in imgs]
+    part_segs = (torch.randn(B, 5, H, H, generator=g) * 2).contiguous()
+    part_segs[3, 2] = -1.0                                    # a constant negative plane: max_part < 1e-5 branch
+
+    class _Self:
+        pass
+
+    def run(avg, cam_probs):
+        st = _Self()
+        q = list(imgs)
+        st.renderer = lambda verts, faces, cams, tex: (q.pop(0), None, None)
+        st.stex1 = st.stex2 = st.stex3 = st.stex4 = torch.zeros(B, 1)
+        st.proj = torch.full((B, 1, H, H), 0.1)
+        st.weights = torch.tensor([0, 5.0, 0.0, 0.0, 5.0]).view(1, 5, 1, 1)
+        st.loss_type = 'mse'
+        for i in imgs:
+            i.grad = None
+        loss, projs = loss_utils.part_matching_loss.forward(st, torch.zeros(B, 1), None, None, part_segs, cam_probs, avg)
+        loss.backward()
+        # gradient wrt the rgb-mean plane = sum of the gradients of its three channels
+        return loss.detach(), torch.stack([i.grad[:, 0:3].sum(1) for i in imgs], 1), projs
+
+    loss_avg, grad_avg, projs = run(True, None)
+    probs = torch.softmax(torch.randn(2, 2, generator=g), 1)
+    loss_w, grad_w, _ = run(False, probs)
+    planes = torch.cat([p.detach() for p in projs], 1)        # [B,4,H,H] rgb means, the quantity the loss consumes
+    ps_util_src = open(ps_spec.origin).read()
+    ns = {"torch": torch, "np": np}
+    start = ps_util_src.index("def normalize_tensor"); end = ps_util_src.index("# Converts a Tensor into a Numpy array")
+    exec(compile(ps_util_src[start:end], ps_spec.origin, "exec"), ns)
+    shapes = ((8, 7, 7), (16, 5, 5), (12, 3, 6))
+    f0 = [torch.randn(3, *sh, generator=g).relu().requires_grad_(True) for sh in shapes]
+    f1 = [torch.randn(3, *sh, generator=g).relu().requires_grad_(True) for sh in shapes]
+    val = 0
+    for kk in range(len(f0)):
+        cur = (1. - ns["cos_sim"](f0[kk], f1[kk]))
+        val = 1. * cur if kk == 0 else val + cur               # networks_basic.py:53-58
+    gv = torch.rand(3, generator=g) + 0.5
+    (val * gv).sum().backward()
+    out = dict(planes=np_(planes), part_segs=np_(part_segs), loss_avg=np_(loss_avg), grad_avg=np_(grad_avg),
+               cam_probs=np_(probs), loss_weighted=np_(loss_w), grad_weighted=np_(grad_w), cos_val=np_(val), cos_gv=np_(gv))
+    for k in range(len(f0)):
+        out.update({"cf0_%d" % k: np_(f0[k]), "cf1_%d" % k: np_(f1[k]), "cg0_%d" % k: np_(f0[k].grad),
+                    "cg1_%d" % k: np_(f1[k].grad)})
+    np.savez_compressed(os.path.join(OUT, "part_loss_and_cos_grads.npz"), **out)
+    print("part_loss_and_cos_grads.npz: loss_avg %.6f loss_weighted %.6f cos %s" % (float(loss_avg), float(loss_w), np_(val)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     lib, sr, smr, loss_utils, geom_utils, chamfer_python, scops_utils, ps_spec = install_reference()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "part_cos":
+        gen_part_loss_and_cos_grads(loss_utils, ps_spec)
+        return
     sys.path.insert(0, ROOT)
     from oracle import softras  # only for its ctypes helper on the ref .so
     if sys.argv[1:] == ["save_obj"]:

@@ -1,7 +1,7 @@
 """ctypes front-end for the CPU raster oracle -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
-Nothing under umr_amd/ does (tests/test_no_oracle_in_product.py enforces it).
+Nothing under umr_amd/ does (tests/test_cabi_and_layout.py::test_product_never_imports_the_oracle enforces it).
 
 Two back-ends with one calling convention (that of the reference binding,
 external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda.cpp:62-138):

@@ -350,6 +350,46 @@ def cos_sim_distance(feats0, feats1, eps=1e-10):
     return val
 
 
+def alexnet_taps(x, state_dict):
+    """torchvision `alexnet().features` cut after each of the five ReLUs
+    (external/PerceptualSimilarity/models/pretrained_networks.py:59-95: slices [0,2) [2,5) [5,8) [8,10) [10,12)),
+    evaluated with plain F.conv2d / F.max_pool2d on the weights of `state_dict`
+    (keys `net.slices.<i>.<j>.{weight,bias}` as umr_amd.perceptual.PNet stores them)."""
+    w = lambda i, j, n: state_dict["net.slices.%d.%d.%s" % (i, j, n)].detach().to(x.dtype).cpu()
+    outs = []
+    x = F.relu(F.conv2d(x, w(0, 0, "weight"), w(0, 0, "bias"), stride=4, padding=2)); outs.append(x)
+    x = F.relu(F.conv2d(F.max_pool2d(x, 3, 2), w(1, 1, "weight"), w(1, 1, "bias"), stride=1, padding=2)); outs.append(x)
+    x = F.relu(F.conv2d(F.max_pool2d(x, 3, 2), w(2, 1, "weight"), w(2, 1, "bias"), stride=1, padding=1)); outs.append(x)
+    x = F.relu(F.conv2d(x, w(3, 0, "weight"), w(3, 0, "bias"), stride=1, padding=1)); outs.append(x)
+    x = F.relu(F.conv2d(x, w(4, 0, "weight"), w(4, 0, "bias"), stride=1, padding=1)); outs.append(x)
+    return outs
+
+
+class PerceptualTextureLoss:
+    """nnutils/loss_utils.py:128-150 -> nnutils/perceptual_loss.py:38-57 (inputs 2x-1, forward_pair(target, pred)) ->
+    networks_basic.py:13-64 (shift / scale, AlexNet taps, sum of 1 - cos_sim).  The pretrained weights are not
+    obtainable offline: `state_dict` carries whatever weights the HIP-side PNet was given."""
+
+    def __init__(self, state_dict):
+        self.sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        self.shift = torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1)
+        self.scale = torch.tensor([.458, .448, .450]).view(1, 3, 1, 1)
+
+    def dist(self, pred, target):
+        in0, in1 = 2 * target - 1, 2 * pred - 1
+        f0 = alexnet_taps((in0 - self.shift) / self.scale, self.sd)
+        f1 = alexnet_taps((in1 - self.shift) / self.scale, self.sd)
+        return cos_sim_distance(f0, f1)
+
+    def __call__(self, img_pred, img_gt, mask_gt, mask_pred=None, avg=True):
+        mask_gt = mask_gt.unsqueeze(1)
+        if mask_pred is not None:
+            d = self.dist(img_pred * mask_pred.unsqueeze(1), img_gt * mask_gt)
+        else:
+            d = self.dist(img_pred * mask_gt, img_gt * mask_gt)
+        return d.mean() if avg else d
+
+
 def compute_dt_barrier(mask, k=50):
     """utils/image.py:130-141 (numpy + scipy; scipy is the EDT oracle)."""
     from scipy.ndimage import distance_transform_edt

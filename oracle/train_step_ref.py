@@ -22,9 +22,15 @@ def rotate_cam_y(cam, angle_deg):
 
 
 class RenderCompareS1Ref:
-    def __init__(self, template_verts, faces, image_size=256, weights=None, n_threads=1, backend="port"):
+    def __init__(self, template_verts, faces, image_size=256, weights=None, n_threads=1, backend="port",
+                 texture_loss=None, epoch=0):
+        """texture_loss: callable(img_pred, img_gt, mask_gt, mask_pred) (TR.PerceptualTextureLoss in the reference,
+        train_s1.py:150); None = the masked L1 of loss_utils.py:103-116.  epoch: train_s1.py:250-255 gates the
+        symmetry term (epoch < stop_ori_epoch) and the deformation term (epoch > update_template_freq)."""
         from umr_amd.train_step import S1Weights  # plain constants (reference flag defaults)
         self.w = weights or S1Weights()
+        self.texture_loss = texture_loss or TR.texture_loss_masks
+        self.epoch = epoch
         self.faces = faces.long()
         mk = lambda kind: TR.SoftRenderer(image_size, kind, backend=backend, n_threads=n_threads)
         self.renderer, self.dis_renderer, self.hard_renderer, self.tex_renderer = mk("softmax"), mk("softmax"), mk("hard"), mk("softmax")
@@ -50,26 +56,32 @@ class RenderCompareS1Ref:
         bs, fs = tex.shape[:2]
         tex = tex.view(bs, fs, -1, 3)
         rgba, p2f, _ = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex)
-        t["tex"] = TR.texture_loss_masks(rgba[:, :3], imgs, masks, mask_pred_seen)
+        t["tex"] = self.texture_loss(rgba[:, :3], imgs, masks, mask_pred_seen)
         t["tex_dt"] = TR.texture_dt_loss(tex_flow, dts)
         _, _, aggr = self.hard_renderer(pred_vs.detach(), faces, proj_cam.detach())
         t["tex_cycle"], _ = TR.tex_cycle(tex_flow, p2f.detach(), aggr[:, 1].reshape(bs, -1).detach())
         pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, rotate_cam_y(proj_cam.detach(), batch["gan_angles"]))
         t["gan"] = pred_unseen[:, 3].mean()
-        total = t["mask"] * w.mask_loss_wt + t["triangle"] * w.triangle_reg_wt + t["flatten"] * w.flatten_reg_wt \
-            + t["ori"] * w.ori_reg_wt + t["deform"] * w.deform_reg_wt + t["tex"] * w.tex_loss_wt \
-            + t["tex_dt"] * w.tex_dt_loss_wt + t["tex_cycle"] * w.tex_cycle_loss_wt + t["gan"] * w.gan_loss_wt
+        total = t["mask"] * w.mask_loss_wt + t["triangle"] * w.triangle_reg_wt + t["flatten"] * w.flatten_reg_wt
+        if self.epoch < w.stop_ori_epoch:            # train_s1.py:250-252
+            total = total + t["ori"] * w.ori_reg_wt
+        if self.epoch > w.update_template_freq:      # train_s1.py:253-255
+            total = total + t["deform"] * w.deform_reg_wt
+        total = total + t["tex"] * w.tex_loss_wt + t["tex_dt"] * w.tex_dt_loss_wt \
+            + t["tex_cycle"] * w.tex_cycle_loss_wt + t["gan"] * w.gan_loss_wt
         return total, t
 
 
 class RenderCompareS2Ref:
-    """experiments/train_s2.py:201-316 on the oracle, term by term as umr_amd.train_step.RenderCompareS2 with
-    texture_loss_type='l1' (masked L1, nnutils/loss_utils.py:103-116) and no discriminator network."""
+    """experiments/train_s2.py:201-316 on the oracle, term by term as umr_amd.train_step.RenderCompareS2, no
+    discriminator network.  texture_loss: callable(img_pred, img_gt, mask_gt, mask_pred, avg=False) -- the reference's
+    MultiTextureLoss uses PerceptualTextureLoss (loss_utils.py:291-292); None = masked L1 (loss_utils.py:103-116)."""
 
     def __init__(self, template_verts, faces, part_vertex_ids, uv_img, uv_sampler, image_size=256, num_hypo_cams=8,
-                 weights=None, n_threads=1, backend="port", tex_size=6):
+                 weights=None, n_threads=1, backend="port", tex_size=6, texture_loss=None):
         from umr_amd.train_step import S2Weights
         self.w = weights or S2Weights()
+        self.texture_loss = texture_loss or TR.texture_loss_masks
         self.K, self.image_size = num_hypo_cams, image_size
         self.faces = faces.long()
         mk = lambda kind: TR.SoftRenderer(image_size, kind, backend=backend, n_threads=n_threads)
@@ -107,7 +119,7 @@ class RenderCompareS2Ref:
         tex = tex.view(bs, fs, -1, 3)
         rep = lambda x: x.unsqueeze(1).repeat(1, K, *([1] * (x.dim() - 1))).view(-1, *x.shape[1:])
         rgba, _, _ = self.tex_r(rep(pred_vs.detach()), rep(faces), cams_all.detach().view(-1, 7), rep(tex))
-        tl = TR.texture_loss_masks(rgba[:, :3], rep(imgs), rep(masks), mask_all, avg=False)
+        tl = self.texture_loss(rgba[:, :3], rep(imgs), rep(masks), mask_all, avg=False)
         t["tex"] = (tl.view(bs, -1) * probs.detach()).sum(dim=1).mean()
         t["tex_dt"] = TR.texture_dt_loss(tex_flow, batch["dts_barrier"])
         _, p2f, aggr = self.hard_r(pred_vs.detach(), faces, proj_cam)

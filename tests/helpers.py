@@ -29,9 +29,28 @@ def assert_close_frac(got, ref, atol, rtol=0.0, frac=0.999, max_outlier=None, na
     err = np.abs(got - ref)
     ok = err <= atol + rtol * np.abs(ref)
     f = ok.mean() if ok.size else 1.0
+    _record(name, got.size, f, float(err.max()) if err.size else 0.0, atol, rtol, frac, max_outlier)
     assert f >= frac, "%s: only %.5f within tol (max err %.3e, atol %.1e rtol %.1e)" % (name, f, err.max(), atol, rtol)
     if max_outlier is not None and err.size:
         assert err.max() <= max_outlier, "%s: outlier %.3e > %.3e" % (name, err.max(), max_outlier)
+
+
+def _record(name, n, frac_ok, max_err, atol, rtol, need, max_outlier):
+    """Measured parity figures, one JSON line per check: printed (pytest -s / failure reports) and appended to
+    gpurun_out/parity_measured.jsonl so the numbers behind every tolerance are on file (profiles/r02_parity_measured.jsonl)."""
+    import json
+    import os
+    rec = dict(check=name, test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], elements=int(n),
+               frac_within=float(frac_ok), max_abs_err=float(max_err), atol=float(np.max(atol)), rtol=float(rtol),
+               frac_required=float(need), max_outlier_allowed=None if max_outlier is None else float(max_outlier))
+    print("[parity] " + json.dumps(rec))
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.jsonl"), "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
 
 
 def t2n(x):

@@ -27,8 +27,10 @@ def test_library_builds_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(h, s), "missing export %s" % s
     # and the ctypes prototype table covers the same set
-    assert set(_lib.SIGNATURES) | {"umr_version"} == set(syms)
+    assert set(_lib.SIGNATURES) | {"umr_version", "umr_build_id"} == set(syms)
     assert _lib.version().startswith("umr_hip")
+    from umr_amd import build
+    assert _lib.build_id() == build.source_hash()      # the library on disk was compiled from the sources on disk
 
 
 def test_product_never_imports_the_oracle():
@@ -58,22 +60,18 @@ def test_size_queries_need_no_gpu():
     assert L.umr_project_workspace_bytes(2, 642) == 2 * 642 * 12
 
 
-def test_host_side_helpers_vs_reference_goldens():
-    """Pure-torch host logic that replaces reference python loops: vectorised SCOPS centroids, PNet cosine head,
-    on-device camera rotation."""
-    import numpy as np
-    from conftest import load_golden
-    from umr_amd.loss_utils import batch_get_centers
-    from umr_amd.perceptual import cos_sim
-    g = load_golden("parts_and_cossim.npz")
-    pm = torch.from_numpy(g["part_maps"]).requires_grad_(True)
-    cen = batch_get_centers(pm[:, 1:])
-    np.testing.assert_allclose(cen.detach().numpy(), g["centers"], atol=1e-6)
-    cen.backward(torch.ones_like(cen))
-    np.testing.assert_allclose(pm.grad.numpy(), g["grad_part_maps"], atol=1e-7, rtol=1e-4)
-    f0 = [torch.from_numpy(g["f0_0"]), torch.from_numpy(g["f0_1"])]
-    f1 = [torch.from_numpy(g["f1_0"]), torch.from_numpy(g["f1_1"])]
-    np.testing.assert_allclose(sum(1. - cos_sim(a, b) for a, b in zip(f0, f1)).numpy(), g["cos_dist"], atol=1e-6)
+def test_fused_loss_heads_have_no_eager_fallback():
+    """The PNet distance head and the part-matching reductions are HIP kernels (csrc/perceptual.hip); handed CPU tensors
+    they must refuse loudly instead of computing with eager torch (their CPU restatements live in oracle/ only)."""
+    from umr_amd.perceptual import cos_sim_distance
+    from umr_amd.functional import PartMatchFunction
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        cos_sim_distance([torch.zeros(1, 4, 3, 3)], [torch.zeros(1, 4, 3, 3)])
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        PartMatchFunction.apply(torch.zeros(1, 4, 8, 8), torch.zeros(1, 4, 8, 8), torch.zeros(1, 5, 8, 8),
+                                (0., 5., 0., 0., 5.), 0.1, 1e-3)
+    import umr_amd.loss_utils as LU
+    assert not hasattr(LU, "batch_get_centers")       # the eager centroid helper is gone from the product
 
 
 def test_symmetric_mesh_counts_match_reference_constants():
@@ -157,11 +155,36 @@ def test_checkpoint_and_obj_formats(tmp_path):
     path = io_utils.save_network(torch.nn.DataParallel(a), "pred", "latest", str(tmp_path))
     assert path.endswith("pred_net_latest.pth")
     sd = torch.load(path)
-    assert not any(k.startswith("module.") for k in sd) and "encoder.resnet_conv.conv1.weight" in sd
+    assert not any(k.startswith("module.") for k in sd)
+    # state_dict keys are the reference's (nnutils/cub_mesh.py: ResNetConv.resnet :56, Encoder :87-99, ShapePredictor.pred_layer
+    # :176, Camera :281-290, TexturePredictorUV :136-141, buffers mean_v :395 / uv_sampler :431), so .pth files interchange
+    ref_keys = ["encoder.resnet_conv.resnet.conv1.weight", "encoder.resnet_conv.resnet.bn1.running_mean",
+                "encoder.resnet_conv.resnet.layer1.0.conv1.weight", "encoder.resnet_conv.resnet.layer2.0.downsample.0.weight",
+                "encoder.resnet_conv.resnet.layer4.1.bn2.weight", "encoder.resnet_conv.resnet.fc.weight",
+                "encoder.enc_conv1.0.weight", "encoder.enc_conv1.1.running_var", "encoder.enc_fc.0.0.weight",
+                "encoder.enc_fc.1.1.weight", "encoder.mean_fc.0.weight", "encoder.mean_fc.2.bias", "encoder.logvar_fc.2.weight",
+                "shape_predictor.pred_layer.weight", "shape_predictor.pred_layer.bias",
+                "cam_predictor.fc_layer.0.0.weight", "cam_predictor.quat_predictor.pred_layer.bias",
+                "cam_predictor.prob_predictor.weight", "cam_predictor.scale_predictor.pred_layer.weight",
+                "cam_predictor.trans_predictor.pred_layer.bias", "texture_predictor.enc.0.0.weight",
+                "texture_predictor.decoder.0.2.weight", "texture_predictor.decoder.1.0.weight", "mean_v", "uv_sampler"]
+    assert [k for k in ref_keys if k not in sd] == []
+    assert "faces" not in sd and "flip" not in sd                      # plain attributes in the reference (:399, :409)
+    multi = MeshNet((64, 64), default_opts(subdivide=1, nz_feat=16, z_dim=8, multiple_cam_hypo=True), nz_feat=16).state_dict()
+    for k in ("cam_predictor.fc.0.0.weight", "cam_predictor.camera_predictor.7.quat_predictor.pred_layer.weight",
+              "cam_predictor.camera_predictor.0.fc_layer.1.1.running_mean", "cam_predictor.scale_predictor.pred_layer.weight",
+              "cam_predictor.trans_predictor.pred_layer.weight", "cam_predictor.quat_predictor.pred_layer.bias",
+              "cam_predictor.cam_biases"):                             # cub_mesh.py:309-332
+        assert k in multi, k
+    assert multi["cam_predictor.prob_predictor.weight"].shape == (8, 16) and multi["cam_predictor.cam_biases"].shape == (8, 4)
     b = MeshNet((64, 64), opts, nz_feat=16)
     loaded = io_utils.load_network(b, "pred", "latest", str(tmp_path))
-    assert "uv_sampler" not in loaded and "shape_predictor.weight" in loaded
-    assert torch.equal(a.shape_predictor.weight, b.shape_predictor.weight)
+    assert "uv_sampler" not in loaded and "shape_predictor.pred_layer.weight" in loaded
+    assert torch.equal(a.shape_predictor.pred_layer.weight, b.shape_predictor.pred_layer.weight)
+    # a checkpoint whose keys do not match is an error, not a silent random-init model
+    torch.save({"encoder.resnet_conv.layers.0.weight": torch.zeros(1)}, str(tmp_path / "bad_net_latest.pth"))
+    with pytest.raises(RuntimeError, match="not loaded"):
+        io_utils.load_network(b, "bad", "latest", str(tmp_path))
     io_utils.save_obj(str(tmp_path / "m.obj"), a.get_mean_shape(), a.faces)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "save_obj.npz"))   # written by the reference
     io_utils.save_obj(str(tmp_path / "plain.obj"), torch.from_numpy(g["verts"]), torch.from_numpy(g["faces"]))

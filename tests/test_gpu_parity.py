@@ -170,7 +170,7 @@ def test_backward_is_linear_in_upstream_gradient():
     from umr_amd import functional as UF
     verts, faces, cams, gen = scene(2, 3, seed=9)
     from umr_amd.functional import ProjectFacesFunction
-    _, fv = ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    _, fv, _ = ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
     tex = torch.rand(2, 1280, 36, 3, generator=gen).to(DEV)
     g1 = torch.randn(2, 4, 512, 512, generator=gen).to(DEV)
     g2 = torch.randn(2, 4, 512, 512, generator=gen).to(DEV)
@@ -282,7 +282,7 @@ def test_empty_scene_and_offscreen_mesh():
     from umr_amd import functional as UF
     verts, faces, cams, gen = scene(1, 1, seed=3)
     from umr_amd.functional import ProjectFacesFunction
-    _, fv = ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    _, fv, _ = ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
     off = (fv + torch.tensor([5.0, 0, 0], device=DEV)).detach().requires_grad_(True)
     tex = torch.rand(1, 80, 1, 3, device=DEV)
     sc, p2f, aggr = UF.soft_rasterize(off, tex, 50, [0.25, 0.5, 0.75], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
@@ -335,7 +335,7 @@ def test_face_major_backward_non_pow2_and_determinism():
     """IS not a power of two exercises the fp64 pixel-centre path; face-major results are run-to-run identical."""
     from umr_amd import functional as UF
     verts, faces, cams, gen = scene(2, 2, seed=21)
-    _, fv = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
     tex = torch.rand(2, 320, 4, 3, generator=gen).to(DEV)
     g = torch.randn(2, 4, 100, 100, generator=gen).to(DEV)
 

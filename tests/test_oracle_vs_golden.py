@@ -186,6 +186,49 @@ def test_parts_and_cossim_restatement():
     np.testing.assert_allclose(torch_ref.cos_sim_distance(f0, f1).numpy(), g["cos_dist"], atol=1e-6)
 
 
+def test_part_matching_and_cos_sim_gradients_restatement():
+    """oracle restatements of part_matching_loss's reductions (loss_utils.py:399-440) and of the PNet head
+    (networks_basic.py:50-58 + util.py:71-83) against values AND gradients produced by the reference's own code
+    (oracle/gen_golden.py --only part_cos)."""
+    from oracle import torch_ref
+    g = load_golden("part_loss_and_cos_grads.npz")
+    planes = torch.from_numpy(g["planes"]).requires_grad_(True)
+    parts = torch.from_numpy(g["part_segs"])
+    loss = torch_ref.part_matching_core([planes[:, k:k + 1] for k in range(4)], parts)
+    np.testing.assert_allclose(float(loss), float(g["loss_avg"]), rtol=1e-6)
+    loss.backward()
+    np.testing.assert_allclose(planes.grad.numpy(), g["grad_avg"], atol=1e-9, rtol=1e-4)
+    f0 = [torch.from_numpy(g["cf0_%d" % k]).requires_grad_(True) for k in range(3)]
+    f1 = [torch.from_numpy(g["cf1_%d" % k]).requires_grad_(True) for k in range(3)]
+    val = torch_ref.cos_sim_distance(f0, f1)
+    np.testing.assert_allclose(val.detach().numpy(), g["cos_val"], atol=1e-6)
+    (val * torch.from_numpy(g["cos_gv"])).sum().backward()
+    for k in range(3):
+        np.testing.assert_allclose(f0[k].grad.numpy(), g["cg0_%d" % k], atol=1e-7, rtol=1e-4)
+        np.testing.assert_allclose(f1[k].grad.numpy(), g["cg1_%d" % k], atol=1e-7, rtol=1e-4)
+
+
+def test_perceptual_texture_loss_restatement_consistency():
+    """oracle.torch_ref.PerceptualTextureLoss (the CPU side of the step-level parity tests) against a second formulation:
+    nn.Module AlexNet taps (umr_amd.perceptual.AlexNetFeatures evaluated on CPU tensors by torch itself -- no HIP code
+    involved) + the golden-pinned cos_sim_distance.  Pins the weight-key mapping and the shift / scale / 2x-1 prologue."""
+    from oracle import torch_ref
+    from umr_amd.perceptual import PNet
+    torch.manual_seed(3)
+    net = PNet()
+    ptl = torch_ref.PerceptualTextureLoss(net.state_dict())
+    gen = torch.Generator().manual_seed(5)
+    pred, gt = torch.rand(2, 3, 64, 64, generator=gen), torch.rand(2, 3, 64, 64, generator=gen)
+    m_gt, m_pr = (torch.rand(2, 64, 64, generator=gen) > 0.4).float(), torch.rand(2, 64, 64, generator=gen)
+    got = ptl(pred, gt, m_gt, m_pr, avg=False)
+    with torch.no_grad():
+        in0, in1 = 2 * (gt * m_gt[:, None]) - 1, 2 * (pred * m_pr[:, None]) - 1
+        f0 = net.net((in0 - net.shift) / net.scale)
+        f1 = net.net((in1 - net.shift) / net.scale)
+    np.testing.assert_allclose(got.numpy(), torch_ref.cos_sim_distance(f0, f1).numpy(), atol=1e-6)
+    assert got.shape == (2,) and float(got.min()) > 0
+
+
 def test_texture_atlas_and_obj_text_vs_reference_golden(oracle_built):
     """save_obj golden produced by the reference's own functional/save_obj.py + its atlas kernel body."""
     from oracle import softras as S

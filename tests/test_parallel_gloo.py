@@ -38,11 +38,15 @@ def _worker(rank, world, port, q):
     full = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(7))
     mine = parallel.shard(full, rank, world)
     assert mine.shape[0] == 2
+    with pytest.raises(ValueError):           # a batch that does not split evenly would hang DDP on uneven inputs
+        parallel.shard(torch.zeros(5, 1), rank, world)
     ddp = parallel.wrap_ddp(net, None, world)
     torch.manual_seed(100)                    # same VAE noise on both ranks -> comparable with the 1-process run below
     loss = _surrogate_loss(ddp(mine))
     loss.backward()
-    g = torch.cat([p.grad.flatten() for p in net.parameters()])
+    trainable = lambda m: [p for p in m.parameters() if p.requires_grad]   # frozen: resnet fc (never evaluated)
+    assert all(p.grad is not None for p in trainable(net))                 # DDP saw a gradient for every trainable parameter
+    g = torch.cat([p.grad.flatten() for p in trainable(net)])
     # reference: average of the two shards' gradients computed without DDP
     ref_net = MeshNet((64, 64), opts, nz_feat=32)
     ref_net.load_state_dict(net.state_dict())
@@ -52,10 +56,10 @@ def _worker(rank, world, port, q):
         ref_net.zero_grad()
         torch.manual_seed(100)
         _surrogate_loss(ref_net(parallel.shard(full, rr, world))).backward()
-        gr = torch.cat([p.grad.flatten() for p in ref_net.parameters()])
+        gr = torch.cat([p.grad.flatten() for p in trainable(ref_net)])
         acc = gr if acc is None else acc + gr
     err = float((g - acc / world).abs().max())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(trainable(net), lr=1e-3)
     opt.step()
     checksum = float(sum(p.double().sum() for p in net.parameters()))
     means = parallel.mean_scalars({"loss": float(loss), "rank": float(rank)}, world)
@@ -67,6 +71,13 @@ def _worker(rank, world, port, q):
     with torch.no_grad():
         expect = before + net.shape_predictor(feats.mean(0, keepdim=True)).view(-1, 3)
     terr = float((net.mean_v - expect).abs().max())
+    # buffers are NOT re-broadcast every forward (replicas are kept identical by construction): a rank-local change to a
+    # BatchNorm statistic survives the next forward, as under the reference's DataParallel-free per-rank statistics
+    bn = net.encoder.resnet_conv.resnet.bn1
+    bn.running_mean.fill_(float(rank + 1))
+    with torch.no_grad():
+        ddp(mine)
+    assert float(bn.running_mean[0]) == float(rank + 1)
     q.put((rank, max(err, terr), checksum, means["rank"]))
     dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ from umr_amd import functional as UF  # noqa: E402
 def bench(N, subdiv, IS, TS, rgb="softmax", iters=10, need_gf=True, need_gt=True, pool=False, need_p2f=True):
     dev = torch.device("cuda:0")
     verts, faces, cams, gen = scene(N, subdiv, seed=0)
-    _, fv = UF.ProjectFacesFunction.apply(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732, False)
+    _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732, False)
     F = faces.shape[1]
     tex = torch.rand(N, F, TS, 3, generator=gen).to(dev)
     fv = fv.detach().requires_grad_(need_gf)
@@ -56,7 +56,7 @@ if __name__ == "__main__" and "--alpha" not in sys.argv:
 def bench_alpha(N, subdiv, IS, iters=10, pool=True):
     dev = torch.device("cuda:0")
     verts, faces, cams, gen = scene(N, subdiv, seed=0)
-    _, fv = UF.ProjectFacesFunction.apply(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732, False)
+    _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732, False)
     fv = fv.detach().requires_grad_(True)
     H = IS // 2 if pool else IS
     g = torch.randn(N, H, H, device=dev)

@@ -25,6 +25,8 @@ SIGNATURES = {
                             ctypes.POINTER(ctypes.c_float), _P, _Z, _P], _I),
     "umr_raster_backward": ([_P] * 8 + [_I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P, _Z, _P], _I),
     "umr_project_faces_forward": ([_P] * 5 + [_I, _I, _I, _F, _F, _I, _P], _I),
+    "umr_project_faces_lit_forward": ([_P] * 6 + [_I, _I, _I, _F, _F, _I, _F, _F, ctypes.POINTER(_F), ctypes.POINTER(_F), _P], _I),
+    "umr_project_faces_lit_backward": ([_P] * 9 + [_I, _I, _I, _I, _F, ctypes.POINTER(_F), ctypes.POINTER(_F), _P, _Z, _P], _I),
     "umr_project_workspace_bytes": ([_I, _I], _Z),
     "umr_project_faces_backward": ([_P] * 7 + [_I, _I, _I, _I, _P, _Z, _P], _I),
     "umr_rotate_cam_y": ([_P, _P, _P, _I, _P], _I),
@@ -43,6 +45,14 @@ SIGNATURES = {
     "umr_visible_face_mask": ([_P, _P, _I, _L, _I, _P], _I),
     "umr_upsample2x_bilinear_forward": ([_P, _P, _L, _I, _I, _P], _I),
     "umr_upsample2x_bilinear_backward": ([_P, _P, _L, _I, _I, _P], _I),
+    "umr_cos_sim_workspace_bytes": ([_I, _I, ctypes.POINTER(_I)], _Z),
+    "umr_cos_sim_forward": ([_I, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _F, _P, _P,
+                             _Z, _P], _I),
+    "umr_cos_sim_backward": ([_I, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P),
+                              ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _F, _P, _P, _Z, _P], _I),
+    "umr_part_match_workspace_bytes": ([_I, _I, _I], _Z),
+    "umr_part_match_forward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(_F), _F, _F, _P, _P, _P, _Z, _P], _I),
+    "umr_part_match_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(_F), _F, _F, _P, _P, _P, _P, _P, _Z, _P], _I),
     "umr_dt_barrier_workspace_bytes": ([_I, _I, _I], _Z),
     "umr_dt_barrier": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P], _I),
     "umr_texture_atlas_shape": ([_I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
@@ -62,6 +72,7 @@ def lib():
                 "There is no CPU fallback." % LIB_PATH)
         h = ctypes.CDLL(LIB_PATH)
         h.umr_version.restype = ctypes.c_char_p
+        h.umr_build_id.restype = ctypes.c_char_p
         for name, (argtypes, restype) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.argtypes = argtypes
@@ -72,6 +83,10 @@ def lib():
 
 def version():
     return lib().umr_version().decode()
+
+
+def build_id():
+    return lib().umr_build_id().decode()
 
 
 def ptr(t):

@@ -11,12 +11,29 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libumr_hip.so")
-SOURCES = ["raster.hip", "geometry.hip", "losses.hip", "edt.hip", "atlas.hip"]
+SOURCES = ["raster.hip", "geometry.hip", "losses.hip", "perceptual.hip", "edt.hip", "atlas.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
          "-munsafe-fp-atomics",   # native global_atomic_add_f32 instead of CAS loops
          "-ffp-contract=off",     # branch-deciding expressions round like the reference's float code
          "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+
+
+def _dep_files():
+    return sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] +
+                  [os.path.normpath(os.path.join(HERE, "..", "include", "umr_hip.h"))])
+
+
+def source_hash():
+    """sha256 over the kernel sources + the C-ABI header (file names and contents).  The build embeds it in the library
+    (umr_build_id()); tests compare the two, so a stale .so is detected wherever the tests run -- file times do not
+    survive the copy to the GPU box, contents do."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _dep_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:32]
 
 
 def _stale():
@@ -32,7 +49,8 @@ def build(force=False, verbose=True, extra_flags=()):
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + ['-DUMR_SRC_HASH="%s"' % source_hash()] + list(extra_flags) + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print("[umr_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -32,24 +32,52 @@ __device__ __forceinline__ void quat_rot(const Cam &q, float x, float y, float z
     r3 = ((q.w * p3 + q.a * p2) - q.b * p1) + q.c * p0;
 }
 
+struct Light { float ambient, directional, cr, cg, cb, dx, dy, dz; };
+
+// One thread per (view, face): rotates the three corners, writes the 9 + 9 coordinates and -- when asked -- the face's
+// surface light (external/SoftRas/soft_renderer/lighting.py:50-57, functional/ambient_lighting.py:17,
+// directional_lighting.py:26-27 on mesh.py:111-118's normals):
+//   n = normalize(cross(p2 - p1, p0 - p1), eps 1e-6);  light = ambient c + directional c relu(n . d)
+// evaluated on the PRE look_at coordinates like the reference (lighting precedes the transform, renderer.py:89-91; the
+// look_at step only shifts z, so the edge vectors are the same).
 __global__ void k_project_faces(const float *__restrict__ verts, const float *__restrict__ cams,
                                 const int *__restrict__ faces_idx, float *__restrict__ face_pre,
-                                float *__restrict__ face_out, int N, int V, int F, float offset_z, float eye_z,
-                                int group) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
-    if (i >= N * F * 3) return;
-    const int n = i / (F * 3), m = n / group;              // view n renders mesh m = n / group (K views per mesh)
+                                float *__restrict__ face_out, float *__restrict__ light_out, int N, int V, int F,
+                                float offset_z, float eye_z, int group, const Light L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, f)
+    if (i >= N * F) return;
+    const int n = i / F, m = n / group;                    // view n renders mesh m = n / group (K views per mesh)
     const Cam cm = load_cam(cams, n);
-    const int vi = faces_idx[(size_t)m * F * 3 + (i - n * F * 3)];
-    const float *v = verts + ((size_t)m * V + vi) * 3;
-    float r1, r2, r3;
-    quat_rot(cm, v[0], v[1], v[2], r1, r2, r3);
-    const float X = cm.s * r1 + cm.tx;
-    const float Y = -(cm.s * r2 + cm.ty);
-    const float Z = cm.s * r3 + offset_z;
-    if (face_pre) { float *o = face_pre + (size_t)i * 3; o[0] = X; o[1] = Y; o[2] = Z; }
-    float *o = face_out + (size_t)i * 3;
-    o[0] = X; o[1] = Y; o[2] = Z - eye_z;
+    const int *fi = faces_idx + ((size_t)m * F + (i - n * F)) * 3;
+    float P[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *v = verts + ((size_t)m * V + fi[c]) * 3;
+        float r1, r2, r3;
+        quat_rot(cm, v[0], v[1], v[2], r1, r2, r3);
+        P[c * 3] = cm.s * r1 + cm.tx;
+        P[c * 3 + 1] = -(cm.s * r2 + cm.ty);
+        P[c * 3 + 2] = cm.s * r3 + offset_z;
+    }
+    if (face_pre) {
+        float *o = face_pre + (size_t)i * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = P[k];
+    }
+    float *o = face_out + (size_t)i * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = (k % 3 == 2) ? P[k] - eye_z : P[k];
+    if (light_out) {
+        const float ax = P[0] - P[3], ay = P[1] - P[4], az = P[2] - P[5];      // v10
+        const float bx = P[6] - P[3], by = P[7] - P[4], bz = P[8] - P[5];      // v12
+        const float nx = by * az - bz * ay, ny = bz * ax - bx * az, nz = bx * ay - by * ax;   // cross(v12, v10)
+        const float nrm = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-6f);
+        const float cosine = fmaxf((nx / nrm) * L.dx + (ny / nrm) * L.dy + (nz / nrm) * L.dz, 0.f);
+        float *lo = light_out + (size_t)i * 3;
+        lo[0] = L.ambient * L.cr + L.directional * (L.cr * cosine);
+        lo[1] = L.ambient * L.cg + L.directional * (L.cg * cosine);
+        lo[2] = L.ambient * L.cb + L.directional * (L.cb * cosine);
+    }
 }
 
 __global__ void k_project_points(const float *__restrict__ verts, const float *__restrict__ cams,
@@ -65,18 +93,46 @@ __global__ void k_project_points(const float *__restrict__ verts, const float *_
     if (out_dim == 3) out[(size_t)i * 3 + 2] = cm.s * r3 + offset_z;
 }
 
-// scatter-add face-corner gradients onto projected vertices: gproj[n, v, :] (zeroed beforehand)
+// scatter-add face-corner gradients onto projected vertices: gproj[n, v, :] (zeroed beforehand).  One thread per
+// (view, face); the gradient of the surface light (when given) is chained through normalize / cross here, using the
+// projected corners saved by the forward.
 __global__ void k_scatter_face_grads(const float *__restrict__ g_out, const float *__restrict__ g_pre,
+                                     const float *__restrict__ g_light, const float *__restrict__ face_out,
                                      const int *__restrict__ faces_idx, float *__restrict__ gproj, int N, int V,
-                                     int F, int group) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
-    if (i >= N * F * 3) return;
-    const int n = i / (F * 3);
-    const int vi = faces_idx[(size_t)(n / group) * F * 3 + (i - n * F * 3)];
-    float gx = g_out[(size_t)i * 3], gy = g_out[(size_t)i * 3 + 1], gz = g_out[(size_t)i * 3 + 2];
-    if (g_pre) { gx += g_pre[(size_t)i * 3]; gy += g_pre[(size_t)i * 3 + 1]; gz += g_pre[(size_t)i * 3 + 2]; }
-    float *d = gproj + ((size_t)n * V + vi) * 3;
-    atomicAdd(d, gx); atomicAdd(d + 1, gy); atomicAdd(d + 2, gz);
+                                     int F, int group, const Light L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (n, f)
+    if (i >= N * F) return;
+    const int n = i / F;
+    const int *fi = faces_idx + ((size_t)(n / group) * F + (i - n * F)) * 3;
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = g_out[(size_t)i * 9 + k] + (g_pre ? g_pre[(size_t)i * 9 + k] : 0.f);
+    if (g_light) {
+        const float *P = face_out + (size_t)i * 9;
+        const float ax = P[0] - P[3], ay = P[1] - P[4], az = P[2] - P[5];
+        const float bx = P[6] - P[3], by = P[7] - P[4], bz = P[8] - P[5];
+        const float nx = by * az - bz * ay, ny = bz * ax - bx * az, nz = bx * ay - by * ax;
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        const float nrm = fmaxf(len, 1e-6f), inv = 1.f / nrm;
+        const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
+        const float cosine = ux * L.dx + uy * L.dy + uz * L.dz;
+        const float *gl = g_light + (size_t)i * 3;
+        const float gc = cosine > 0.f ? L.directional * (L.cr * gl[0] + L.cg * gl[1] + L.cb * gl[2]) : 0.f;
+        // d cos / d n: (d - u (u.d)) / |n| while |n| > eps, d / eps below it (F.normalize clamps the denominator)
+        const float k = len > 1e-6f ? cosine : 0.f;
+        const float gnx = gc * (L.dx - ux * k) * inv, gny = gc * (L.dy - uy * k) * inv, gnz = gc * (L.dz - uz * k) * inv;
+        // n = b x a  =>  db = a x gn,  da = gn x b
+        const float dbx = ay * gnz - az * gny, dby = az * gnx - ax * gnz, dbz = ax * gny - ay * gnx;
+        const float dax = gny * bz - gnz * by, day = gnz * bx - gnx * bz, daz = gnx * by - gny * bx;
+        g[0] += dax; g[1] += day; g[2] += daz;
+        g[6] += dbx; g[7] += dby; g[8] += dbz;
+        g[3] -= dax + dbx; g[4] -= day + dby; g[5] -= daz + dbz;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float *d = gproj + ((size_t)n * V + fi[c]) * 3;
+        atomicAdd(d, g[c * 3]); atomicAdd(d + 1, g[c * 3 + 1]); atomicAdd(d + 2, g[c * 3 + 2]);
+    }
 }
 
 // geom_utils.rotate_cam (nnutils/geom_utils.py:167-193) for the y axis: new_q = q_y(angle) (x) q, renormalised, w >= 0
@@ -167,35 +223,63 @@ __global__ __launch_bounds__(256) void k_project_backward(const float *__restric
 
 extern "C" {
 
-int umr_project_faces_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
-                              float *face_out, int N, int V, int F, float offset_z, float eye_z, int mesh_group,
-                              void *stream) {
+static Light make_light(float ambient, float directional, const float *color3, const float *direction3) {
+    Light L = {ambient, directional, 1.f, 1.f, 1.f, 0.f, 1.f, 0.f};
+    if (color3) { L.cr = color3[0]; L.cg = color3[1]; L.cb = color3[2]; }
+    if (direction3) { L.dx = direction3[0]; L.dy = direction3[1]; L.dz = direction3[2]; }
+    return L;
+}
+
+int umr_project_faces_lit_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
+                                  float *face_out, float *light_out, int N, int V, int F, float offset_z, float eye_z,
+                                  int mesh_group, float light_ambient, float light_directional, const float *light_color3,
+                                  const float *light_direction3, void *stream) {
     if (!verts || !cams || !faces_idx || !face_out || N <= 0 || V <= 0 || F <= 0) return UMR_ERR_ARG;
     if (mesh_group < 1 || N % mesh_group) return UMR_ERR_ARG;
     if ((long long)N * F * 3 > 0x7fffffffLL) return UMR_ERR_ARG;
-    const int total = N * F * 3;
-    k_project_faces<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(verts, cams, faces_idx, face_pre, face_out,
-                                                                        N, V, F, offset_z, eye_z, mesh_group);
+    const int total = N * F;
+    k_project_faces<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+        verts, cams, faces_idx, face_pre, face_out, light_out, N, V, F, offset_z, eye_z, mesh_group,
+        make_light(light_ambient, light_directional, light_color3, light_direction3));
     return umr_launch_status();
+}
+
+int umr_project_faces_forward(const float *verts, const float *cams, const int *faces_idx, float *face_pre,
+                              float *face_out, int N, int V, int F, float offset_z, float eye_z, int mesh_group,
+                              void *stream) {
+    return umr_project_faces_lit_forward(verts, cams, faces_idx, face_pre, face_out, nullptr, N, V, F, offset_z, eye_z,
+                                         mesh_group, 0.f, 0.f, nullptr, nullptr, stream);
 }
 
 size_t umr_project_workspace_bytes(int N, int V) { return N > 0 && V > 0 ? (size_t)N * V * 3 * sizeof(float) : 0; }
 
-int umr_project_faces_backward(const float *grad_face_out, const float *grad_face_pre, const float *verts,
-                               const float *cams, const int *faces_idx, float *grad_verts, float *grad_cams,
-                               int N, int V, int F, int mesh_group, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+int umr_project_faces_lit_backward(const float *grad_face_out, const float *grad_face_pre, const float *grad_light,
+                                   const float *face_out, const float *verts, const float *cams, const int *faces_idx,
+                                   float *grad_verts, float *grad_cams, int N, int V, int F, int mesh_group,
+                                   float light_directional, const float *light_color3, const float *light_direction3,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
     if (!grad_face_out || !verts || !cams || !faces_idx || !grad_cams || !workspace) return UMR_ERR_ARG;
+    if (grad_light && !face_out) return UMR_ERR_ARG;
     if (N <= 0 || V <= 0 || F <= 0 || (long long)N * F * 3 > 0x7fffffffLL) return UMR_ERR_ARG;
     if (mesh_group < 1 || N % mesh_group) return UMR_ERR_ARG;
     if (workspace_bytes < umr_project_workspace_bytes(N, V)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, umr_project_workspace_bytes(N, V), st) != hipSuccess) return UMR_ERR_LAUNCH;
-    const int total = N * F * 3;
-    k_scatter_face_grads<<<(total + 255) / 256, 256, 0, st>>>(grad_face_out, grad_face_pre, faces_idx,
-                                                              (float *)workspace, N, V, F, mesh_group);
+    const int total = N * F;
+    k_scatter_face_grads<<<(total + 255) / 256, 256, 0, st>>>(grad_face_out, grad_face_pre, grad_light, face_out, faces_idx,
+                                                              (float *)workspace, N, V, F, mesh_group,
+                                                              make_light(0.f, light_directional, light_color3, light_direction3));
     k_project_backward<0><<<N, 256, 0, st>>>((const float *)workspace, verts, cams, grad_verts, grad_cams, V, mesh_group);
     return umr_launch_status();
+}
+
+int umr_project_faces_backward(const float *grad_face_out, const float *grad_face_pre, const float *verts,
+                               const float *cams, const int *faces_idx, float *grad_verts, float *grad_cams,
+                               int N, int V, int F, int mesh_group, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    return umr_project_faces_lit_backward(grad_face_out, grad_face_pre, nullptr, nullptr, verts, cams, faces_idx, grad_verts,
+                                          grad_cams, N, V, F, mesh_group, 0.f, nullptr, nullptr, workspace, workspace_bytes,
+                                          stream);
 }
 
 int umr_project_points_forward(const float *verts, const float *cams, float *out, int N, int V, int out_dim,

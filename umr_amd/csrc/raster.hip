@@ -58,7 +58,12 @@ struct ProfScope {  // brackets exactly one kernel launch on `st`
 
 extern "C" {
 
-const char *umr_version(void) { return "umr_hip 0.1 gfx950"; }
+const char *umr_version(void) { return "umr_hip 0.2 gfx950"; }
+
+#ifndef UMR_SRC_HASH
+#define UMR_SRC_HASH "unknown"
+#endif
+const char *umr_build_id(void) { return UMR_SRC_HASH; }
 
 int umr_debug_set(const char *key, int value) {
     if (!key) return UMR_ERR_ARG;

@@ -199,13 +199,15 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
 
 
 class ProjectFacesFunction(Function):
-    """verts [N/G,V,3], cams [N,7], faces [N/G,F,3] int32 -> (face_pre [N,F,3,3], face_out [N,F,3,3]).
-    Fuses geom_utils.orthographic_proj_withz + smr.Render's y flip + face_vertices + LookAt/orthogonal.
+    """verts [N/G,V,3], cams [N,7], faces [N/G,F,3] int32 -> (face_pre [N,F,3,3], face_out [N,F,3,3], light [N,F,3]).
+    Fuses geom_utils.orthographic_proj_withz + smr.Render's y flip + face_vertices + LookAt/orthogonal and, when
+    `light` = (ambient, directional, color3, direction3) is given, sr.Lighting's per-face surface light
+    (lighting.py:50-57); face_pre / light come back empty when not asked for.
     G = N_cams / N_meshes >= 1 camera hypotheses per mesh: view n renders mesh n // G, i.e. the layout of
     `vs.unsqueeze(1).repeat(1, K, 1, 1).view(B*K, V, 3)` (nnutils/loss_utils.py:260-262) without the copies."""
 
     @staticmethod
-    def forward(ctx, verts, cams, faces_idx, offset_z, eye_z, want_pre):
+    def forward(ctx, verts, cams, faces_idx, offset_z, eye_z, want_pre, light=None):
         L = _lib.lib()
         dev = verts.device
         v, c = _f32c(verts), _f32c(cams)
@@ -217,36 +219,48 @@ class ProjectFacesFunction(Function):
         G = N // M
         face_out = torch.empty(N, F, 3, 3, device=dev, dtype=torch.float32)
         face_pre = torch.empty(N, F, 3, 3, device=dev, dtype=torch.float32) if want_pre else None
-        rc = L.umr_project_faces_forward(ptr(v), ptr(c), ptr(faces_idx), ptr(face_pre), ptr(face_out), N, V, F,
-                                         float(offset_z), float(eye_z), G, _lib.stream_ptr(dev))
-        _lib.check(rc, "umr_project_faces_forward")
-        ctx.save_for_backward(v, c, faces_idx)
+        light_out = torch.empty(N, F, 3, device=dev, dtype=torch.float32) if light is not None else None
+        amb, dirn, col, dvec = light if light is not None else (0., 0., (1., 1., 1.), (0., 1., 0.))
+        ctx.light = (float(dirn), (ctypes.c_float * 3)(*[float(x) for x in col]),
+                     (ctypes.c_float * 3)(*[float(x) for x in dvec])) if light is not None else None
+        rc = L.umr_project_faces_lit_forward(ptr(v), ptr(c), ptr(faces_idx), ptr(face_pre), ptr(face_out), ptr(light_out),
+                                             N, V, F, float(offset_z), float(eye_z), G, float(amb), float(dirn),
+                                             (ctypes.c_float * 3)(*[float(x) for x in col]),
+                                             (ctypes.c_float * 3)(*[float(x) for x in dvec]), _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_project_faces_lit_forward")
+        if light is not None:
+            ctx.save_for_backward(v, c, faces_idx, face_out)
+        else:
+            ctx.save_for_backward(v, c, faces_idx)
         ctx.want_pre = want_pre
-        if want_pre:
-            return face_pre, face_out
-        return face_out.new_empty(0), face_out
+        empty = face_out.new_empty(0)
+        return (face_pre if want_pre else empty), face_out, (light_out if light is not None else empty)
 
     @staticmethod
-    def backward(ctx, g_pre, g_out):
+    def backward(ctx, g_pre, g_out, g_light):
         L = _lib.lib()
-        v, c, faces_idx = ctx.saved_tensors
+        v, c, faces_idx = ctx.saved_tensors[:3]
+        face_out = ctx.saved_tensors[3] if ctx.light is not None else None
         dev = v.device
         M, V = v.shape[:2]
         N = c.shape[0]
         G = N // M
         F = faces_idx.shape[1]
-        g_out = g_out.to(torch.float32).contiguous()
+        g_out = (g_out if g_out is not None else torch.zeros(N, F, 3, 3, device=dev)).to(torch.float32).contiguous()
         g_pre = g_pre.to(torch.float32).contiguous() if (ctx.want_pre and g_pre is not None) else None
+        g_light = g_light.to(torch.float32).contiguous() if (ctx.light is not None and g_light is not None) else None
         grad_verts = torch.zeros(N, V, 3, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         grad_cams = torch.empty_like(c)
         ws_bytes = L.umr_project_workspace_bytes(N, V)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        rc = L.umr_project_faces_backward(ptr(g_out), ptr(g_pre), ptr(v), ptr(c), ptr(faces_idx), ptr(grad_verts),
-                                          ptr(grad_cams), N, V, F, G, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
-        _lib.check(rc, "umr_project_faces_backward")
+        dirn, col, dvec = ctx.light if ctx.light is not None else (0., None, None)
+        rc = L.umr_project_faces_lit_backward(ptr(g_out), ptr(g_pre), ptr(g_light), ptr(face_out), ptr(v), ptr(c),
+                                              ptr(faces_idx), ptr(grad_verts), ptr(grad_cams), N, V, F, G, dirn, col, dvec,
+                                              ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "umr_project_faces_lit_backward")
         if grad_verts is not None and G > 1:
             grad_verts = grad_verts.view(M, G, V, 3).sum(1)      # what autograd does for the reference's repeat
-        return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None, None, None
+        return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None, None, None, None
 
 
 class ProjectPointsFunction(Function):
@@ -452,3 +466,93 @@ class Upsample2xBilinearFunction(Function):
         _lib.check(L.umr_upsample2x_bilinear_backward(ptr(g), ptr(gi), B * C, H, W, _lib.stream_ptr(g.device)),
                    "umr_upsample2x_bilinear_backward")
         return gi
+
+
+class CosSimDistanceFunction(Function):
+    """PNet head (networks_basic.py:42-64 + util/util.py:71-83): apply(eps, *feats0, *feats1) with 2 T feature maps
+    [N,C_t,X_t,Y_t] -> val [N] = sum_t (1 - mean_xy cos(f0_t, f1_t)).  One launch for all taps each way."""
+
+    @staticmethod
+    def forward(ctx, eps, *feats):
+        L = _lib.lib()
+        T = len(feats) // 2
+        f0 = [_f32c(f) for f in feats[:T]]
+        f1 = [_f32c(f) for f in feats[T:]]
+        N = f0[0].shape[0]
+        for a, b in zip(f0, f1):
+            if a.shape != b.shape or a.dim() != 4 or a.shape[0] != N:
+                raise RuntimeError("cos_sim_distance: feature pairs must be [N,C,X,Y] of equal shapes")
+        dev = f0[0].device
+        C = (ctypes.c_int * T)(*[a.shape[1] for a in f0])
+        P = (ctypes.c_int * T)(*[a.shape[2] * a.shape[3] for a in f0])
+        ws_bytes = L.umr_cos_sim_workspace_bytes(T, N, P)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        val = torch.empty(N, device=dev, dtype=torch.float32)
+        p0 = (ctypes.c_void_p * T)(*[ptr(a) for a in f0])
+        p1 = (ctypes.c_void_p * T)(*[ptr(a) for a in f1])
+        _lib.check(L.umr_cos_sim_forward(T, p0, p1, C, P, N, float(eps), ptr(val), ptr(ws), ws_bytes,
+                                         _lib.stream_ptr(dev)), "umr_cos_sim_forward")
+        ctx.save_for_backward(ws, *f0, *f1)
+        ctx.eps, ctx.T = float(eps), T
+        return val
+
+    @staticmethod
+    def backward(ctx, gval):
+        L = _lib.lib()
+        T = ctx.T
+        ws, feats = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        f0, f1 = feats[:T], feats[T:]
+        N = f0[0].shape[0]
+        dev = ws.device
+        need = ctx.needs_input_grad[1:]
+        g0 = [torch.empty_like(a) if need[t] else None for t, a in enumerate(f0)]
+        g1 = [torch.empty_like(a) if need[T + t] else None for t, a in enumerate(f1)]
+        if not any(need):
+            return (None,) * (1 + 2 * T)
+        C = (ctypes.c_int * T)(*[a.shape[1] for a in f0])
+        P = (ctypes.c_int * T)(*[a.shape[2] * a.shape[3] for a in f0])
+        tab = lambda ts: (ctypes.c_void_p * T)(*[ptr(t) for t in ts])
+        gv = gval.to(torch.float32).contiguous()
+        _lib.check(L.umr_cos_sim_backward(T, tab(f0), tab(f1), tab(g0), tab(g1), C, P, N, ctx.eps, ptr(gv), ptr(ws),
+                                          ws.numel(), _lib.stream_ptr(dev)), "umr_cos_sim_backward")
+        return (None,) + tuple(g0) + tuple(g1)
+
+
+class PartMatchFunction(Function):
+    """Reductions of part_matching_loss (nnutils/loss_utils.py:399-440, scops_utils.py:12-54):
+    apply(render_a [B,4,H,W], render_b [B,4,H,W], part_segs [B,5,H,W], weights5 (python floats), background, eps)
+    -> (l_eqv [B], l_lm [B]); see include/umr_hip.h for the exact definition.  Gradients flow to the two renders."""
+
+    @staticmethod
+    def forward(ctx, render_a, render_b, part_segs, weights5, background, center_eps):
+        L = _lib.lib()
+        a, b, q = _f32c(render_a), _f32c(render_b), _f32c(part_segs)
+        B, _, H, W = a.shape
+        if a.shape != b.shape or a.shape[1] != 4 or q.shape != (B, 5, H, W):
+            raise RuntimeError("part_match: renders must be [B,4,H,W] and part_segs [B,5,H,W]")
+        dev = a.device
+        w = (ctypes.c_float * 5)(*[float(x) for x in weights5])
+        ws_bytes = L.umr_part_match_workspace_bytes(B, H, W)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        out = torch.empty(2, B, device=dev, dtype=torch.float32)
+        _lib.check(L.umr_part_match_forward(ptr(a), ptr(b), ptr(q), B, H, W, w, float(background), float(center_eps),
+                                            ptr(out[0]), ptr(out[1]), ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                   "umr_part_match_forward")
+        ctx.save_for_backward(a, b, q, ws)
+        ctx.cfg = ([float(x) for x in weights5], float(background), float(center_eps))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_eqv, g_lm):
+        L = _lib.lib()
+        a, b, q, ws = ctx.saved_tensors
+        B, _, H, W = a.shape
+        dev = a.device
+        w5, bg, eps = ctx.cfg
+        w = (ctypes.c_float * 5)(*w5)
+        ge = (g_eqv if g_eqv is not None else torch.zeros(B, device=dev)).to(torch.float32).contiguous()
+        gl = (g_lm if g_lm is not None else torch.zeros(B, device=dev)).to(torch.float32).contiguous()
+        ga, gb = torch.zeros_like(a), torch.zeros_like(b)
+        _lib.check(L.umr_part_match_backward(ptr(a), ptr(b), ptr(q), B, H, W, w, bg, eps, ptr(ge), ptr(gl), ptr(ga), ptr(gb),
+                                             ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "umr_part_match_backward")
+        return ga, gb, None, None, None, None

@@ -31,16 +31,25 @@ def save_network(network, network_label, epoch_label, save_dir):
     return path
 
 
-def load_network(network, network_label, epoch_label, save_dir, skip=("uv_sampler", "noise")):
+def load_network(network, network_label, epoch_label, save_dir, skip=("uv_sampler", "noise"), strict=True):
     """nnutils/train_utils.py:117-125 with the tolerant filtering of test_utils.py:106-116: keys in `skip` (buffers
-    that depend on the batch size) and keys whose shapes differ are left at their current values.
-    Returns the list of keys that were loaded."""
+    that depend on the batch size) are left at their current values.  umr_amd.model names its modules as the reference
+    does (cub_mesh.py), so a reference checkpoint loads key for key.  Anything else that cannot be placed -- a key this
+    model lacks, a key the file lacks, a shape mismatch -- raises when `strict` (the reference's filter would silently
+    leave the model at its random initialisation); strict=False restores the caffe-like behaviour and returns what was
+    loaded.  Returns the sorted list of loaded keys."""
     path = os.path.join(save_dir, '{}_net_{}.pth'.format(network_label, epoch_label))
     state = torch.load(path, map_location="cpu")
     net = _unwrap(network)
     own = net.state_dict()
-    use = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state.items()}
-    use = {k: v for k, v in use.items() if k in own and not any(s in k for s in skip) and own[k].shape == v.shape}
+    state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state.items()}
+    skipped = lambda k: any(s in k for s in skip) or k.endswith("num_batches_tracked")
+    use = {k: v for k, v in state.items() if k in own and not skipped(k) and own[k].shape == v.shape}
+    bad = sorted(k for k in state if k not in use and not skipped(k)) + \
+        sorted("(missing) " + k for k in own if k not in state and not skipped(k))
+    if bad and strict:
+        raise RuntimeError("load_network(%s): %d of %d entries not loaded (unknown key / shape mismatch / missing): %s%s"
+                           % (path, len(bad), len(state), ", ".join(bad[:8]), " ..." if len(bad) > 8 else ""))
     own.update(use)
     net.load_state_dict(own)
     return sorted(use)

@@ -228,18 +228,6 @@ class MultiTextureLoss(nn.Module):
         return tex_loss, tex_dt_loss, tex_cycle_loss, texture_pred
 
 
-def batch_get_centers(pred_softmax, epsilon=1e-3):
-    """nnutils/scops_utils.py:12-54 without the B x C python loop / per-call numpy coordinate maps:
-    soft centroid (x, y) of every part map -> [B,C,2]."""
-    B, C, H, W = pred_softmax.shape
-    # get_coordinate_tensors(h, w) is called with (x_max=h, y_max=w): x = col / h * 2 - 1, y = row / w * 2 - 1
-    x_map = (torch.arange(H, device=pred_softmax.device, dtype=torch.float32) / H * 2 - 1.0)[None, :].expand(W, H)
-    y_map = (torch.arange(W, device=pred_softmax.device, dtype=torch.float32) / W * 2 - 1.0)[:, None].expand(W, H)
-    pm = pred_softmax + epsilon
-    pdf = pm / pm.sum(dim=(2, 3), keepdim=True)
-    return torch.stack(((pdf * x_map).sum(dim=(2, 3)), (pdf * y_map).sum(dim=(2, 3))), dim=-1)
-
-
 class part_matching_loss(nn.Module):
     """nnutils/loss_utils.py:333-440 (loss_type 'mse').  `scops_path` may be the reference's directory holding
     semantic_seg.png, or a tensor `uv_img` [1,1,128,256] of part labels 0..4 (the SCOPS template is not
@@ -277,6 +265,7 @@ class part_matching_loss(nn.Module):
         self.renderer.need_p2f = False
         self.im_size = im_size
         self.register_buffer("weights", torch.tensor([0, 5.0, 0.0, 0.0, 5.0]).view(1, 5, 1, 1))
+        self._w5 = (0.0, 5.0, 0.0, 0.0, 5.0)            # the same weights by value for the fused reduction (:377-378)
         self.loss_type = loss_type
 
     def forward(self, verts, faces, cams, part_segs, cam_probs=None, avg=True):
@@ -286,22 +275,14 @@ class part_matching_loss(nn.Module):
         proj_a, _, _ = self.renderer(verts, faces, cams, self.stex123)
         proj_b, _, _ = self.renderer(verts, faces, cams, self.stex4)
         projs = [proj_a[:, 0:1], proj_a[:, 1:2], proj_a[:, 2:3], proj_b[:, 0:1]]
-        bg = torch.full((bs, 1, self.im_size, self.im_size), 0.1, device=verts.device)
-        proj = torch.cat([bg] + projs, dim=1)
-        centers_proj = batch_get_centers(torch.softmax(proj, dim=1)[:, 1:, :, :])
-        centers_parts = batch_get_centers(torch.softmax(part_segs, dim=1)[:, 1:, :, :])
+        # everything after the renders (:399-440: background plane, soft-max over the 5 planes, SCOPS soft centroids of
+        # both stacks, per-plane max normalisation, weighted MSE) is one fused op: 4 launches forward, 1 backward
+        l_eqv, l_lm = UF.PartMatchFunction.apply(proj_a, proj_b, part_segs, self._w5, 0.1, 1e-3)
+        H, W = proj_a.shape[2], proj_a.shape[3]
         if avg:
-            loss_lmeqv = torch.nn.functional.mse_loss(centers_proj, centers_parts)
+            loss_eqv = l_eqv.sum() / (bs * 5 * H * W)
+            loss_lmeqv = l_lm.sum() / (bs * 8)
         else:
-            l = torch.nn.functional.mse_loss(centers_proj, centers_parts, reduction='none')
-            l = torch.sum(l, dim=(1, 2)) / (l.size(1) * l.size(2))
-            loss_lmeqv = (l.view(cam_probs.size()) * cam_probs).sum(dim=1).mean()
-        max_proj = proj.view(bs, 5, -1).max(dim=2)[0].clamp_min(1e-5)
-        max_part = part_segs.view(bs, 5, -1).max(dim=2)[0].clamp_min(1e-5)
-        d = (proj / max_proj.view(bs, 5, 1, 1) - part_segs / max_part.view(bs, 5, 1, 1)).pow(2) * self.weights
-        if avg:
-            loss_eqv = torch.mean(d)
-        else:
-            l = torch.sum(d, dim=(1, 2, 3)) / (d.size(1) * d.size(2) * d.size(3))
-            loss_eqv = (l.view(cam_probs.size()) * cam_probs).sum(dim=1).mean()
+            loss_eqv = ((l_eqv / (5 * H * W)).view(cam_probs.size()) * cam_probs).sum(dim=1).mean()
+            loss_lmeqv = ((l_lm / 8).view(cam_probs.size()) * cam_probs).sum(dim=1).mean()
         return (loss_eqv + loss_lmeqv) / 4.0, projs

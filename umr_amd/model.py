@@ -120,22 +120,34 @@ class BasicBlock(nn.Module):
         return F.relu(out + idt, inplace=True)
 
 
-class ResNetConv(nn.Module):
-    """cub_mesh.py:53-74: resnet18 without avgpool/fc (the reference keeps an unused fc; dropping it also removes the
-    one parameter that never receives a gradient)."""
+class ResNet18(nn.Module):
+    """torchvision.models.resnet18 parameter layout (conv1, bn1, layer1..4, fc), so checkpoints interchange with the
+    reference's `encoder.resnet_conv.resnet.*` keys.  `fc` is never evaluated (cub_mesh.py:62-73 stops after layer4) and
+    never receives a gradient in the reference either; it is frozen here so DDP does not wait for it."""
 
     def __init__(self):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         cfg = [(64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)]
-        self.layers = nn.ModuleList([nn.Sequential(BasicBlock(a, b, s), BasicBlock(b, b, 1)) for a, b, s in cfg])
+        for i, (a, b, st) in enumerate(cfg):
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(BasicBlock(a, b, st), BasicBlock(b, b, 1)))
+        self.fc = nn.Linear(512, 1000)
+        for p in self.fc.parameters():
+            p.requires_grad = False
+
+
+class ResNetConv(nn.Module):
+    """cub_mesh.py:53-74: the resnet18 trunk up to layer4 (no avgpool / fc)."""
+
+    def __init__(self):
+        super().__init__()
+        self.resnet = ResNet18()
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, 2, 1)
-        for l in self.layers:
-            x = l(x)
-        return x
+        r = self.resnet
+        x = F.max_pool2d(F.relu(r.bn1(r.conv1(x)), inplace=True), 3, 2, 1)
+        return r.layer4(r.layer3(r.layer2(r.layer1(x))))
 
 
 class Encoder(nn.Module):
@@ -179,24 +191,54 @@ class TexturePredictorUV(nn.Module):
         return tex.contiguous(), uvimage_pred
 
 
-class Camera(nn.Module):
-    """cub_mesh.py:276-301 -> [quat(4), prob(1), scale(1), trans(2)]."""
+class _Pred(nn.Module):
+    """A Linear named `pred_layer`: ShapePredictor / QuatPredictor / ScalePredictor / TransPredictor of cub_mesh.py:169-233
+    all keep their single layer under that name, which is what their state_dict keys look like."""
 
-    def __init__(self, nz):
+    def __init__(self, nz, nout):
+        super().__init__()
+        self.pred_layer = nn.Linear(nz, nout)
+
+    def forward(self, feat):
+        return self.pred_layer(feat)
+
+
+class ShapePredictor(_Pred):
+    """cub_mesh.py:169-184."""
+
+    def __init__(self, nz_feat, num_verts):
+        super().__init__(nz_feat, num_verts * 3)
+        self.pred_layer.weight.data.normal_(0, 0.0001)           # :177
+
+
+def _freeze(*mods):
+    for m in mods:
+        for p in m.parameters():
+            p.requires_grad = False
+
+
+class Camera(nn.Module):
+    """cub_mesh.py:276-301 -> [quat(4), prob(1), scale(1), trans(2)]; sub-module names as the reference's."""
+
+    def __init__(self, nz, scale_lr=1.0, scale_bias=1.0):
         super().__init__()
         self.fc_layer = fc_stack(nz, nz, 2)
-        self.quat = nn.Linear(nz, 4)
-        self.prob = nn.Linear(nz, 1)
-        self.scale = nn.Linear(nz, 1)
-        self.trans = nn.Linear(nz, 2)
+        self.quat_predictor = _Pred(nz, 4)
+        self.prob_predictor = nn.Linear(nz, 1)
+        self.scale_predictor = _Pred(nz, 1)
+        self.trans_predictor = _Pred(nz, 2)
+        self.scale_lr, self.scale_bias = scale_lr, scale_bias    # ScalePredictor's (lr, bias), :208-212 defaults 1.0, 1.0
         net_init(self)
-        self.quat.bias.data = torch.tensor([1., 0., 0., 0.])   # initialize_to_zero_rotation (:200-203)
+        self.init_quat_module()
+
+    def init_quat_module(self):
+        self.quat_predictor.pred_layer.bias.data = torch.tensor([1., 0., 0., 0.])   # initialize_to_zero_rotation (:200-203)
 
     def forward(self, feat):
         f = self.fc_layer(feat)
-        quat = F.normalize(self.quat(f))
-        scale = F.relu(self.scale(f) + 1.0) + 1e-12                # ScalePredictor (:213-216)
-        return torch.cat([quat, self.prob(f), scale, self.trans(f)], dim=1)
+        quat = F.normalize(self.quat_predictor(f))
+        scale = F.relu(self.scale_lr * self.scale_predictor(f) + self.scale_bias) + 1e-12     # ScalePredictor (:213-216)
+        return torch.cat([quat, self.prob_predictor(f), scale, self.trans_predictor(f)], dim=1)
 
 
 class MultiCamPredictor(nn.Module):
@@ -205,12 +247,31 @@ class MultiCamPredictor(nn.Module):
     def __init__(self, nz_feat, num_cams=8):
         super().__init__()
         self.fc = fc_stack(nz_feat, nz_feat, 2, use_bn=False)
-        self.cameras = nn.ModuleList([Camera(nz_feat) for _ in range(num_cams)])
+        # shared scale / translation / probability / quaternion heads: the reference builds them, evaluates the first two and
+        # throws the result away (:345-348), never touches the others -- none ever receives a gradient.  Kept (frozen)
+        # so the state_dict has the reference's keys.
+        self.scale_predictor = _Pred(nz_feat, 1)
+        self.trans_predictor = _Pred(nz_feat, 2)
+        self.prob_predictor = nn.Linear(nz_feat, num_cams)
+        self.camera_predictor = nn.ModuleList([Camera(nz_feat) for _ in range(num_cams)])
+        self.quat_predictor = _Pred(nz_feat, 4)
+        net_init(self)
+        for c in self.camera_predictor:
+            c.init_quat_module()
+        self.quat_predictor.pred_layer.bias.data = torch.tensor([1., 0., 0., 0.])
+        _freeze(self.scale_predictor, self.trans_predictor, self.prob_predictor, self.quat_predictor)
         self.num_cams = num_cams
+        # :326-332 (registered, never read by forward)
+        base_rot, bias = (0.9239, 0., 0.3827, 0.), [(0.7071, 0.7071, 0., 0.)]
+        for _ in range(1, num_cams):
+            (a1, b1, c1, d1), (a2, b2, c2, d2) = base_rot, bias[-1]
+            bias.append((a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2, a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+                         a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2, a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2))
+        self.register_buffer("cam_biases", torch.tensor(bias, dtype=torch.float32))
 
     def forward(self, feat):
         f = self.fc(feat)
-        cams = torch.stack([c(f) for c in self.cameras], dim=1)      # [B,K,8]
+        cams = torch.stack([c(f) for c in self.camera_predictor], dim=1)      # [B,K,8]
         probs = F.softmax(cams[:, :, 4], dim=1)
         cam = torch.cat([cams[:, :, 5:6], cams[:, :, 6:8], cams[:, :, 0:4], probs.unsqueeze(-1)], dim=2)
         inds = torch.multinomial(probs.detach(), 1)                  # per-rank RNG stream (:358-359)
@@ -285,15 +346,14 @@ class MeshNet(nn.Module):
             self.num_output = self.num_indept + self.num_sym
             flip = torch.ones(1, 3)
             flip[0, axis] = -1
-            self.register_buffer("flip", flip)
+            self.register_buffer("flip", flip, persistent=False)       # a plain attribute in the reference (:399)
         else:
             self.num_output = verts.shape[0]
         self.register_buffer("mean_v", torch.from_numpy(verts[:self.num_output]).float())
-        self.register_buffer("faces", torch.from_numpy(faces).long())
+        self.register_buffer("faces", torch.from_numpy(faces).long(), persistent=False)   # attribute in the reference (:409)
         self.verts_np, self.faces_np = verts, faces
         self.encoder = Encoder(input_shape, nz_feat=nz_feat, z_dim=opts.z_dim)
-        self.shape_predictor = nn.Linear(opts.z_dim, self.num_output * 3)
-        self.shape_predictor.weight.data.normal_(0, 0.0001)           # cub_mesh.py:176-177
+        self.shape_predictor = ShapePredictor(opts.z_dim, self.num_output)
         self.cam_predictor = MultiCamPredictor(nz_feat, opts.num_hypo_cams) if opts.multiple_cam_hypo else Camera(nz_feat)
         T = opts.tex_size
         num_faces = self.num_indept_faces + self.num_sym_faces if self.symmetric_texture else faces.shape[0]   # :418-421
@@ -345,7 +405,11 @@ def build_training_step(tv, faces, args, dev, world):
     disc = Discriminator(opts.grl_wt, img_size=args.image_size).to(dev)
     model = nn.ModuleDict(dict(net=net, disc=disc))
     ddp_net, ddp_disc = wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world)
-    rc = RenderCompareS1(net.get_mean_shape().detach(), net.faces, args.image_size, discriminator=ddp_disc).to(dev)
+    # train_s1.py:150: the texture term is the AlexNet perceptual distance (two feature passes over B images and one
+    # backward per step); random weights offline, frozen (requires_grad False) and therefore not in the optimizer
+    from .perceptual import PerceptualTextureLoss
+    rc = RenderCompareS1(net.get_mean_shape().detach(), net.faces, args.image_size, discriminator=ddp_disc,
+                         texture_loss=PerceptualTextureLoss(dev), epoch=getattr(args, "epoch", 0)).to(dev)
     # same update rule as train_utils.py:186-187; `fused` runs it as one multi-tensor kernel on the GPU
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
                            betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))

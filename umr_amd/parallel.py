@@ -28,19 +28,26 @@ def init_distributed(backend=None):
 
 
 def wrap_ddp(module, device, world):
+    """broadcast_buffers=False: replicas start identical (same seed / same checkpoint) and every update to a buffer is
+    either rank-local by design (BatchNorm running statistics, as under DataParallel) or made identically on all ranks
+    (update_template below), so rank 0's buffers are not re-broadcast before every forward."""
     if world <= 1:
         return module
     if device is not None and torch.device(device).type == "cuda":
         return torch.nn.parallel.DistributedDataParallel(module, device_ids=[torch.device(device).index],
-                                                         bucket_cap_mb=BUCKET_MB, gradient_as_bucket_view=True)
-    return torch.nn.parallel.DistributedDataParallel(module, bucket_cap_mb=BUCKET_MB)
+                                                         bucket_cap_mb=BUCKET_MB, gradient_as_bucket_view=True,
+                                                         broadcast_buffers=False)
+    return torch.nn.parallel.DistributedDataParallel(module, bucket_cap_mb=BUCKET_MB, broadcast_buffers=False)
 
 
 def shard(tensor, rank, world):
-    """Contiguous batch shard of rank `rank` (images are independent in every kernel and loss)."""
+    """Contiguous batch shard of rank `rank` (images are independent in every kernel and loss).  The batch
+    must split evenly: short or empty shards would give DDP uneven inputs (hang / crash in the bucketed all-reduce)."""
     n = tensor.shape[0]
-    per = (n + world - 1) // world
-    return tensor[rank * per:min(n, (rank + 1) * per)]
+    if n % world:
+        raise ValueError("shard: batch of %d does not divide over %d ranks (drop the remainder first)" % (n, world))
+    per = n // world
+    return tensor[rank * per:(rank + 1) * per]
 
 
 def mean_scalars(values, world):

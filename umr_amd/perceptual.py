@@ -5,9 +5,12 @@ AlexNet's convolutions are dense contractions and stay on MIOpen (out of scope a
 torchvision is not installed and the pretrained weights cannot be downloaded here, so the feature extractor is
 written out (torchvision `alexnet().features` layout, taps after each of the 5 ReLUs,
 pretrained_networks.py:59-95) with RANDOM weights unless a state_dict is supplied.  The distance head
-(networks_basic.py:42-64 + util/util.py:71-83) is exact: sum over taps of 1 - mean_xy cos(f0, f1)."""
+(networks_basic.py:42-64 + util/util.py:71-83: sum over taps of 1 - mean_xy cos(f0, f1)) is one HIP launch for all
+five taps in each direction (csrc/perceptual.hip) instead of ~8 elementwise / reduction launches per tap."""
 import torch
 import torch.nn as nn
+
+from . import functional as UF
 
 
 class AlexNetFeatures(nn.Module):
@@ -30,11 +33,10 @@ class AlexNetFeatures(nn.Module):
         return outs
 
 
-def cos_sim(in0, in1, eps=1e-10):
-    """util/util.py:71-83: features normalised over channels, dot product, mean over x then y -> [N]."""
-    n0 = in0 / (torch.sqrt(torch.sum(in0 ** 2, dim=1, keepdim=True)) + eps)
-    n1 = in1 / (torch.sqrt(torch.sum(in1 ** 2, dim=1, keepdim=True)) + eps)
-    return torch.mean(torch.mean(torch.sum(n0 * n1, dim=1), dim=1), dim=1)
+def cos_sim_distance(feats0, feats1, eps=1e-10):
+    """sum over the feature pairs of 1 - util.cos_sim(f0, f1) (networks_basic.py:50-58, util/util.py:71-83) -> [N].
+    GPU tensors only (umr_cos_sim_forward / _backward); there is no eager fallback."""
+    return UF.CosSimDistanceFunction.apply(eps, *feats0, *feats1)
 
 
 class PNet(nn.Module):
@@ -47,12 +49,14 @@ class PNet(nn.Module):
         self.net = AlexNetFeatures()
 
     def forward(self, in0, in1):
-        f0 = self.net((in0 - self.shift) / self.scale)
-        f1 = self.net((in1 - self.shift) / self.scale)
-        val = 0
-        for a, b in zip(f0, f1):
-            val = val + (1. - cos_sim(a, b))
-        return val
+        # two passes as in the reference (:43-47); a side that carries no gradient (the ground-truth image) records
+        # no autograd graph, so the convolutions' backward runs over the predicted half only
+        def taps(x):
+            if x.requires_grad:
+                return self.net((x - self.shift) / self.scale)
+            with torch.no_grad():
+                return self.net((x - self.shift) / self.scale)
+        return cos_sim_distance(taps(in0), taps(in1))
 
 
 class PerceptualLoss(object):

@@ -6,9 +6,8 @@ rasterizer.py:42-55), so loss code written against the reference runs unchanged:
 
     imgs [N,4,H,H], p2f [N,F,2], aggr [N,2,2H,2H] = SoftRenderer(H, 'softmax')(verts, faces, cams, textures)
 
-Execution: one projection+gather kernel, (torch elementwise lighting only when a directional light is
-on), one face-setup + one tiled raster kernel with the 2x2 anti-aliasing pool fused; backward is the
-mirror image.  No CPU path.
+Execution: one projection + gather + surface-lighting kernel, one face-setup + one tiled raster kernel with the
+2x2 anti-aliasing pool fused; backward is the mirror image.  No CPU path.
 """
 import torch
 
@@ -63,18 +62,16 @@ class SoftRenderer(torch.nn.Module):
             cache[key] = torch.tensor(key[1], dtype=torch.float32, device=ref.device)
         return cache[key]
 
-    def _light(self, face_pre):
-        """lighting.py:50-57 (surface mode): ambient + directional * relu(n.d) per face -> [N,F,3]."""
-        col = self._const(face_pre, self.light_color)[None, None, :]
-        light = self.light_intensity_ambient * col
-        if self.light_intensity_directional != 0:
-            v10 = face_pre[:, :, 0] - face_pre[:, :, 1]
-            v12 = face_pre[:, :, 2] - face_pre[:, :, 1]
-            n = torch.nn.functional.normalize(torch.cross(v12, v10, dim=2), p=2, dim=2, eps=1e-6)
-            d = self._const(face_pre, self.light_direction)[None, None, :]
-            cosine = torch.relu(torch.sum(n * d, dim=2))
-            light = light + self.light_intensity_directional * (col * cosine[:, :, None])
-        return light
+    def silhouettes(self, vertices, faces, cams):
+        """Alpha channel of forward() only -> [N,S,S] (S = img_size): what the mask / unseen-view renders consume
+        (loss_utils.py:266, train_s1.py:200,236).  Same mesh-group convention as forward(): cams [N,7] may hold several
+        views per mesh (view n renders mesh n // (N / M)), e.g. the seen and the rotated camera of each image interleaved,
+        so both silhouettes of a training step come out of ONE launch per direction."""
+        faces = faces.int().contiguous()
+        _, face_out, _ = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
+        size = self.img_size * (2 if self.anti_aliasing else 1)
+        return UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
+                                           self.dist_eps, self.gamma_val, self.anti_aliasing)
 
     def forward(self, vertices, faces, cams, textures=None):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
@@ -86,32 +83,40 @@ class SoftRenderer(torch.nn.Module):
         N = cams.shape[0]
         if self.ids_only and self.render_type == 'hard':
             with torch.no_grad():
-                _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
+                _, face_out, _ = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
                 size = self.img_size * (2 if self.anti_aliasing else 1)
                 aggr = UF.visibility(face_out, size, self.near, self.far, True, self.eps, self.sigma_val, self.dist_eps,
                                      self.gamma_val)
             return None, aggr.new_zeros(N, faces.shape[1], 2), aggr                # hard p2f is identically 0
         if self.alpha_only:
-            _, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
-            size = self.img_size * (2 if self.anti_aliasing else 1)
-            alpha = UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
-                                                self.dist_eps, self.gamma_val, self.anti_aliasing)
+            alpha = self.silhouettes(vertices, faces, cams)
             S = alpha.shape[1]
             bg = self._const(alpha, self.background_color).view(1, 3, 1, 1).expand(N, 3, S, S)
             imgs = torch.cat([bg, alpha.unsqueeze(1)], dim=1)
             return imgs, alpha.new_zeros(N, faces.shape[1], 2), None
         directional = self.light_intensity_directional != 0
-        face_pre, face_out = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z,
-                                                           directional)
+        # lighting.py:50-57: with a directional term the per-face light comes out of the projection kernel (normals of
+        # the projected faces); ambient-only lighting is a constant factor
+        light = (self.light_intensity_ambient, self.light_intensity_directional, self.light_color,
+                 self.light_direction) if directional else None
+        _, face_out, face_light = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False,
+                                                                light)
         F = faces.shape[1]
-        if textures is None:                                              # mesh.py:46-50
-            textures = torch.ones(1 if not directional else N, F, 1, 3, dtype=torch.float32, device=vertices.device)
         if directional:
-            if textures.shape[0] != N:                                    # per-view lighting needs per-view texels
-                textures = textures.repeat_interleave(N // textures.shape[0], dim=0)
-            textures = textures * self._light(face_pre)[:, :, None, :]
-        elif self.light_intensity_ambient != 1 or any(c != 1 for c in self.light_color):
-            textures = textures * (self.light_intensity_ambient * self._const(textures, self.light_color))
+            # lighting.py:56: textures * light[:, :, None, :]; textures=None means all-ones (mesh.py:46-50), i.e. the
+            # light itself is the texture.  Per-view lighting needs per-view texels: shared sets broadcast here.
+            lit = face_light[:, :, None, :]
+            if textures is None:
+                textures = lit
+            else:
+                if textures.shape[0] != N:
+                    textures = textures.repeat_interleave(N // textures.shape[0], dim=0)
+                textures = textures * lit
+        else:
+            if textures is None:                                          # mesh.py:46-50
+                textures = self._const(vertices, [1.0] * (F * 3)).view(1, F, 1, 3)
+            if self.light_intensity_ambient != 1 or any(c != 1 for c in self.light_color):
+                textures = textures * (self.light_intensity_ambient * self._const(textures, self.light_color))
         size = self.img_size * (2 if self.anti_aliasing else 1)          # rasterizer.py:43
         return UF.soft_rasterize(face_out, textures, size, self.background_color, self.near, self.far, True,
                                  self.eps, self.sigma_val, 'euclidean', self.dist_eps, self.gamma_val,

@@ -24,6 +24,8 @@ class S1Weights:
     tex_loss_wt = 3.0
     tex_dt_loss_wt = 3.0
     tex_cycle_loss_wt = 0.5
+    stop_ori_epoch = 3.0          # train_s1.py:53: the symmetry term is on while epoch < stop_ori_epoch
+    update_template_freq = 5      # train_s1.py:66: the deformation term is on once epoch > update_template_freq
 
 
 def rotate_cam_y(cam, angle_deg):
@@ -68,8 +70,10 @@ class RenderCompareS1(nn.Module):
 
     outputs: pred_vs [B,V,3], delta_v [B,V',3], cam [B,7], tex_flow [B,F,T,T,2]
     batch:   imgs [B,3,H,H], masks [B,H,H], dts_barrier [B,1,H,H], gan_angles [B] (degrees)
-    texture_loss: callable(img_pred, img_gt, mask_gt, mask_pred) -> scalar (PerceptualTextureLoss in the
-                  reference, train_s1.py:150); default = loss_utils.texture_loss_masks (L1).
+    texture_loss: callable(img_pred, img_gt, mask_gt, mask_pred) -> scalar.  The reference uses
+                  PerceptualTextureLoss (train_s1.py:150) -- pass umr_amd.perceptual.PerceptualTextureLoss(device), as
+                  model.build_training_step does; None = loss_utils.texture_loss_masks (masked L1, :103-116).
+    epoch: current epoch (see set_epoch).
     discriminator: optional nn.Module taking [2B,1,H,H] masks (train_s1.py:243).
     """
 
@@ -80,7 +84,7 @@ class RenderCompareS1(nn.Module):
         self.image_size = image_size
         self.register_buffer("faces", faces.long())
         self.renderer = SoftRenderer(image_size, renderer_type)            # train_s1.py:105
-        self.dis_renderer = SoftRenderer(image_size, renderer_type)        # :106
+        self.dis_renderer = SoftRenderer(image_size, renderer_type)        # :106 (same settings: shares renderer's launch)
         self.hard_renderer = SoftRenderer(image_size, "hard")              # :107
         self.tex_renderer = SoftRenderer(image_size, renderer_type)        # :109-110
         self.tex_renderer.ambient_light_only()
@@ -98,6 +102,10 @@ class RenderCompareS1(nn.Module):
         self.discriminator = discriminator
         self.epoch = epoch
 
+    def set_epoch(self, epoch):
+        """train_s1.py:250-255 reads `self.curr_epoch`: which regularisers enter the total depends on it."""
+        self.epoch = epoch
+
     def forward(self, outputs, batch):
         w = self.w
         pred_vs, delta_v, proj_cam, tex_flow = outputs["pred_vs"], outputs["delta_v"], outputs["cam"], outputs["tex_flow"]
@@ -105,9 +113,14 @@ class RenderCompareS1(nn.Module):
         B = pred_vs.shape[0]
         faces = self.faces[None].expand(B, -1, -1)
         terms = {}
-        # shape losses (:199-206)
-        pred_seen, _, _ = self.renderer(pred_vs, faces, proj_cam)
-        mask_pred_seen = pred_seen[:, 3]
+        # shape losses (:199-206).  The mask render (:199) and the unseen-view render of the adversarial term (:235) draw
+        # the same meshes with the same renderer settings and only their alpha is read (:200, :236, :242): they run as
+        # ONE silhouette launch over 2B views (view 2b = predicted camera, 2b+1 = rotated camera of image b), forward
+        # and backward -- at B = 16 a single N = 16 launch leaves a third of the chip idle in its tail
+        random_cams = rotate_cam_y(proj_cam.detach(), batch["gan_angles"])                        # :232-233
+        both = self.renderer.silhouettes(pred_vs, faces, torch.stack((proj_cam, random_cams), dim=1).reshape(2 * B, 7))
+        both = both.view(B, 2, both.shape[-2], both.shape[-1])
+        mask_pred_seen, mask_pred_unseen = both[:, 0], both[:, 1]
         terms["mask"] = loss_utils.neg_iou_loss(mask_pred_seen, masks)
         terms["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
         terms["flatten"] = self.flatten_loss_fn(pred_vs).mean()
@@ -125,20 +138,22 @@ class RenderCompareS1(nn.Module):
         aggr_ids = aggr_info[:, 1].reshape(bs, -1)
         tex_cycle, _ = self.texture_cycle_fn(tex_flow, p2f_info.detach(), aggr_ids.detach())
         terms["tex_cycle"] = tex_cycle
-        # unseen-view render for the adversarial term (:232-245)
-        random_cams = rotate_cam_y(proj_cam.detach(), batch["gan_angles"])
-        pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, random_cams)
+        # adversarial term on the unseen view (:232-245)
         if self.discriminator is not None:
-            pred = torch.cat((pred_seen.detach(), pred_unseen))
+            pred = torch.cat((mask_pred_seen.detach(), mask_pred_unseen)).unsqueeze(1)             # :238, :243
             labels = gan_labels(self, B, pred.device)
-            gan_preds = self.discriminator(pred[:, 3].unsqueeze(1))
+            gan_preds = self.discriminator(pred)
             terms["gan"] = nn.functional.binary_cross_entropy_with_logits(gan_preds.view(-1), labels)
         else:  # keep the render + its backward in the step even without a discriminator network
-            terms["gan"] = pred_unseen[:, 3].mean()
+            terms["gan"] = mask_pred_unseen.mean()
+        # train_s1.py:247-265; the symmetry term only while epoch < stop_ori_epoch (:250), the deformation term only once
+        # epoch > update_template_freq (:253) -- weight 0 keeps the term in `terms` for logging, as the reference does
+        ori_wt = w.ori_reg_wt if self.epoch < w.stop_ori_epoch else 0.0
+        deform_wt = w.deform_reg_wt if self.epoch > w.update_template_freq else 0.0
         total = weighted_total(self, terms, [
             ("mask", w.mask_loss_wt), ("triangle", w.triangle_reg_wt), ("flatten", w.flatten_reg_wt),
-            ("ori", w.ori_reg_wt), ("deform", w.deform_reg_wt), ("tex", w.tex_loss_wt), ("tex_dt", w.tex_dt_loss_wt),
-            ("tex_cycle", w.tex_cycle_loss_wt), ("gan", w.gan_loss_wt)])                              # train_s1.py:247-257
+            ("ori", ori_wt), ("deform", deform_wt), ("tex", w.tex_loss_wt), ("tex_dt", w.tex_dt_loss_wt),
+            ("tex_cycle", w.tex_cycle_loss_wt), ("gan", w.gan_loss_wt)])
         return total, terms
 
 
