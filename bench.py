@@ -115,14 +115,18 @@ def main():
 
     torch.manual_seed(1234 + rank)   # per-rank synthetic shard (weak scaling: fixed per-GPU batch)
     tv, faces, outputs, batch = make_s1_inputs(args.batch, args.image_size, args.subdivide, seed=100 + rank, device=dev)
+    def build_step():
+        if args.workload == "s2":
+            from umr_amd.model import build_training_step_s2
+            return build_training_step_s2(args, dev, 2 if args.force_ddp else world)
+        from umr_amd.model import build_training_step
+        return build_training_step(tv, faces, args, dev, 2 if args.force_ddp else world)
+
     step_fn = None
     if args.workload == "s2":
-        from umr_amd.model import build_training_step_s2
         use_model = True
-        step_fn = build_training_step_s2(args, dev, 2 if args.force_ddp else world)
-    elif use_model:
-        from umr_amd.model import build_training_step
-        step_fn = build_training_step(tv, faces, args, dev, 2 if args.force_ddp else world)
+    if use_model:
+        step_fn = build_step()
     else:
         from umr_amd.perceptual import PerceptualTextureLoss
         rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size, texture_loss=PerceptualTextureLoss(dev),
@@ -146,15 +150,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step_fn()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step_fn()
-    host_dt = time.perf_counter() - t0          # time to ENQUEUE the steps (host side); dt below includes the drain
-    barrier()
-    dt = time.perf_counter() - t0
+    def measure():
+        for _ in range(args.warmup):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step_fn()
+        host_dt = time.perf_counter() - t0      # time to ENQUEUE the steps (host side); dt below includes the drain
+        barrier()
+        return loss, host_dt, time.perf_counter() - t0
+
+    # Training on synthetic (random) images is chaotic -- float-atomic summation order alone changes the trajectory -- and
+    # a run can diverge to a non-finite loss, after which every render degenerates (NaN geometry) and the timing means
+    # nothing.  Such a measurement is discarded and repeated on a freshly initialised model (all ranks decide together);
+    # the number of discarded attempts is reported in config.discarded_nonfinite_runs.
+    discarded = 0
+    while True:
+        loss, host_dt, dt = measure()
+        ok = torch.isfinite(loss.detach()).reshape(1).to(torch.float32)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if bool(ok.item()) or discarded >= 2 or not use_model:
+            break
+        discarded += 1
+        torch.manual_seed(4321 + 17 * discarded + rank)
+        step_fn = build_step()
     # roofline pass: the same steps again, untimed, with the library recording a HIP-event pair around every raster
     # main kernel on its launch stream (event creation / bookkeeping stays out of `value`)
     _lib.profile_enable(True)
@@ -231,7 +253,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                         "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
-                        "final_loss": float(loss.detach())}, **rccl),
+                        "final_loss": float(loss.detach()), "discarded_nonfinite_runs": discarded}, **rccl),
         # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
         # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the
         # variant touches, once) / its mean HIP-event duration over the profile pass.
