@@ -64,7 +64,7 @@ def test_raster_cabi_vs_reference_golden(name):
     # preprocessing is pure fp32 IEEE arithmetic in the reference's order -> bit exact
     np.testing.assert_array_equal(t2n(o["faces_info"]), g["faces_info"])
     # 1e-4 = north_star render tolerance
-    assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=0.999, max_outlier=0.6, name="soft_colors")
+    assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="soft_colors")   # measured on MI355X: max |err| 3.6e-7, every element within 1e-4
     if int(g["func_id_rgb"]) == 1:
         assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=1e-3, frac=0.999, name="aggrs")
         scale = np.abs(g["p2f_sum"]).max()
@@ -119,7 +119,7 @@ def test_smr_softrenderer_vs_reference_golden(name):
         r.ambient_light_only()
     imgs, p2f, aggr = r.forward(verts, faces, cams, tex)
     assert imgs.shape == g["imgs"].shape and aggr.shape == g["aggr"].shape
-    assert_close_frac(t2n(imgs), g["imgs"], atol=1e-4, frac=0.999, max_outlier=0.3, name="imgs")   # 1e-4: north_star
+    assert_close_frac(t2n(imgs), g["imgs"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="imgs")   # 1e-4: north_star; measured max |err| 2.4e-7
     assert_close_frac(t2n(p2f), g["p2f"], atol=2e-3, rtol=1e-3, frac=0.99, name="p2f")
     np.testing.assert_allclose(t2n(r.project_points(verts, cams)), g["proj_points"], atol=2e-6)
     imgs.backward(torch.from_numpy(g["grad_imgs"]).to(DEV))
@@ -153,7 +153,9 @@ def test_full_size_vs_oracle(oracle_built, ts, rgb):
     sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 512, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4,
                                       rgb, 'prod', 'surface')
     sc.backward(gsc.to(DEV))
-    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.999, max_outlier=1.0, name="soft_colors")  # north_star 1e-4
+    # north_star: 1e-4.  Measured at this size (2.1 M values): 99.9997-100 % within 1e-4, max |err| 1.6e-4 .. 2.7e-4 -- the
+    # handful beyond 1e-4 are pixels outside the silhouette whose colour is a ratio of ~1e-9 weights
+    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.9999, max_outlier=2e-3, name="soft_colors")
     if rgb == "softmax":
         p2f_ref = o["p2f_info"] / np.maximum(o["p2f_sum"], 1e-12)
         assert_close_frac(t2n(p2f), p2f_ref, atol=2e-3, frac=0.99, name="p2f")
@@ -467,7 +469,8 @@ def test_cfg4_size_vs_oracle(oracle_built):
     fvd, texd = fv.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True)
     sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 1024, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
     sc.backward(gsc.to(DEV))
-    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.999, max_outlier=1.0, name="soft_colors")
+    # measured (4.2 M values): 99.998 % within 1e-4, max |err| 9.7e-4
+    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.9999, max_outlier=5e-3, name="soft_colors")
     assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
     assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="gt")
 
@@ -542,7 +545,7 @@ def test_front_face_culling_and_depth_range_vs_oracle(oracle_built, rgb):
     sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 128, [0, 0, 0], cfg["near"], cfg["far"], False, 1e-3, 1e-5,
                                       'euclidean', 1e-10, 1e-4, rgb, 'prod', 'surface')
     sc.backward(gsc.to(DEV))
-    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.999, max_outlier=1.0, name="soft_colors")
+    assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-4, name="soft_colors")   # measured max 2.6e-6
     assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
     assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * max(np.abs(gt).max(), 1e-12), rtol=5e-3, frac=0.99, name="gt")
     # and the silhouette-only kernels under the same depth range (the per-face "always in range" shortcut must not fire)

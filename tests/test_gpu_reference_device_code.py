@@ -1,0 +1,120 @@
+"""GPU: the reference's OWN rasterizer device code (soft_rasterize_cuda_kernel.cu:22-659, unmodified text, compiled
+natively by hipcc for gfx950 -- oracle/ref_gpu) executed on the MI355X, as a second execution model for the raster pin:
+
+  1. against the committed raster goldens (which were produced by the SAME text run through the host shim with its
+     builder-written min/max/atomicAdd stand-ins): if both executions agree, the stand-ins did not shape the goldens;
+  2. against the product HIP path at full size (2 x 1280 faces x 512^2), reference device code and product side by side
+     on the same GPU, no CPU restatement in between.
+
+Skipped only where the prebuilt library is absent (it is built in the CPU container where /root/reference exists and
+travels with the snapshot; see oracle/README.md)."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import scene, assert_close_frac, t2n
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RASTER = ["raster_softmax_ts36.npz", "raster_softmax_ts1.npz", "raster_hard_ts1.npz", "raster_hard_ts4.npz"]
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+
+def _lib(name="libsoftras_ref_gfx950.so"):
+    path = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(path):
+        pytest.skip("%s not built (needs /root/reference at build time)" % name)
+    h = ctypes.CDLL(path)
+    h.refgpu_forward_soft_rasterize.argtypes = [_P] * 8 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P]
+    h.refgpu_backward_soft_rasterize.argtypes = [_P] * 8 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P]
+    return h
+
+
+def _run_ref(h, faces, tex, IS, cfg, gsc, background=(0., 0., 0.)):
+    """functional/soft_rasterize.py:47-75, 95-106 around the reference kernels: buffers pre-filled the reference's way."""
+    from umr_amd.functional import standard_grid
+    N, F = faces.shape[:2]
+    TS = tex.shape[2]
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    faces_info = torch.zeros(N, F, 27, device=DEV)
+    aggrs = torch.zeros(N, 2, IS, IS, device=DEV)
+    p2f_info, p2f_sum = torch.zeros(N, F, 2, device=DEV), torch.zeros(N, F, 2, device=DEV)
+    sc = torch.ones(N, 4, IS, IS, device=DEV)
+    for k in range(3):
+        sc[:, k] *= float(background[k])
+    grid = standard_grid(IS, torch.device(DEV))
+    scal = (float(cfg["near"]), float(cfg["far"]), float(cfg["eps"]), float(cfg["sigma_val"]), 2, float(cfg["dist_eps_log"]),
+            float(cfg["gamma_val"]), int(cfg["func_id_rgb"]), 2, 0, int(bool(cfg["double_side"])))
+    st = torch.cuda.current_stream().cuda_stream
+    assert h.refgpu_forward_soft_rasterize(p(faces), p(tex), p(faces_info), p(aggrs), p(grid), p(p2f_info), p(p2f_sum), p(sc),
+                                           N, F, IS, TS, *scal, st) == 0
+    gf, gt = torch.zeros(N, F, 9, device=DEV), torch.zeros_like(tex)
+    assert h.refgpu_backward_soft_rasterize(p(faces), p(tex), p(sc), p(faces_info), p(aggrs), p(gf), p(gt), p(gsc),
+                                            N, F, IS, TS, *scal, st) == 0
+    torch.cuda.synchronize()
+    return dict(faces_info=faces_info, aggrs_info=aggrs, p2f_info=p2f_info, p2f_sum=p2f_sum, soft_colors=sc, grad_faces=gf,
+                grad_textures=gt)
+
+
+@pytest.mark.parametrize("name", RASTER)
+def test_reference_device_code_on_gpu_reproduces_the_goldens(name):
+    h = _lib()
+    g = load_golden(name)
+    faces = torch.from_numpy(g["faces"]).to(DEV)
+    tex = torch.from_numpy(g["textures"]).to(DEV)
+    gsc = torch.from_numpy(g["grad_soft_colors"]).to(DEV)
+    o = _run_ref(h, faces, tex, int(g["image_size"]), g, gsc, g["background"])
+    # face preprocessing: fp32 +,-,*,/ only -> the two executions of the same text must agree to the bit
+    assert np.array_equal(t2n(o["faces_info"]).view(np.uint32), g["faces_info"].view(np.uint32))
+    # images: same text, device libm (exp / sqrt / pow) instead of the host's: agreement to a few ulp
+    assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=2e-6, frac=1.0, max_outlier=2e-6, name="refgpu_soft_colors")
+    assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=1e-5, frac=0.9999, name="refgpu_aggrs")
+    if int(g["func_id_rgb"]) == 1:
+        assert_close_frac(t2n(o["p2f_sum"]), g["p2f_sum"], atol=1e-6 * np.abs(g["p2f_sum"]).max(), rtol=1e-4, frac=1.0, name="refgpu_p2f_sum")
+    gf, gt = g["grad_faces"], g["grad_textures"]
+    # hardware float atomics: the summation order is not the host loop's
+    assert_close_frac(t2n(o["grad_faces"]).reshape(gf.shape), gf, atol=1e-5 * np.abs(gf).max(), rtol=1e-3, frac=0.999, name="refgpu_grad_faces")
+    assert_close_frac(t2n(o["grad_textures"]), gt, atol=1e-5 * max(np.abs(gt).max(), 1e-12), rtol=1e-3, frac=0.999, name="refgpu_grad_textures")
+
+
+@pytest.mark.parametrize("ts,rgb", [(36, "softmax"), (1, "hard")])
+def test_product_vs_reference_device_code_full_size(ts, rgb):
+    """Product kernels and the reference's device code side by side on the MI355X at the full BASELINE size."""
+    from oracle import torch_ref           # projection only (test infrastructure), to build screen-space faces
+    from umr_amd import functional as UF
+    h = _lib()
+    verts, faces, cams, gen = scene(2, 3, seed=77)
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).contiguous()
+    F = faces.shape[1]
+    tex = torch.rand(2, F, ts, 3, generator=gen)
+    gsc = torch.randn(2, 4, 512, 512, generator=gen)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4,
+               func_id_rgb={"hard": 0, "softmax": 1}[rgb], double_side=True)
+    ref = _run_ref(h, fv.view(2, F, 9).to(DEV), tex.to(DEV), 512, cfg, gsc.to(DEV))
+    fvd, texd = fv.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True)
+    sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 512, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, rgb)
+    sc.backward(gsc.to(DEV))
+    assert_close_frac(t2n(sc), t2n(ref["soft_colors"]), atol=1e-4, frac=0.9999, max_outlier=2e-3, name="vs_refgpu_soft_colors")
+    rp = ref["p2f_info"] / ref["p2f_sum"].clamp_min(1e-12)          # functional/soft_rasterize.py:73
+    assert_close_frac(t2n(p2f), t2n(rp), atol=2e-3, frac=0.99, name="vs_refgpu_p2f")
+    gf, gt = t2n(ref["grad_faces"]), t2n(ref["grad_textures"])
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="vs_refgpu_grad_faces")
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="vs_refgpu_grad_textures")
+
+
+def test_fma_contraction_sensitivity_of_the_reference_text():
+    """nvcc contracts a*b+c into FMA by default; the goldens (and the oracle) come from non-contracted builds.  The same
+    text built with contraction on: how far do its images move?  Reported in profiles/r02_parity_measured.jsonl; bounded by
+    the north_star tolerance so the choice of contraction mode cannot hide a parity failure."""
+    h = _lib("libsoftras_ref_gfx950_fma.so")
+    g = load_golden("raster_softmax_ts36.npz")
+    faces, tex = torch.from_numpy(g["faces"]).to(DEV), torch.from_numpy(g["textures"]).to(DEV)
+    o = _run_ref(h, faces, tex, int(g["image_size"]), g, torch.from_numpy(g["grad_soft_colors"]).to(DEV), g["background"])
+    assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=0.995, name="refgpu_fma_soft_colors")

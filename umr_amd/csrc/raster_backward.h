@@ -154,6 +154,17 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 #define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2
                        // (a third, vertical step measured slower)
 #endif
+#ifndef FM_FMA_ACC
+#define FM_FMA_ACC 0      // 1: gradient accumulators updated with explicit fused multiply-adds (the summation order of the
+#endif                    // reference's atomics is not defined either, so these sums are not pinned to a rounding sequence)
+#if FM_FMA_ACC
+#define FM_ACC(acc, a, b) acc = fmaf(a, b, acc)
+#else
+#define FM_ACC(acc, a, b) acc += (a) * (b)
+#endif
+#ifndef FM_STATE_CULL
+#define FM_STATE_CULL 1   // sub-tile skips from the saved forward state inside the culling pass (A/B: -DFM_STATE_CULL=0)
+#endif
 #ifndef FM_TEXCOPY
 #define FM_TEXCOPY 4   // private copies of a wave's LDS texel accumulators (power of two): neighbouring pixels share a
 #endif                 // texel, and same-address ds_add_f32 from one wave serialise -- spread them over copies
@@ -298,6 +309,37 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                     const float cyh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), cyl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
                     want = tile_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), 0.5f * (cxh - cxl),
                                         0.5f * (cyh - cyl), A.thr);
+#if FM_STATE_CULL
+                    // Exact sub-tile skips from the saved forward state, decided HERE by the one lane that owns the
+                    // candidate (64 candidates per pass) instead of by a whole wave visit that finds its four sub-tiles dead:
+                    //  * silhouette: every pixel of the sub-tile has alpha == 1.0f -> g (1 - alpha) finite = 0 (:584);
+                    //  * texel gradients only, soft-max: even the face's nearest depth is >= 89 gamma behind the soft-max
+                    //    maximum of every pixel -> p = D exp(<-89) / S = 0.0f (:608); hard mode: the face wins no pixel (:596).
+                    // Inside the silhouette that removes most of the back-facing half of the mesh before any visit.
+                    if (FM_TW == 4 && FM_TH == 4 && (RGB == 2 || !NEED_GF) && want && px0 + 3 < IS && pr0 + 3 < IS && (IS & 3) == 0) {
+                        const char *plane = RGB == 2 ? sc_n : ag_n + pst;           // alpha | soft-max maximum (hard: face id)
+                        const unsigned o0 = (unsigned)(pr0 * IS + px0) * 4u, rs = (unsigned)IS * 4u;
+                        const float4 q0 = ld_u4(plane, o0), q1 = ld_u4(plane, o0 + rs), q2 = ld_u4(plane, o0 + 2u * rs),
+                                     q3 = ld_u4(plane, o0 + 3u * rs);
+                        if (RGB == 2) {
+                            want = !((q0.x == 1.f) & (q0.y == 1.f) & (q0.z == 1.f) & (q0.w == 1.f) & (q1.x == 1.f) & (q1.y == 1.f) &
+                                     (q1.z == 1.f) & (q1.w == 1.f) & (q2.x == 1.f) & (q2.y == 1.f) & (q2.z == 1.f) & (q2.w == 1.f) &
+                                     (q3.x == 1.f) & (q3.y == 1.f) & (q3.z == 1.f) & (q3.w == 1.f));
+                        } else if (RGB == 1) {
+                            const float mn = fminf(fminf(fminf(fminf(q0.x, q0.y), fminf(q0.z, q0.w)), fminf(fminf(q1.x, q1.y), fminf(q1.z, q1.w))),
+                                                   fminf(fminf(fminf(q2.x, q2.y), fminf(q2.z, q2.w)), fminf(fminf(q3.x, q3.y), fminf(q3.z, q3.w))));
+                            const float zmin_c = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
+                            // same expression as the per-pixel test below; monotone in the maximum, so the sub-tile's smallest
+                            // maximum decides for all 16 pixels (NaN state: comparison false -> visited)
+                            want = !(((c_far - zmin_c) * c_rr - mn) * c_ig < -89.f);
+                        } else {
+                            const float ff = (float)f;
+                            want = (q0.x == ff) | (q0.y == ff) | (q0.z == ff) | (q0.w == ff) | (q1.x == ff) | (q1.y == ff) | (q1.z == ff) |
+                                   (q1.w == ff) | (q2.x == ff) | (q2.y == ff) | (q2.z == ff) | (q2.w == ff) | (q3.x == ff) | (q3.y == ff) |
+                                   (q3.z == ff) | (q3.w == ff);
+                        }
+                    }
+#endif
                 }
                 unsigned long long tm = __ballot(want);
                 while (tm) {
@@ -362,9 +404,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                         c_a *= p.frag * (1.f - p.frag) * (-c_nis);
                         const float k2a = 2.f * p.sign * c_a;
                         const float a0 = k2a * p.b0, a1 = k2a * p.b1, a2 = k2a * p.b2;
-                        gv[0] += a0 * p.dx; gv[1] += a0 * p.dy;
-                        gv[3] += a1 * p.dx; gv[4] += a1 * p.dy;
-                        gv[6] += a2 * p.dx; gv[7] += a2 * p.dy;
+                        FM_ACC(gv[0], a0, p.dx); FM_ACC(gv[1], a0, p.dy);
+                        FM_ACC(gv[3], a1, p.dx); FM_ACC(gv[4], a1, p.dy);
+                        FM_ACC(gv[6], a2, p.dx); FM_ACC(gv[7], a2, p.dy);
                         continue;
                     }
                     const float gscale = pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
@@ -389,7 +431,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                         const float ps = p.frag * __expf((zn - smax) * c_ig) * __builtin_amdgcn_rcpf(ssum);  // :608
                         const int tix = texel_index(q0, q1, A.R);
                         if (NEED_GT) {
-                            if (TS == 1) { gt0 += ps * g0; gt1 += ps * g1; gt2 += ps * g2; }
+                            if (TS == 1) { FM_ACC(gt0, ps, g0); FM_ACC(gt1, ps, g1); FM_ACC(gt2, ps, g2); }
                             else texel_accumulate(my_tex, tix, ps * g0, ps * g1, ps * g2, lane);
                         }
                         if (NEED_GF) {
@@ -410,9 +452,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                         c_xy *= p.frag * (1.f - p.frag) * (-c_nis);  // :632
                         const float k2 = 2.f * p.sign * c_xy;        // :640
                         const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
-                        gv[0] += b0 * p.dx; gv[1] += b0 * p.dy; gv[2] += gz0;
-                        gv[3] += b1 * p.dx; gv[4] += b1 * p.dy; gv[5] += gz1;
-                        gv[6] += b2 * p.dx; gv[7] += b2 * p.dy; gv[8] += gz2;
+                        FM_ACC(gv[0], b0, p.dx); FM_ACC(gv[1], b0, p.dy); gv[2] += gz0;
+                        FM_ACC(gv[3], b1, p.dx); FM_ACC(gv[4], b1, p.dy); gv[5] += gz1;
+                        FM_ACC(gv[6], b2, p.dx); FM_ACC(gv[7], b2, p.dy); gv[8] += gz2;
                     }
                 }
             }
