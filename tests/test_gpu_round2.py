@@ -356,3 +356,85 @@ def test_bench_json_contract_small():
     assert rf["bound"] == "hbm" and rf["launches"] >= 1 and 0 < rf["frac"] < 1 and rf["forward_kernel"]["launches"] >= 1
     assert rf["silhouette_forward"]["launches"] >= 1 and rf["silhouette_backward"]["launches"] >= 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+
+
+def test_registered_custom_ops_schema_and_fake_kernels():
+    """torch.ops.umr.{soft_rasterize, soft_rasterize_backward, silhouette, silhouette_backward}: torch.library.opcheck
+    (schema, fake-tensor propagation against the real kernels, autograd registration) on real inputs."""
+    from torch.library import opcheck
+    from umr_amd import ops  # noqa: F401
+    from umr_amd import functional as UF
+    verts, faces, cams, gen = scene(2, 1, seed=4)
+    _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    tex = torch.rand(1, faces.shape[1], 4, 3, generator=gen).to(DEV)           # one texture set shared by both views
+    args = (fv.detach().requires_grad_(True), tex.requires_grad_(True), 32, [0., 0., 0.], 1., 100., True, 1e-3, 1e-5, 1e-10,
+            1e-4, 1, True, True)
+    opcheck(torch.ops.umr.soft_rasterize.default, args, test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    opcheck(torch.ops.umr.silhouette.default, (fv.detach().requires_grad_(True), 32, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, True),
+            test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    img, p2f, aggr, saved = torch.ops.umr.soft_rasterize(*args)
+    assert img.shape == (2, 4, 16, 16) and saved.shape == (2, 4, 32, 32) and aggr.shape == (2, 2, 32, 32)
+    img.sum().backward()
+    assert args[0].grad.shape == fv.shape and args[1].grad.shape == tex.shape     # texture gradient summed over the group
+
+
+def test_hot_path_step_replays_from_a_hip_graph():
+    """The whole render-and-compare step (--model 0 path of bench.py: every raster / loss kernel forward AND backward, the
+    AlexNet perceptual term included) captured once into a HIP graph and replayed: same losses and gradients as the eager
+    step, also after the inputs are changed in place.  (Float-atomic sums -- p2f, the projection scatter -- are not
+    bit-reproducible even eager-to-eager, hence 1e-5 relative instead of bit equality; the deterministic terms are equal to
+    the bit.)"""
+    from umr_amd.perceptual import PerceptualTextureLoss
+    from umr_amd.synthetic import make_s1_inputs
+    from umr_amd.train_step import RenderCompareS1
+    torch.manual_seed(9)
+    tv, faces, outputs, batch = make_s1_inputs(4, 128, 2, seed=3, device=DEV)
+    rc = RenderCompareS1(tv.to(DEV), faces.to(DEV), 128, texture_loss=PerceptualTextureLoss(DEV)).to(DEV)
+    leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
+
+    def step():
+        for l in leaves:
+            l.grad = None
+        outputs["pred_vs"] = outputs["mean_shape"][None] + outputs["delta_v"]
+        total, terms = rc(outputs, batch)
+        total.backward()
+        return total, terms
+
+    def snapshot(total, terms):
+        torch.cuda.synchronize()
+        return float(total), {k: float(v) for k, v in terms.items()}, [l.grad.detach().clone() for l in leaves]
+
+    eager = snapshot(*step())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_total, static_terms = step()
+    for l in leaves:
+        l.grad.zero_()
+    graph.replay()
+    replay = snapshot(static_total, static_terms)
+
+    def same(a, b):
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]), (a[0], b[0])
+        for k in b[1]:
+            assert abs(a[1][k] - b[1][k]) <= 1e-5 * max(1.0, abs(b[1][k])), k
+        for k in ("mask", "triangle", "flatten", "tex_dt"):            # no float atomics on these paths
+            assert a[1][k] == b[1][k], k
+        for x, y in zip(a[2], b[2]):
+            assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max())
+    same(replay, eager)
+    # new inputs, written in place into the captured buffers
+    with torch.no_grad():
+        outputs["cam"][:, 0] *= 0.9
+        outputs["delta_v"].mul_(0.5)
+        batch["masks"].copy_(batch["masks"].roll(1, 0))
+    graph.replay()
+    replay2 = snapshot(static_total, static_terms)
+    eager2 = snapshot(*step())
+    same(replay2, eager2)
+    assert abs(eager2[0] - eager[0]) > 1e-3            # the inputs really changed

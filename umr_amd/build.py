@@ -16,6 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
          "-munsafe-fp-atomics",   # native global_atomic_add_f32 instead of CAS loops
          "-ffp-contract=off",     # branch-deciding expressions round like the reference's float code
+         "-fno-slp-vectorize",    # no v_pk_{mul,add,fma}_f32 pairs: a packed op issues in ~5 cycles against 2 x 2.4 for the
+                                  # two scalar ops it replaces (tools/ubench), and the pairing costs extra moves (-2..11 %)
          "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 

@@ -2,6 +2,7 @@
 // runs in production, and k_raster_backward, the pixel-major variant kept for A/B runs and very large TS.
 #pragma once
 #include "raster_core.h"
+#include <type_traits>
 
 namespace {
 
@@ -154,8 +155,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 #define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2
                        // (a third, vertical step measured slower)
 #endif
+#ifndef FM_VREC
+#define FM_VREC 0         // 1: the face's inverse barycentric matrix and corner coordinates as VGPR operands (FaceV)
+#endif
 #ifndef FM_FMA_ACC
-#define FM_FMA_ACC 0      // 1: gradient accumulators updated with explicit fused multiply-adds (the summation order of the
+#define FM_FMA_ACC 1      // 1: gradient accumulators updated with explicit fused multiply-adds (the summation order of the
 #endif                    // reference's atomics is not defined either, so these sums are not pinned to a rounding sequence)
 #if FM_FMA_ACC
 #define FM_ACC(acc, a, b) acc = fmaf(a, b, acc)
@@ -270,17 +274,21 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // TS == 1 texel gradient
     if (live) {
-        Face fc;
+        // VGPR-resident operands where the register budget of 7 waves / SIMD has room for them (silhouette and
+        // texel-gradient-only variants: 56-60 VGPRs with them; the full variant would spill)
+        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF);
+        typename std::conditional<VREC, FaceV, Face>::type fc;
         load_face(fc, A.rec + ((size_t)n * F + f) * REC);
+        if constexpr (VREC) fc.fill();
         const float *__restrict__ tex_f = A.textures + ((size_t)(n / A.tex_group) * F + f) * TS * 3;
         // pixel-index window of the dilated bbox, widened by one pixel; the exact per-pixel reject of the
         // reference (:536) still runs inside eval_pair, so the window only has to be conservative.
         // xp(i) = (2i + 1 - IS)/IS  <=>  i = (xp*IS + IS - 1)/2
         const float h = 0.5f * IS;
-        int x0 = (int)floorf(fc.g<R_XLO>() * h + h - 0.5f) - 1, x1 = (int)ceilf(fc.g<R_XHI>() * h + h - 0.5f) + 1;
-        int yi0 = (int)floorf(fc.g<R_YLO>() * h + h - 0.5f) - 1, yi1 = (int)ceilf(fc.g<R_YHI>() * h + h - 0.5f) + 1;
+        int x0 = (int)floorf(fc.template g<R_XLO>() * h + h - 0.5f) - 1, x1 = (int)ceilf(fc.template g<R_XHI>() * h + h - 0.5f) + 1;
+        int yi0 = (int)floorf(fc.template g<R_YLO>() * h + h - 0.5f) - 1, yi1 = (int)ceilf(fc.template g<R_YHI>() * h + h - 0.5f) + 1;
         // NaN / inf bounds: comparisons below fail safe to the full image (the reference would visit all pixels)
-        if (!(fc.g<R_XLO>() == fc.g<R_XLO>() && fc.g<R_XHI>() == fc.g<R_XHI>() && fc.g<R_YLO>() == fc.g<R_YLO>() && fc.g<R_YHI>() == fc.g<R_YHI>())) { x0 = 0; x1 = IS - 1; yi0 = 0; yi1 = IS - 1; }
+        if (!(fc.template g<R_XLO>() == fc.template g<R_XLO>() && fc.template g<R_XHI>() == fc.template g<R_XHI>() && fc.template g<R_YLO>() == fc.template g<R_YLO>() && fc.template g<R_YHI>() == fc.template g<R_YHI>())) { x0 = 0; x1 = IS - 1; yi0 = 0; yi1 = IS - 1; }
         x0 = max(x0, 0); x1 = min(x1, IS - 1); yi0 = max(yi0, 0); yi1 = min(yi1, IS - 1);
         const int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;  // row = IS-1-yi
         if (x0 <= x1 && r0 <= r1) {
@@ -292,9 +300,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
             const bool pow2 = COMMON ? true : ((IS & (IS - 1)) == 0);
             const float inv_is = 1.f / (float)IS;
             const int ntx = tx1 - tx0 + 1, ntiles = ntx * (ty1 - ty0 + 1);
-            const float4 i0 = make_float4(fc.g<R_INV + 0>(), fc.g<R_INV + 1>(), fc.g<R_INV + 2>(), fc.g<R_INV + 3>());
-            const float4 i1 = make_float4(fc.g<R_INV + 4>(), fc.g<R_INV + 5>(), fc.g<R_INV + 6>(), fc.g<R_INV + 7>());
-            const float4 i2 = make_float4(fc.g<R_INV + 8>(), fc.g<R_K0>(), fc.g<R_K1>(), fc.g<R_K2>());
+            const float4 i0 = make_float4(fc.template g<R_INV + 0>(), fc.template g<R_INV + 1>(), fc.template g<R_INV + 2>(), fc.template g<R_INV + 3>());
+            const float4 i1 = make_float4(fc.template g<R_INV + 4>(), fc.template g<R_INV + 5>(), fc.template g<R_INV + 6>(), fc.template g<R_INV + 7>());
+            const float4 i2 = make_float4(fc.template g<R_INV + 8>(), fc.template g<R_K0>(), fc.template g<R_K1>(), fc.template g<R_K2>());
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
             for (int tb = 0; tb < ntiles; tb += 64) {
                 // one lane per sub-tile: drop those no pixel of which can survive (conservative), then walk the rest
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                         } else if (RGB == 1) {
                             const float mn = fminf(fminf(fminf(fminf(q0.x, q0.y), fminf(q0.z, q0.w)), fminf(fminf(q1.x, q1.y), fminf(q1.z, q1.w))),
                                                    fminf(fminf(fminf(q2.x, q2.y), fminf(q2.z, q2.w)), fminf(fminf(q3.x, q3.y), fminf(q3.z, q3.w))));
-                            const float zmin_c = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
+                            const float zmin_c = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
                             // same expression as the per-pixel test below; monotone in the maximum, so the sub-tile's smallest
                             // maximum decides for all 16 pixels (NaN state: comparison false -> visited)
                             want = !(((c_far - zmin_c) * c_rr - mn) * c_ig < -89.f);
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             dead = false;
                             if (!NEED_GF) {   // (with vertex gradients both terms must vanish: too rare to pay for)
                                 const float smx = ld_u(ag_n, pn4 + pst);
-                                const float zmin_f = fminf(fminf(fc.g<R_Z0>(), fc.g<R_Z1>()), fc.g<R_Z2>());
+                                const float zmin_f = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
                                                 : ((c_far - zmin_f) * c_rr - smx) * c_ig < -89.f;
                             }
@@ -443,9 +451,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             c_rgb *= ps;
                             c_xy += c_rgb * __builtin_amdgcn_rcpf(p.frag);
                             const float c_z = -(c_rgb * c_ig * c_rr) * zp * zp;  // :624
-                            gz0 = c_z * q0 * fc.g<R_RZ0>() * fc.g<R_RZ0>();
-                            gz1 = c_z * q1 * fc.g<R_RZ1>() * fc.g<R_RZ1>();
-                            gz2 = c_z * q2 * fc.g<R_RZ2>() * fc.g<R_RZ2>();
+                            gz0 = c_z * q0 * fc.template g<R_RZ0>() * fc.template g<R_RZ0>();
+                            gz1 = c_z * q1 * fc.template g<R_RZ1>() * fc.template g<R_RZ1>();
+                            gz2 = c_z * q2 * fc.template g<R_RZ2>() * fc.template g<R_RZ2>();
                         }
                     }
                     if (NEED_GF) {

@@ -168,10 +168,30 @@ struct Face {  // wave-uniform: 32 SGPRs + the record's address
         if constexpr (I < 16) return qa[I];
         else return qb[I - 16];
     }
+    // hot arithmetic operands: inverse barycentric matrix and corner coordinates.  FaceV (below) overrides these with
+    // VGPR-resident copies: on gfx950 a VALU instruction with an SGPR source issues at half the rate of the same
+    // instruction on VGPRs (tools/ubench/valu_ubench.hip: v_mul_f32 2.4 vs 4.3 cycles per wave-instruction)
+    template <int I> __device__ __forceinline__ float inv() const { return g<R_INV + I>(); }
+    template <int I> __device__ __forceinline__ float xy() const { return g<R_X0 + I>(); }
     __device__ __forceinline__ int obt() const { return (__float_as_int(g<R_FLAGS>()) & 3) - 1; }
     __device__ __forceinline__ bool front() const { return g<R_FRONT>() != 0.f; }
     __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
     __device__ __forceinline__ bool depth_in_range() const { return (__float_as_int(g<R_FLAGS>()) & 8) != 0; }
+};
+
+struct FaceV : Face {   // + 15 VGPRs per lane, filled once per face by the face-major backward (a wave owns one face)
+    float vinv[9], vxy[6];
+    template <int I> __device__ __forceinline__ float inv() const { return vinv[I]; }
+    template <int I> __device__ __forceinline__ float xy() const { return vxy[I]; }
+    __device__ __forceinline__ void fill() {
+#define UMR_VMOV(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
+        UMR_VMOV(vinv[0], g<R_INV + 0>()); UMR_VMOV(vinv[1], g<R_INV + 1>()); UMR_VMOV(vinv[2], g<R_INV + 2>());
+        UMR_VMOV(vinv[3], g<R_INV + 3>()); UMR_VMOV(vinv[4], g<R_INV + 4>()); UMR_VMOV(vinv[5], g<R_INV + 5>());
+        UMR_VMOV(vinv[6], g<R_INV + 6>()); UMR_VMOV(vinv[7], g<R_INV + 7>()); UMR_VMOV(vinv[8], g<R_INV + 8>());
+        UMR_VMOV(vxy[0], g<R_X0>()); UMR_VMOV(vxy[1], g<R_Y0>()); UMR_VMOV(vxy[2], g<R_X1>());
+        UMR_VMOV(vxy[3], g<R_Y1>()); UMR_VMOV(vxy[4], g<R_X2>()); UMR_VMOV(vxy[5], g<R_Y2>());
+#undef UMR_VMOV
+    }
 };
 
 __device__ __forceinline__ void load_face(Face &fc, const float *rg) {
@@ -199,21 +219,22 @@ __device__ __forceinline__ float div_r(float a, float b, float r) {
 
 // bbox reject (:355), barycentric (:25-29), euclidean distance (:63-152), threshold reject (:382),
 // sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
-__device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, float yp, float threshold,
+template <class FaceT>
+__device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, float yp, float threshold,
                                           float neg_inv_sigma) {
     // Written branch-free (predicates + selects): per-lane divergence would otherwise cost ~80 scalar
     // exec-mask instructions per face visit.  Dead lanes compute garbage that the returned predicate masks.
-    const bool inb = !((xp > fc.g<R_XHI>()) | (xp < fc.g<R_XLO>()) | (yp > fc.g<R_YHI>()) | (yp < fc.g<R_YLO>()));
+    const bool inb = !((xp > fc.template g<R_XHI>()) | (xp < fc.template g<R_XLO>()) | (yp > fc.template g<R_YHI>()) | (yp < fc.template g<R_YLO>()));
     // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
     // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
-    const float w0 = (fc.g<R_INV + 0>() * xp + fc.g<R_INV + 1>() * yp) + fc.g<R_INV + 2>();
-    const float w1 = (fc.g<R_INV + 3>() * xp + fc.g<R_INV + 4>() * yp) + fc.g<R_INV + 5>();
-    const float w2 = (fc.g<R_INV + 6>() * xp + fc.g<R_INV + 7>() * yp) + fc.g<R_INV + 8>();
+    const float w0 = (fc.template inv<0>() * xp + fc.template inv<1>() * yp) + fc.template inv<2>();
+    const float w1 = (fc.template inv<3>() * xp + fc.template inv<4>() * yp) + fc.template inv<5>();
+    const float w2 = (fc.template inv<6>() * xp + fc.template inv<7>() * yp) + fc.template inv<8>();
     p.w0 = w0; p.w1 = w1; p.w2 = w2;
     const bool inside = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
     // inside: nearest edge LINE, first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
     // corner k+2 and its squared distance is w_c^2 K_c
-    const float m0 = w2 * w2 * fc.g<R_K2>(), m1 = w0 * w0 * fc.g<R_K0>(), m2 = w1 * w1 * fc.g<R_K1>();
+    const float m0 = w2 * w2 * fc.template g<R_K2>(), m1 = w0 * w0 * fc.template g<R_K0>(), m2 = w1 * w1 * fc.template g<R_K1>();
     const bool c1 = m1 < m0;
     const float best = c1 ? m1 : m0;
     const int kin = (m2 < best) ? 2 : (c1 ? 1 : 0);
@@ -223,11 +244,11 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, flo
     // and/or ops -- as nested selects the compiler turns it into a dynamically indexed vector read, which on gfx9
     // means copying 16 SGPRs to VGPRs (8 v_mov_b64 + s_set_gpr_idx) on every face visit
     const int mk0 = -(int)(ob == 0), mk1 = -(int)(ob == 1), mk2 = -(int)(ob == 2);
-    const float cx = __int_as_float((__float_as_int(fc.g<R_X0>()) & mk0) | (__float_as_int(fc.g<R_X1>()) & mk1) |
-                                    (__float_as_int(fc.g<R_X2>()) & mk2));
-    const float cy = __int_as_float((__float_as_int(fc.g<R_Y0>()) & mk0) | (__float_as_int(fc.g<R_Y1>()) & mk1) |
-                                    (__float_as_int(fc.g<R_Y2>()) & mk2));
-    const bool ovr = (xp - cx) * fc.g<R_OX>() + (yp - cy) * fc.g<R_OY>() > 0;
+    const float cx = __int_as_float((__float_as_int(fc.template g<R_X0>()) & mk0) | (__float_as_int(fc.template g<R_X1>()) & mk1) |
+                                    (__float_as_int(fc.template g<R_X2>()) & mk2));
+    const float cy = __int_as_float((__float_as_int(fc.template g<R_Y0>()) & mk0) | (__float_as_int(fc.template g<R_Y1>()) & mk1) |
+                                    (__float_as_int(fc.template g<R_Y2>()) & mk2));
+    const bool ovr = (xp - cx) * fc.template g<R_OX>() + (yp - cy) * fc.template g<R_OY>() > 0;
     // Region code m = n0 | n1 << 1 | n2 << 2 with n_k = (w_k <= 0); the reference's if-chain (:112-126) is a table of
     // m -- single flag: opposite edge (n0 -> 1, n1 -> 2, n2 -> 0); two flags: the vertex region between them
     // ({n0,n1} -> 2, {n2,n0} -> 1, {n1,n2} -> 0; all three -- degenerate faces only -- ends like {n1,n2}); none: -1 --
@@ -257,8 +278,8 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const Face &fc, float xp, flo
     const float b1 = k0 ? bb : (k1 ? ba : 0.f);
     const float b2 = k0 ? 0.f : (k1 ? bb : ba);
     const float t0 = b0 - w0, t1 = b1 - w1, t2 = b2 - w2;
-    const float dx = (t0 * fc.g<R_X0>() + t1 * fc.g<R_X1>()) + t2 * fc.g<R_X2>();  // :95-96, :148-149
-    const float dy = (t0 * fc.g<R_Y0>() + t1 * fc.g<R_Y1>()) + t2 * fc.g<R_Y2>();
+    const float dx = (t0 * fc.template xy<0>() + t1 * fc.template xy<2>()) + t2 * fc.template xy<4>();  // :95-96, :148-149
+    const float dy = (t0 * fc.template xy<1>() + t1 * fc.template xy<3>()) + t2 * fc.template xy<5>();
     const float dis = dx * dx + dy * dy;
     p.b0 = b0; p.b1 = b1; p.b2 = b2; p.dx = dx; p.dy = dy;
     p.sign = inside ? 1.f : -1.f;

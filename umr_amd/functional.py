@@ -37,8 +37,19 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-class SoftRasterizeFunction(Function):
-    """Drop-in for external/SoftRas/soft_renderer/functional/soft_rasterize.py:9-108.
+def _check_raster_shapes(face_vertices, textures):
+    fv, tex = face_vertices, textures
+    N, F = fv.shape[:2] if fv.dim() >= 2 else (0, 0)
+    if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] < 1 or N % tex.shape[0] \
+            or N // tex.shape[0] > 65535 or tex.shape[1] != F or tex.shape[3] != 3:
+        raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N or N/G,F,TS,3]; got "
+                           "%s and %s" % (tuple(fv.shape), tuple(tex.shape)))   # kernels index textures by (n//G, f)
+
+
+class SoftRasterizeFunction:
+    """Drop-in for external/SoftRas/soft_renderer/functional/soft_rasterize.py:9-108 (`.apply(...)` with the same
+    positional arguments).  The autograd formula lives on the registered operator torch.ops.umr.soft_rasterize
+    (umr_amd/ops.py); this class keeps the reference's call form.
 
     Extra (trailing) arguments drive the fused MI355X paths and default to the reference behaviour:
       pool:       also return/consume the 2x2 average-pooled image (anti-aliasing fused into the kernels;
@@ -47,120 +58,38 @@ class SoftRasterizeFunction(Function):
     """
 
     @staticmethod
-    def forward(ctx, face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
-                fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
-                gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-                pool=False, need_p2f=True):
-        L = _lib.lib()
-        dev = face_vertices.device
-        fv = _f32c(face_vertices)
-        tex = _f32c(textures)
-        N, F = fv.shape[:2]
-        if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] < 1 or N % tex.shape[0] \
-                or N // tex.shape[0] > 65535 or tex.shape[1] != F or tex.shape[3] != 3:
-            raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N or N/G,F,TS,3]; got "
-                               "%s and %s" % (tuple(fv.shape), tuple(tex.shape)))   # kernels index textures by (n//G, f)
-        G = N // tex.shape[0]     # G views share one texture set (the reference repeats textures x K, loss_utils.py:303-306)
-        ctx.tex_group = G
-        TS = tex.shape[2]
-        IS = int(image_size)
-        ctx.cfg = (IS, float(near), float(far), float(eps), float(sigma_val), _FUNC_DIST[dist_func],
-                   float(math.log(1. / dist_eps - 1.)), float(gamma_val), _FUNC_RGB[aggr_func_rgb],
-                   _FUNC_ALPHA[aggr_func_alpha], _FUNC_SAMPLE[texture_type], 1 if fill_back else 0)
-        ctx.pool = bool(pool)
-        # the reference fills 0.8 GB of buffers per N=128 call (functional/soft_rasterize.py:47-55); here the
-        # kernel takes the background colour by value and writes every plane, so nothing is pre-filled
-        aggrs_info = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
-        p2f_acc = torch.zeros(2, N, F, 2, device=dev, dtype=torch.float32)
-        p2f_info, p2f_sum = p2f_acc[0], p2f_acc[1]
-        soft_colors = torch.empty(N, 4, IS, IS, device=dev, dtype=torch.float32)
-        bg = (ctypes.c_float * 3)(float(background_color[0]), float(background_color[1]), float(background_color[2]))
-        pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
-        grid = standard_grid(IS, dev) if (need_p2f and ctx.cfg[8] == 1) else None
-        ws_bytes = L.umr_raster_workspace_bytes(N, F)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
-        rc = L.umr_raster_forward(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_info),
-                                  ptr(p2f_sum), ptr(soft_colors), ptr(pooled), N, F, TS, IS_, near_, far_, eps_,
-                                  sig, fd, de, gam, frgb, fal, fsm, ds, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
-                                  ws_bytes, _lib.stream_ptr(dev))
-        _lib.check(rc, "umr_raster_forward")
-        p2f = p2f_info / p2f_sum.clamp_min(1e-12)  # functional/soft_rasterize.py:73
-        ctx.save_for_backward(fv, tex, soft_colors, aggrs_info)
-        ctx.fv_shape = face_vertices.shape
-        ctx.mark_non_differentiable(p2f, aggrs_info)
-        return (pooled if pool else soft_colors), p2f, aggrs_info
-
-    @staticmethod
-    def backward(ctx, grad_soft_colors, grad_p2f_info=None, grad_aggrs_info=None):
-        L = _lib.lib()
-        fv, tex, soft_colors, aggrs_info = ctx.saved_tensors
-        dev = fv.device
-        N, F = fv.shape[:2]
-        TS = tex.shape[2]
-        need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32) if need_gf else None
-        G = ctx.tex_group
-        grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32) if need_gt else None   # per view
-        g = grad_soft_colors.to(torch.float32).contiguous()
-        ws_bytes = L.umr_raster_workspace_bytes(N, F)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
-        rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
-                                   ptr(grad_textures), ptr(g), (1 if ctx.pool else 0) | (G << 8), 1 if need_gf else 0,
-                                   1 if need_gt else 0, N, F, TS, IS_, near_, far_, eps_, sig, fd, de, gam, frgb,
-                                   fal, fsm, ds, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
-        _lib.check(rc, "umr_raster_backward")
-        gf = grad_faces.view(ctx.fv_shape) if need_gf else None
-        if need_gt and G > 1:
-            grad_textures = grad_textures.view(N // G, G, F, TS, 3).sum(1)   # autograd of the reference's repeat
-        return (gf, grad_textures) + (None,) * 15
+    def apply(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
+              fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
+              gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
+              pool=False, need_p2f=True):
+        from . import ops  # noqa: F401  (registers torch.ops.umr.*)
+        _check_raster_shapes(face_vertices, textures)
+        if _FUNC_DIST[dist_func] != 2 or _FUNC_ALPHA[aggr_func_alpha] != 2 or _FUNC_SAMPLE[texture_type] != 0:
+            raise RuntimeError("soft_rasterize: only dist_func='euclidean', aggr_func_alpha='prod', texture_type='surface' "
+                               "(the modes UMR instantiates, nnutils/smr.py:53-66) are built")
+        if not face_vertices.is_cuda:
+            raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
+        image, p2f, aggrs, _ = torch.ops.umr.soft_rasterize(
+            face_vertices, textures, int(image_size), [float(c) for c in background_color], float(near), float(far),
+            bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), _FUNC_RGB[aggr_func_rgb],
+            bool(pool), bool(need_p2f))
+        return image, p2f, aggrs
 
 
-class SilhouetteFunction(Function):
+class SilhouetteFunction:
     """Alpha channel of the soft render only (UMR_RASTER_ALPHA_ONLY): face_vertices [N,F,3,3] -> alpha [N,S,S]
     with S = image_size (or image_size/2 when `pool`).  Bit-identical to channel 3 of SoftRasterizeFunction; the
-    backward is the reference's with a zero rgb gradient (mask / GAN-view renders)."""
+    backward is the reference's with a zero rgb gradient (mask / GAN-view renders).
+    Registered operator: torch.ops.umr.silhouette."""
 
     @staticmethod
-    def forward(ctx, face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
-        L = _lib.lib()
-        dev = face_vertices.device
-        fv = _f32c(face_vertices)
-        N, F = fv.shape[:2]
-        IS = int(image_size)
-        ctx.cfg = (IS, float(near), float(far), float(eps), float(sigma_val), 2, float(math.log(1. / dist_eps - 1.)),
-                   float(gamma_val), 1, 2, 0, 1 if fill_back else 0)
-        ctx.pool = bool(pool)
-        alpha = torch.empty(N, IS, IS, device=dev, dtype=torch.float32)
-        pooled = torch.empty(N, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
-        ws_bytes = L.umr_raster_workspace_bytes(N, F)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
-        rc = L.umr_raster_forward(ptr(fv), None, None, None, None, None, None, ptr(alpha), ptr(pooled), N, F, 1, IS_,
-                                  near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds, 2 | 1, None, ptr(ws),
-                                  ws_bytes, _lib.stream_ptr(dev))
-        _lib.check(rc, "umr_raster_forward(alpha only)")
-        ctx.save_for_backward(fv, alpha)
-        ctx.fv_shape = face_vertices.shape
-        return pooled if pool else alpha
-
-    @staticmethod
-    def backward(ctx, g):
-        L = _lib.lib()
-        fv, alpha = ctx.saved_tensors
-        dev = fv.device
-        N, F = fv.shape[:2]
-        grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32)
-        g = g.to(torch.float32).contiguous()
-        ws_bytes = L.umr_raster_workspace_bytes(N, F)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        (IS_, near_, far_, eps_, sig, fd, de, gam, frgb, fal, fsm, ds) = ctx.cfg
-        rc = L.umr_raster_backward(ptr(fv), None, ptr(alpha), None, None, ptr(grad_faces), None, ptr(g),
-                                   2 | (1 if ctx.pool else 0), 1, 0, N, F, 1, IS_, near_, far_, eps_, sig, fd, de, gam,
-                                   frgb, fal, fsm, ds, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
-        _lib.check(rc, "umr_raster_backward(alpha only)")
-        return (grad_faces.view(ctx.fv_shape),) + (None,) * 9
+    def apply(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
+        from . import ops  # noqa: F401
+        if not face_vertices.is_cuda:
+            raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
+        out, _ = torch.ops.umr.silhouette(face_vertices, int(image_size), float(near), float(far), bool(fill_back), float(eps),
+                                          float(sigma_val), float(dist_eps), float(gamma_val), bool(pool))
+        return out
 
 
 def visibility(face_vertices, image_size, near=1., far=100., fill_back=True, eps=1e-3, sigma_val=1e-5, dist_eps=1e-10,

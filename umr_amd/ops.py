@@ -1,0 +1,217 @@
+"""The C-ABI rasterizer entry points as registered PyTorch custom ops (`torch.ops.umr.*`).
+
+The reference exposes its rasterizer to PyTorch as an extension module with two functions
+(external/SoftRas/soft_renderer/cuda/soft_rasterize_cuda.cpp:141-144: forward_soft_rasterize, backward_soft_rasterize)
+and wraps them in an autograd.Function (functional/soft_rasterize.py:9-108).  Here the same two calls -- umr_raster_forward /
+umr_raster_backward of libumr_hip.so -- are registered through torch.library with
+
+  * a device implementation (ctypes call, enqueued on the current HIP stream, no host synchronisation),
+  * a fake (meta) implementation, so shapes / dtypes propagate under FakeTensor tracing (torch.compile, export,
+    torch.library.opcheck) without touching the GPU,
+  * an autograd formula (umr::soft_rasterize's backward is umr::soft_rasterize_backward),
+
+so the hot-path step is visible to PyTorch's graph machinery as ordinary operators and can be captured in a HIP graph
+(tests/test_gpu_round2.py::test_hot_path_step_replays_from_a_hip_graph).  umr_amd.functional.soft_rasterize and the
+SoftRenderer route through these ops.
+
+  umr::soft_rasterize(face_vertices[N,F,3,3], textures[N/G,F,TS,3], image_size, background[3], near, far, fill_back, eps,
+                      sigma_val, dist_eps, gamma_val, rgb_mode{0 hard,1 softmax}, pool, need_p2f)
+        -> (image [N,4,S,S] (S = image_size or image_size/2 when pool), p2f [N,F,2], aggrs_info [N,2,IS,IS],
+            soft_colors [N,4,IS,IS] (saved state; == image when not pool))
+  umr::soft_rasterize_backward(face_vertices, textures, soft_colors, aggrs_info, grad_image, <same scalars>,
+                               need_grad_faces, need_grad_textures) -> (grad_face_vertices, grad_textures)
+  umr::silhouette(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
+        -> (alpha_out [N,S,S], alpha [N,IS,IS] (saved state))
+  umr::silhouette_backward(face_vertices, alpha, grad_alpha_out, <same scalars>) -> grad_face_vertices
+"""
+import ctypes
+import math
+from typing import List, Tuple
+
+import torch
+from torch.library import custom_op
+
+from . import _lib
+from ._lib import ptr
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode):
+    # the 12 scalars of soft_rasterize_cuda.cpp:71-82 (dist 'euclidean' = 2, alpha 'prod' = 2, surface textures = 0)
+    return (int(image_size), float(near), float(far), float(eps), float(sigma_val), 2, float(math.log(1. / dist_eps - 1.)),
+            float(gamma_val), int(rgb_mode), 2, 0, 1 if fill_back else 0)
+
+
+@custom_op("umr::soft_rasterize", mutates_args=(), device_types="cuda")
+def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
+                      near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
+                      gamma_val: float, rgb_mode: int, pool: bool, need_p2f: bool
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    from .functional import standard_grid
+    L = _lib.lib()
+    dev = face_vertices.device
+    fv, tex = _f32c(face_vertices), _f32c(textures)
+    N, F = fv.shape[:2]
+    if fv.dim() != 4 or fv.shape[2:] != (3, 3) or tex.dim() != 4 or tex.shape[0] < 1 or N % tex.shape[0] \
+            or N // tex.shape[0] > 65535 or tex.shape[1] != F or tex.shape[3] != 3:
+        raise RuntimeError("soft_rasterize: face_vertices must be [N,F,3,3] and textures [N or N/G,F,TS,3]; got "
+                           "%s and %s" % (tuple(fv.shape), tuple(tex.shape)))   # kernels index textures by (n//G, f)
+    G = N // tex.shape[0]     # G views share one texture set (the reference repeats textures x K, loss_utils.py:303-306)
+    TS, IS = tex.shape[2], int(image_size)
+    # the reference fills 0.8 GB of buffers per N=128 call (functional/soft_rasterize.py:47-55); here the kernel takes the
+    # background colour by value and writes every plane, so nothing is pre-filled
+    aggrs_info = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
+    p2f_acc = torch.zeros(2, N, F, 2, device=dev, dtype=torch.float32)
+    soft_colors = torch.empty(N, 4, IS, IS, device=dev, dtype=torch.float32)
+    bg = (ctypes.c_float * 3)(float(background[0]), float(background[1]), float(background[2]))
+    pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
+    with_p2f = need_p2f and rgb_mode == 1
+    grid = standard_grid(IS, dev) if with_p2f else None
+    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode)
+    rc = L.umr_raster_forward(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_acc[0]), ptr(p2f_acc[1]),
+                              ptr(soft_colors), ptr(pooled), N, F, TS, *sc, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
+                              ws_bytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "umr_raster_forward")
+    p2f = p2f_acc[0] / p2f_acc[1].clamp_min(1e-12)  # functional/soft_rasterize.py:73
+    # custom-op outputs may not alias each other: without the fused pool the image IS the saved state, returned once more
+    # as an empty placeholder in the 4th slot
+    return (pooled if pool else soft_colors), p2f, aggrs_info, (soft_colors if pool else soft_colors.new_empty(0))
+
+
+@soft_rasterize_op.register_fake
+def _(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode,
+      pool, need_p2f):
+    N, F = face_vertices.shape[:2]
+    IS = int(image_size)
+    S = IS // 2 if pool else IS
+    f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
+    return f(N, 4, S, S), f(N, F, 2), f(N, 2, IS, IS), (f(N, 4, IS, IS) if pool else f(0))
+
+
+@custom_op("umr::soft_rasterize_backward", mutates_args=(), device_types="cuda")
+def soft_rasterize_backward_op(face_vertices: torch.Tensor, textures: torch.Tensor, soft_colors: torch.Tensor,
+                               aggrs_info: torch.Tensor, grad_image: torch.Tensor, image_size: int, near: float, far: float,
+                               fill_back: bool, eps: float, sigma_val: float, dist_eps: float, gamma_val: float,
+                               rgb_mode: int, pool: bool, need_grad_faces: bool, need_grad_textures: bool
+                               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    L = _lib.lib()
+    fv, tex = _f32c(face_vertices), _f32c(textures)
+    dev = fv.device
+    N, F = fv.shape[:2]
+    TS = tex.shape[2]
+    G = N // tex.shape[0]
+    grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32) if need_grad_faces else None
+    grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32) if need_grad_textures else None   # per view
+    g = grad_image.to(torch.float32).contiguous()
+    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode)
+    rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
+                               ptr(grad_textures), ptr(g), (1 if pool else 0) | (G << 8), 1 if need_grad_faces else 0,
+                               1 if need_grad_textures else 0, N, F, TS, *sc, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "umr_raster_backward")
+    gf = grad_faces.view(N, F, 3, 3) if need_grad_faces else fv.new_empty(0)
+    if need_grad_textures and G > 1:
+        grad_textures = grad_textures.view(N // G, G, F, TS, 3).sum(1)   # autograd of the reference's repeat
+    return gf, (grad_textures if need_grad_textures else fv.new_empty(0))
+
+
+@soft_rasterize_backward_op.register_fake
+def _(face_vertices, textures, soft_colors, aggrs_info, grad_image, image_size, near, far, fill_back, eps, sigma_val,
+      dist_eps, gamma_val, rgb_mode, pool, need_grad_faces, need_grad_textures):
+    f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
+    return (f(*face_vertices.shape) if need_grad_faces else f(0)), (f(*textures.shape) if need_grad_textures else f(0))
+
+
+def _raster_setup(ctx, inputs, output):
+    (fv, tex, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode, pool, need_p2f) = inputs
+    image, p2f, aggrs, saved = output
+    ctx.save_for_backward(fv, tex, (saved if pool else image), aggrs)
+    ctx.cfg = (image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode, pool)
+
+
+def _raster_backward(ctx, g_image, g_p2f, g_aggrs, g_saved):
+    # grad_p2f_info / grad_aggrs_info are ignored, as in the reference (functional/soft_rasterize.py:78): p2f is forward-only
+    fv, tex, soft_colors, aggrs = ctx.saved_tensors
+    need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    if not (need_gf or need_gt):
+        return (None,) * 14
+    gf, gt = torch.ops.umr.soft_rasterize_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg, need_gf, need_gt)
+    return (gf if need_gf else None, gt if need_gt else None) + (None,) * 12
+
+
+soft_rasterize_op.register_autograd(_raster_backward, setup_context=_raster_setup)
+
+
+# ------------------------------------------------------------------------------------------------ silhouette
+@custom_op("umr::silhouette", mutates_args=(), device_types="cuda")
+def silhouette_op(face_vertices: torch.Tensor, image_size: int, near: float, far: float, fill_back: bool, eps: float,
+                  sigma_val: float, dist_eps: float, gamma_val: float, pool: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    L = _lib.lib()
+    fv = _f32c(face_vertices)
+    dev = fv.device
+    N, F = fv.shape[:2]
+    IS = int(image_size)
+    alpha = torch.empty(N, IS, IS, device=dev, dtype=torch.float32)
+    pooled = torch.empty(N, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
+    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, 1)
+    rc = L.umr_raster_forward(ptr(fv), None, None, None, None, None, None, ptr(alpha), ptr(pooled), N, F, 1, *sc, 2 | 1, None,
+                              ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "umr_raster_forward(alpha only)")
+    return (pooled if pool else alpha), (alpha if pool else alpha.new_empty(0))
+
+
+@silhouette_op.register_fake
+def _(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
+    N, IS = face_vertices.shape[0], int(image_size)
+    S = IS // 2 if pool else IS
+    f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
+    return f(N, S, S), (f(N, IS, IS) if pool else f(0))
+
+
+@custom_op("umr::silhouette_backward", mutates_args=(), device_types="cuda")
+def silhouette_backward_op(face_vertices: torch.Tensor, alpha: torch.Tensor, grad_alpha: torch.Tensor, image_size: int,
+                           near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
+                           gamma_val: float, pool: bool) -> torch.Tensor:
+    L = _lib.lib()
+    fv = _f32c(face_vertices)
+    dev = fv.device
+    N, F = fv.shape[:2]
+    grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32)
+    g = grad_alpha.to(torch.float32).contiguous()
+    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, 1)
+    rc = L.umr_raster_backward(ptr(fv), None, ptr(alpha), None, None, ptr(grad_faces), None, ptr(g), 2 | (1 if pool else 0),
+                               1, 0, N, F, 1, *sc, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "umr_raster_backward(alpha only)")
+    return grad_faces.view(N, F, 3, 3)
+
+
+@silhouette_backward_op.register_fake
+def _(face_vertices, alpha, grad_alpha, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
+    return face_vertices.new_empty(face_vertices.shape, dtype=torch.float32)
+
+
+def _sil_setup(ctx, inputs, output):
+    fv = inputs[0]
+    out, saved = output
+    ctx.save_for_backward(fv, saved if inputs[-1] else out)
+    ctx.cfg = tuple(inputs[1:])
+
+
+def _sil_backward(ctx, g_out, g_saved):
+    fv, alpha = ctx.saved_tensors
+    if not ctx.needs_input_grad[0]:
+        return (None,) * 10
+    return (torch.ops.umr.silhouette_backward(fv, alpha, g_out, *ctx.cfg),) + (None,) * 9
+
+
+silhouette_op.register_autograd(_sil_backward, setup_context=_sil_setup)
