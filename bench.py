@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--epoch", type=int, default=0, help="train_s1 epoch (gates the symmetry / deformation terms)")
     ap.add_argument("--profile-steps", type=int, default=5, help="untimed steps with kernel events for `roofline`")
     ap.add_argument("--master-port", type=int, default=29511)
+    ap.add_argument("--graph", type=int, default=0,
+                    help="--model 0 only: capture the hot-path step (every raster / loss kernel, forward and backward) in ONE HIP "
+                         "graph and time graph replays instead of eager launches")
     return ap.parse_args()
 
 
@@ -143,6 +146,28 @@ def main():
                 import torch.distributed as dist
                 dist.all_reduce(outputs["cam"].grad)
             return total
+
+        if args.graph and world == 1:
+            # ~140 launches of a few microseconds each: eager, the step is host-enqueue bound.  Warm up on a side stream,
+            # drop everything the warm-up allocated, capture once, replay.
+            eager_step = step_fn
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            outputs["pred_vs"] = None
+            for l in leaves:
+                l.grad = None
+            torch.cuda.synchronize()
+            hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hip_graph):
+                static_total = eager_step()
+
+            def step_fn():
+                hip_graph.replay()
+                return static_total
 
     def barrier():
         if world > 1:
@@ -253,7 +278,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                         "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
-                        "final_loss": float(loss.detach()), "discarded_nonfinite_runs": discarded}, **rccl),
+                        "final_loss": float(loss.detach()), "discarded_nonfinite_runs": discarded,
+                        "hip_graph": bool(args.graph and not use_model and world == 1)}, **rccl),
         # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
         # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the
         # variant touches, once) / its mean HIP-event duration over the profile pass.

@@ -411,6 +411,13 @@ def test_hot_path_step_replays_from_a_hip_graph():
         for _ in range(3):
             step()
     torch.cuda.current_stream().wait_stream(side)
+    # nothing allocated by the warm-up (side stream) may die INSIDE the capture: the step's non-leaf tensors and the
+    # gradients are dropped first (the same hygiene torch.cuda.make_graphed_callables applies; a block of another stream
+    # freed during capture takes hipStreamEndCapture down on this stack)
+    outputs["pred_vs"] = None
+    for l in leaves:
+        l.grad = None
+    torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         static_total, static_terms = step()

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                        // (a third, vertical step measured slower)
 #endif
 #ifndef FM_VREC
-#define FM_VREC 0         // 1: the face's inverse barycentric matrix and corner coordinates as VGPR operands (FaceV)
+#define FM_VREC 1         // 1: the face's inverse barycentric matrix and corner coordinates as VGPR operands (FaceV)
 #endif
 #ifndef FM_FMA_ACC
 #define FM_FMA_ACC 1      // 1: gradient accumulators updated with explicit fused multiply-adds (the summation order of the
