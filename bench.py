@@ -136,11 +136,14 @@ def main():
                              epoch=args.epoch).to(dev)
         leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
 
+        last_terms = {}
+
         def step_fn():
             for l in leaves:
                 l.grad = None
             outputs["pred_vs"] = outputs["mean_shape"][None] + outputs["delta_v"]
-            total, _ = rc(outputs, batch)
+            total, terms = rc(outputs, batch)
+            last_terms.update(terms)
             total.backward()
             if world > 1:   # hot-path-only mode has no parameters; exchange the (tiny) camera gradient sums
                 import torch.distributed as dist
@@ -148,22 +151,38 @@ def main():
             return total
 
         if args.graph and world == 1:
-            # ~140 launches of a few microseconds each: eager, the step is host-enqueue bound.  Warm up on a side stream,
-            # drop everything the warm-up allocated, capture once, replay.
+            # ~140 launches of a few microseconds each: eager, the step is host-enqueue bound.  Everything -- the first
+            # eager step (module caches, MIOpen solver search, the leaves' AccumulateGrad nodes), the warm-up and the
+            # capture -- runs on ONE side stream, so no node of the captured autograd pass is tied to the default stream;
+            # what the warm-up allocated is dropped before the capture; the graph is then replayed on the timing stream.
             eager_step = step_fn
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                eager_total = float(eager_step())
+                eager_terms = {k: float(v) for k, v in last_terms.items()}
                 for _ in range(3):
                     eager_step()
+                outputs["pred_vs"] = None
+                last_terms.clear()
+                for l in leaves:
+                    l.grad = None
+                torch.cuda.synchronize()
+                hip_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(hip_graph, stream=side):
+                    static_total = eager_step()
             torch.cuda.current_stream().wait_stream(side)
-            outputs["pred_vs"] = None
-            for l in leaves:
-                l.grad = None
             torch.cuda.synchronize()
-            hip_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(hip_graph):
-                static_total = eager_step()
+
+            def check_replay(where):
+                torch.cuda.synchronize()
+                got = float(static_total)
+                if not abs(got - eager_total) <= 1e-4 * abs(eager_total):
+                    raise SystemExit("HIP-graph replay (%s) does not reproduce the eager step: total %r vs %r, terms %r vs %r"
+                                     % (where, got, eager_total, {k: float(v) for k, v in last_terms.items()}, eager_terms))
+
+            hip_graph.replay()
+            check_replay("first replay")
 
             def step_fn():
                 hip_graph.replay()
@@ -202,6 +221,8 @@ def main():
         discarded += 1
         torch.manual_seed(4321 + 17 * discarded + rank)
         step_fn = build_step()
+    if args.graph and not use_model and world == 1:
+        check_replay("after the timed replays")      # back-to-back replays must still compute the eager step's numbers
     # roofline pass: the same steps again, untimed, with the library recording a HIP-event pair around every raster
     # main kernel on its launch stream (event creation / bookkeeping stays out of `value`)
     _lib.profile_enable(True)

@@ -404,23 +404,25 @@ def test_hot_path_step_replays_from_a_hip_graph():
         torch.cuda.synchronize()
         return float(total), {k: float(v) for k, v in terms.items()}, [l.grad.detach().clone() for l in leaves]
 
-    eager = snapshot(*step())
+    # everything up to and including the capture on ONE side stream (first eager step, warm-up, capture): no node of the
+    # captured autograd pass is then tied to the default stream.  Nothing allocated by the warm-up may die INSIDE the
+    # capture: the step's non-leaf tensors and the gradients are dropped first (the hygiene torch.cuda.make_graphed_callables
+    # applies too; a block of another stream freed during capture takes hipStreamEndCapture down on this stack).
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
+        eager = snapshot(*step())
         for _ in range(3):
             step()
+        outputs["pred_vs"] = None
+        for l in leaves:
+            l.grad = None
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            static_total, static_terms = step()
     torch.cuda.current_stream().wait_stream(side)
-    # nothing allocated by the warm-up (side stream) may die INSIDE the capture: the step's non-leaf tensors and the
-    # gradients are dropped first (the same hygiene torch.cuda.make_graphed_callables applies; a block of another stream
-    # freed during capture takes hipStreamEndCapture down on this stack)
-    outputs["pred_vs"] = None
-    for l in leaves:
-        l.grad = None
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        static_total, static_terms = step()
     for l in leaves:
         l.grad.zero_()
     graph.replay()
@@ -440,7 +442,8 @@ def test_hot_path_step_replays_from_a_hip_graph():
         outputs["cam"][:, 0] *= 0.9
         outputs["delta_v"].mul_(0.5)
         batch["masks"].copy_(batch["masks"].roll(1, 0))
-    graph.replay()
+    for _ in range(12):                                   # back-to-back replays, no host sync in between
+        graph.replay()
     replay2 = snapshot(static_total, static_terms)
     eager2 = snapshot(*step())
     same(replay2, eager2)

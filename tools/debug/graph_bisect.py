@@ -4,7 +4,7 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-CASES = ["full_noperc", "full", "full_b4"]
+CASES = ["fullterms_16_256"]
 
 def main_one(case):
     import torch
@@ -33,8 +33,13 @@ def main_one(case):
         from umr_amd.synthetic import make_s1_inputs
         from umr_amd.train_step import RenderCompareS1
         from umr_amd.perceptual import PerceptualTextureLoss
-        tv, fc, outputs, batch = make_s1_inputs(4 if case == "full_b4" else 2, 64, 2, seed=3, device=DEV)
-        rc = RenderCompareS1(tv.to(DEV), fc.to(DEV), 64, texture_loss=PerceptualTextureLoss(DEV) if case == "full" else None).to(DEV)
+        if case.startswith("fullterms"):
+            bb, hh = int(case.split("_")[1]), int(case.split("_")[2])
+        else:
+            bb, hh = (4 if case == "full_b4" else 2), 64
+        tv, fc, outputs, batch = make_s1_inputs(bb, hh, 3 if hh == 256 else 2, seed=3, device=DEV)
+        rc = RenderCompareS1(tv.to(DEV), fc.to(DEV), hh, texture_loss=PerceptualTextureLoss(DEV) if (case == "full" or (case.startswith("fullterms") and "noperc" not in case)) else None).to(DEV)
+        TERMS = {}
         leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
         if case == "full_leafverts":
             outputs["pred_vs"] = (outputs["mean_shape"][None] + outputs["delta_v"]).detach().requires_grad_(True)
@@ -144,10 +149,15 @@ def main_one(case):
                 with torch.no_grad():
                     total, _ = rc(outputs, batch)
                 return total
-            total, _ = rc(outputs, batch); total.backward(); return total
+            total, tt = rc(outputs, batch); total.backward()
+            if case.startswith("fullterms"):
+                TERMS.update(tt)
+            return total
         raise SystemExit("unknown case")
 
     eager = float(step())
+    eager_terms = {k: float(v) for k, v in TERMS.items()} if case.startswith("fullterms") else {}
+    eager_grads = [l.grad.detach().clone() for l in leaves] if case.startswith("fullterms") else []
     side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):
@@ -155,6 +165,7 @@ def main_one(case):
     torch.cuda.current_stream().wait_stream(side)
     if case.startswith("full") and case != "full_leafverts":
         outputs["pred_vs"] = None
+        TERMS.clear()
     for l in leaves:
         l.grad = None
     torch.cuda.synchronize()
@@ -164,6 +175,14 @@ def main_one(case):
         out = step()
     print("captured", case, flush=True)
     g.replay(); torch.cuda.synchronize()
+    if case.startswith("fullterms"):
+        print("terms eager vs replay:", {k: (round(eager_terms[k], 6), round(float(TERMS[k]), 6)) for k in eager_terms}, flush=True)
+        print("grad max rel diff:", [float((a - l.grad).abs().max() / a.abs().max()) for a, l in zip(eager_grads, leaves)], flush=True)
+        for r in range(2, 61):
+            g.replay()
+            if r in (2, 5, 10, 20, 40, 60):
+                torch.cuda.synchronize()
+                print("replay %d terms:" % r, {k: round(float(TERMS[k]), 5) for k in eager_terms}, "total", float(out), flush=True)
     print("RESULT %s ok eager %.6f replay %.6f" % (case, eager, float(out)), flush=True)
 
 if __name__ == "__main__":
@@ -173,5 +192,6 @@ if __name__ == "__main__":
         for c in CASES:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), c], capture_output=True, text=True, timeout=300)
             res = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
+            print("\n".join(l for l in p.stdout.splitlines() if l.startswith(("terms", "grad", "replay"))), flush=True)
             err = [l for l in p.stderr.splitlines() if ("Error" in l or "error" in l) and "amdgpu.ids" not in l][-2:]
             print(res[0] if res else "RESULT %s FAILED rc=%d last=%s err=%s" % (c, p.returncode, p.stdout.strip().splitlines()[-1:] , err), flush=True)

@@ -264,7 +264,7 @@ int umr_project_faces_lit_backward(const float *grad_face_out, const float *grad
     if (mesh_group < 1 || N % mesh_group) return UMR_ERR_ARG;
     if (workspace_bytes < umr_project_workspace_bytes(N, V)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, umr_project_workspace_bytes(N, V), st) != hipSuccess) return UMR_ERR_LAUNCH;
+    if (!umr_zero_async(workspace, umr_project_workspace_bytes(N, V), st)) return UMR_ERR_LAUNCH;
     const int total = N * F;
     k_scatter_face_grads<<<(total + 255) / 256, 256, 0, st>>>(grad_face_out, grad_face_pre, grad_light, face_out, faces_idx,
                                                               (float *)workspace, N, V, F, mesh_group,

@@ -336,7 +336,7 @@ int umr_neg_iou_forward(const float *predict, long predict_stride, const float *
                         float *sums, int N, long P, void *stream) {
     if (!predict || !target || !loss || !sums || N <= 0 || P <= 0 || predict_stride < P) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, (size_t)N * 2 * sizeof(float), st) != hipSuccess) return UMR_ERR_LAUNCH;
+    if (!umr_zero_async(sums, (size_t)N * 2 * sizeof(float), st)) return UMR_ERR_LAUNCH;
     const int per_block = 8192;
     dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)N);
     k_iou_partial<<<grid, 256, 0, st>>>(predict, predict_stride, target, sums, P, per_block);
@@ -377,8 +377,8 @@ int umr_chamfer_backward(const float *a, const float *b, const int *idx1, const 
         (D != 2 && D != 3))
         return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(grad_a, 0, (size_t)B * n * D * sizeof(float), st) != hipSuccess) return UMR_ERR_LAUNCH;
-    if (hipMemsetAsync(grad_b, 0, (size_t)B * m * D * sizeof(float), st) != hipSuccess) return UMR_ERR_LAUNCH;
+    if (!umr_zero_async(grad_a, (size_t)B * n * D * sizeof(float), st)) return UMR_ERR_LAUNCH;
+    if (!umr_zero_async(grad_b, (size_t)B * m * D * sizeof(float), st)) return UMR_ERR_LAUNCH;
     dim3 ga((n + 255) / 256, B), gb((m + 255) / 256, B);
     if (D == 2) {
         k_chamfer_bwd<2><<<ga, 256, 0, st>>>(a, b, idx1, g1, grad_a, grad_b, n, m);
@@ -425,7 +425,7 @@ int umr_laplacian_backward(const float *lap, const int *nbr_off, const int *nbr_
 int umr_flatten_forward(const float *x, const int *quads, float *loss, int B, int V, int E, void *stream) {
     if (!x || !quads || !loss || B <= 0 || V <= 0 || E <= 0) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), st) != hipSuccess) return UMR_ERR_LAUNCH;
+    if (!umr_zero_async(loss, (size_t)B * sizeof(float), st)) return UMR_ERR_LAUNCH;
     dim3 g((E + 255) / 256, B);
     k_flatten<false><<<g, 256, 0, st>>>(x, quads, loss, nullptr, nullptr, V, E);
     return umr_launch_status();

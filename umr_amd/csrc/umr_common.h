@@ -48,3 +48,17 @@ __device__ __forceinline__ float block_sum(float v, float *smem /* >= 16 floats 
     if (wave == 0) r = wave_sum(r);
     return r;
 }
+
+// Zero-fill as a KERNEL, not hipMemsetAsync: memset nodes captured into a HIP graph from these entry points replayed
+// correctly once and then not at all on ROCm 7.0/7.2 (second replay of a captured training step: the IoU sums and the
+// flatten loss kept accumulating) -- kernel nodes replay reliably, and an eager launch costs the same ~2 us.
+static __global__ void umr_k_zero(unsigned *__restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {   // bytes: multiple of 4, p 4-byte aligned
+    const size_t words = bytes / 4;
+    if (!words) return true;
+    const unsigned blocks = (unsigned)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048);
+    umr_k_zero<<<blocks, 256, 0, st>>>((unsigned *)p, words);
+    return hipGetLastError() == hipSuccess;
+}
