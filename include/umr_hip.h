@@ -263,7 +263,7 @@ int umr_visible_face_mask(const float *face_ids, float *mask, int B, long P, int
  *   workspace: umr_cos_sim_workspace_bytes(); forward writes per-pixel statistics there that backward reads.
  * -------------------------------------------------------------------------------------------*/
 #define UMR_COS_MAX_TAPS 8
-#define UMR_COS_CHUNKS 16
+#define UMR_COS_CHUNKS 1024   /* 64-pixel chunks per feature map: maps of up to 65536 pixels (256 x 256) */
 size_t umr_cos_sim_workspace_bytes(int ntaps, int N, const int *P);
 int umr_cos_sim_forward(int ntaps, const float *const *f0, const float *const *f1, const int *C, const int *P, int N,
                         float eps, float *val, void *workspace, size_t workspace_bytes, void *stream);

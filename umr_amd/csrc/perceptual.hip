@@ -14,41 +14,52 @@ constexpr int COS_MAX_TAPS = UMR_COS_MAX_TAPS;
 struct CosTapDev { const float *f0, *f1; float *g0, *g1; float *stats; int C, P; };
 struct CosArgs { CosTapDev tap[COS_MAX_TAPS]; int ntaps, N, chunks; float eps; };
 
-// One thread per pixel p of sample n, tap t: the channel loop reads f[n, c, p] -- consecutive lanes consecutive p,
-// i.e. coalesced 256-byte rows per channel.  Per pixel: s00 = sum f0^2, s11 = sum f1^2, s01 = sum f0 f1;
-// cos = s01 / ((sqrt(s00) + eps) (sqrt(s11) + eps)).  stats[n, p] = (sqrt(s00), sqrt(s11), s01) for the backward.
+// Forward: a 256-thread block owns 64 consecutive pixels of sample n, tap t; lane = pixel (the channel loop reads
+// f[n, c, p]: consecutive lanes consecutive p = coalesced 256-byte rows), wave w = channels w, w+4, w+8, ... so that the
+// small late taps (15 x 15 pixels, 256-384 channels) still spread over 4 x 4 x N x 5 waves.  Per pixel:
+// s00 = sum f0^2, s11 = sum f1^2, s01 = sum f0 f1 (partial sums of the 4 waves combined through LDS in a fixed order);
+// cos = s01 / ((sqrt(s00) + eps)(sqrt(s11) + eps)).  stats[n, p] = (sqrt(s00), sqrt(s11), s01) for the backward.
 __global__ __launch_bounds__(256) void k_cos_forward(const CosArgs A, float *__restrict__ partial) {
-    __shared__ float smem[16];
+    __shared__ float s_part[4][3][64];
     const int t = blockIdx.z, n = blockIdx.y;
     const CosTapDev T = A.tap[t];
     const int C = T.C, P = T.P;
-    const float *a = T.f0 + (size_t)n * C * P, *b = T.f1 + (size_t)n * C * P;
-    float acc = 0.f;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        float s00 = 0.f, s11 = 0.f, s01 = 0.f;
-        int c = 0;
-        for (; c + 4 <= C; c += 4) {       // four independent loads in flight per stream
-            const float x0 = a[(size_t)c * P + p], x1 = a[(size_t)(c + 1) * P + p], x2 = a[(size_t)(c + 2) * P + p],
-                        x3 = a[(size_t)(c + 3) * P + p];
-            const float y0 = b[(size_t)c * P + p], y1 = b[(size_t)(c + 1) * P + p], y2 = b[(size_t)(c + 2) * P + p],
-                        y3 = b[(size_t)(c + 3) * P + p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    float s00 = 0.f, s11 = 0.f, s01 = 0.f;
+    if (p < P) {
+        const float *a = T.f0 + (size_t)n * C * P + p, *b = T.f1 + (size_t)n * C * P + p;
+        int c = wave;
+        for (; c + 12 < C; c += 16) {       // four independent loads in flight per stream
+            const float x0 = a[(size_t)c * P], x1 = a[(size_t)(c + 4) * P], x2 = a[(size_t)(c + 8) * P], x3 = a[(size_t)(c + 12) * P];
+            const float y0 = b[(size_t)c * P], y1 = b[(size_t)(c + 4) * P], y2 = b[(size_t)(c + 8) * P], y3 = b[(size_t)(c + 12) * P];
             s00 = fmaf(x0, x0, s00); s00 = fmaf(x1, x1, s00); s00 = fmaf(x2, x2, s00); s00 = fmaf(x3, x3, s00);
             s11 = fmaf(y0, y0, s11); s11 = fmaf(y1, y1, s11); s11 = fmaf(y2, y2, s11); s11 = fmaf(y3, y3, s11);
             s01 = fmaf(x0, y0, s01); s01 = fmaf(x1, y1, s01); s01 = fmaf(x2, y2, s01); s01 = fmaf(x3, y3, s01);
         }
-        for (; c < C; ++c) {
-            const float x = a[(size_t)c * P + p], y = b[(size_t)c * P + p];
+        for (; c < C; c += 4) {
+            const float x = a[(size_t)c * P], y = b[(size_t)c * P];
             s00 = fmaf(x, x, s00); s11 = fmaf(y, y, s11); s01 = fmaf(x, y, s01);
         }
-        const float r0 = sqrtf(s00), r1 = sqrtf(s11);
-        acc += s01 / ((r0 + A.eps) * (r1 + A.eps));
-        if (T.stats) {
-            float *st = T.stats + ((size_t)n * P + p) * 3;
-            st[0] = r0; st[1] = r1; st[2] = s01;
-        }
     }
-    const float s = block_sum(acc, smem);
-    if (threadIdx.x == 0) partial[((size_t)t * A.N + n) * A.chunks + blockIdx.x] = s;
+    s_part[wave][0][lane] = s00; s_part[wave][1][lane] = s11; s_part[wave][2][lane] = s01;
+    __syncthreads();
+    if (wave == 0) {
+        float cosv = 0.f;
+        if (p < P) {
+            s00 = ((s_part[0][0][lane] + s_part[1][0][lane]) + s_part[2][0][lane]) + s_part[3][0][lane];
+            s11 = ((s_part[0][1][lane] + s_part[1][1][lane]) + s_part[2][1][lane]) + s_part[3][1][lane];
+            s01 = ((s_part[0][2][lane] + s_part[1][2][lane]) + s_part[2][2][lane]) + s_part[3][2][lane];
+            const float r0 = sqrtf(s00), r1 = sqrtf(s11);
+            cosv = s01 / ((r0 + A.eps) * (r1 + A.eps));
+            if (T.stats) {
+                float *st = T.stats + ((size_t)n * P + p) * 3;
+                st[0] = r0; st[1] = r1; st[2] = s01;
+            }
+        }
+        const float s = wave_sum(cosv);
+        if (lane == 0) partial[((size_t)t * A.N + n) * A.chunks + blockIdx.x] = s;
+    }
 }
 
 // val[n] = sum_t (1 - (sum over chunks) / P_t): fixed summation order -> deterministic
@@ -58,7 +69,8 @@ __global__ void k_cos_finalize(const CosArgs A, const float *__restrict__ partia
     float v = 0.f;
     for (int t = 0; t < A.ntaps; ++t) {
         float s = 0.f;
-        for (int k = 0; k < A.chunks; ++k) s += partial[((size_t)t * A.N + n) * A.chunks + k];
+        const int used = (A.tap[t].P + 63) / 64;
+        for (int k = 0; k < used; ++k) s += partial[((size_t)t * A.N + n) * A.chunks + k];
         v += 1.f - s / (float)A.tap[t].P;
     }
     val[n] = v;
@@ -67,23 +79,27 @@ __global__ void k_cos_finalize(const CosArgs A, const float *__restrict__ partia
 // d val[n] / d f1[c] at pixel p = -(1/P) [ f0[c] i0 i1 - s01 i0 i1^2 f1[c] / r1 ],  i = 1 / (r + eps)  (and symmetrically
 // for f0).  A zero feature vector (r = 0) gets the derivative of its norm defined as 0: torch's sqrt backward gives
 // 0 * inf = NaN there -- a defined deviation, listed in oracle/README.md.
+// Pure element-wise map over [C, P] with three per-pixel coefficients: one thread per (channel group, pixel), lane = pixel.
 __global__ __launch_bounds__(256) void k_cos_backward(const CosArgs A, const float *__restrict__ gval) {
     const int t = blockIdx.z, n = blockIdx.y;
     const CosTapDev T = A.tap[t];
     const int C = T.C, P = T.P;
-    const float *a = T.f0 + (size_t)n * C * P, *b = T.f1 + (size_t)n * C * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    if (p >= P) return;
     const float g = -gval[n] / (float)P;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const float *st = T.stats + ((size_t)n * P + p) * 3;
-        const float r0 = st[0], r1 = st[1], s01 = st[2];
-        const float i0 = 1.f / (r0 + A.eps), i1 = 1.f / (r1 + A.eps);
-        const float k = g * i0 * i1;
-        const float m0 = r0 > 0.f ? s01 * i0 / r0 : 0.f, m1 = r1 > 0.f ? s01 * i1 / r1 : 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float x = a[(size_t)c * P + p], y = b[(size_t)c * P + p];
-            if (T.g0) T.g0[((size_t)n * C + c) * P + p] = k * (y - m0 * x);
-            if (T.g1) T.g1[((size_t)n * C + c) * P + p] = k * (x - m1 * y);
-        }
+    const float *st = T.stats + ((size_t)n * P + p) * 3;
+    const float r0 = st[0], r1 = st[1], s01 = st[2];
+    const float i0 = 1.f / (r0 + A.eps), i1 = 1.f / (r1 + A.eps);
+    const float k = g * i0 * i1;
+    const float m0 = r0 > 0.f ? s01 * i0 / r0 : 0.f, m1 = r1 > 0.f ? s01 * i1 / r1 : 0.f;
+    const size_t base = (size_t)n * C * P + p;
+    const float *a = T.f0 + base, *b = T.f1 + base;
+    float *g0 = T.g0 ? T.g0 + base : nullptr, *g1 = T.g1 ? T.g1 + base : nullptr;
+    for (int c = wave; c < C; c += 4) {
+        const float x = a[(size_t)c * P], y = b[(size_t)c * P];
+        if (g0) g0[(size_t)c * P] = k * (y - m0 * x);
+        if (g1) g1[(size_t)c * P] = k * (x - m1 * y);
     }
 }
 
@@ -364,7 +380,10 @@ int umr_cos_sim_forward(int ntaps, const float *const *f0, const float *const *f
         ws += (size_t)N * P[t] * 3;
     }
     hipStream_t st = (hipStream_t)stream;
-    k_cos_forward<<<dim3(UMR_COS_CHUNKS, N, ntaps), 256, 0, st>>>(A, partial);
+    int maxp = 0;
+    for (int t = 0; t < ntaps; ++t) maxp = P[t] > maxp ? P[t] : maxp;
+    if ((maxp + 63) / 64 > UMR_COS_CHUNKS) return UMR_ERR_ARG;     // feature maps of up to 64 * UMR_COS_CHUNKS pixels
+    k_cos_forward<<<dim3((maxp + 63) / 64, N, ntaps), 256, 0, st>>>(A, partial);
     k_cos_finalize<<<(N + 63) / 64, 64, 0, st>>>(A, partial, val);
     return umr_launch_status();
 }
@@ -383,7 +402,10 @@ int umr_cos_sim_backward(int ntaps, const float *const *f0, const float *const *
         A.tap[t].g0 = g0 ? g0[t] : nullptr; A.tap[t].g1 = g1 ? g1[t] : nullptr;
         ws += (size_t)N * P[t] * 3;
     }
-    k_cos_backward<<<dim3(UMR_COS_CHUNKS, N, ntaps), 256, 0, (hipStream_t)stream>>>(A, grad_val);
+    int maxp = 0;
+    for (int t = 0; t < ntaps; ++t) maxp = P[t] > maxp ? P[t] : maxp;
+    if ((maxp + 63) / 64 > UMR_COS_CHUNKS) return UMR_ERR_ARG;
+    k_cos_backward<<<dim3((maxp + 63) / 64, N, ntaps), 256, 0, (hipStream_t)stream>>>(A, grad_val);
     return umr_launch_status();
 }
 
