@@ -448,3 +448,26 @@ def test_hot_path_step_replays_from_a_hip_graph():
     eager2 = snapshot(*step())
     same(replay2, eager2)
     assert abs(eager2[0] - eager[0]) > 1e-3            # the inputs really changed
+
+
+def test_superblock_bins_do_not_change_results():
+    """Per-mesh coarse binning (k_superblock_bin) only narrows the candidate list a workgroup scans: forward outputs are
+    bit-identical with the bins off (every workgroup scanning all F faces), for power-of-two, ragged and tiny images."""
+    from umr_amd import _lib, functional as UF
+    for (n, sub, IS, ts, rgb) in ((2, 3, 512, 4, "softmax"), (2, 2, 200, 1, "hard"), (1, 1, 24, 1, "softmax"), (3, 2, 136, 9, "softmax")):
+        verts, faces, cams, gen = scene(n, sub, seed=IS)
+        _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+        tex = torch.rand(n, faces.shape[1], ts, 3, generator=gen).to(DEV)
+        outs = []
+        for on in (1, 0):
+            _lib.debug_set("superblock_bins", on)
+            try:
+                sc, p2f, aggr = UF.soft_rasterize(fv, tex, IS, [0.1, 0.2, 0.3], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, rgb)
+                a = UF.SilhouetteFunction.apply(fv, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, IS % 2 == 0)
+                vis = UF.visibility(fv, IS)
+                outs.append((sc.clone(), aggr.clone(), a.clone(), vis.clone(), p2f.clone()))
+            finally:
+                _lib.debug_set("superblock_bins", 1)
+        for x, y in list(zip(outs[0], outs[1]))[:4]:
+            assert torch.equal(x, y)
+        assert float((outs[0][4] - outs[1][4]).abs().max()) <= 1e-5      # p2f: float atomics, order not fixed

@@ -21,6 +21,9 @@ def timed(fn, *a, ids=(0, 1), **k):
 
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "default"
+if os.environ.get("UMR_SB") == "0":
+    _lib.debug_set("superblock_bins", 0)
+    tag += " [no super-block bins]"
 out = {"tag": tag}
 out["n16_ts36_texonly_pooled"] = timed(bench, 16, 3, 512, 36, pool=True, need_p2f=False, need_gf=False, iters=20)
 out["n16_ts36_p2f"] = timed(bench, 16, 3, 512, 36, iters=20)

@@ -1,10 +1,6 @@
 #!/usr/bin/env bash
-# GPU box: A/B of compile-time variants of the raster kernels (round 2).  Output: gpurun_out/r2e/sweep.log
+# GPU box: A/B of the per-mesh super-block bins (round 2).  Output: gpurun_out/r2i/sweep.log
 set -uo pipefail
-R="$(cd "$(dirname "$0")/.." && pwd)"; cd "$R"; O=gpurun_out/r2e; mkdir -p $O
-for v in "-DFM_VREC=0" "-DFM_VREC=1"; do
-  python -c "import sys; from umr_amd.build import build; build(force=True, verbose=False, extra_flags=sys.argv[1].split())" "$v" || continue
-  timeout 200 python tools/sweep_fm.py "$v" 2>/dev/null | tail -1
-done > $O/sweep.log 2>&1
-python -c "from umr_amd.build import build; build(force=True, verbose=False)"
+R="$(cd "$(dirname "$0")/.." && pwd)"; cd "$R"; O=gpurun_out/r2i; mkdir -p $O
+(UMR_SB=1 timeout 200 python tools/sweep_fm.py "bins" 2>/dev/null | tail -1; UMR_SB=0 timeout 200 python tools/sweep_fm.py "nobins" 2>/dev/null | tail -1) > $O/sweep.log 2>&1
 cat $O/sweep.log

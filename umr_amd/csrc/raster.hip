@@ -32,6 +32,27 @@
 namespace {
 
 size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 255) & ~(size_t)255; }
+size_t ws_rec_bytes(int N, int F) { return (size_t)N * F * REC * sizeof(float); }
+size_t ws_sbcount_bytes(int N) { return (((size_t)N * SB_SLOTS * sizeof(int)) + 255) & ~(size_t)255; }
+size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * F * sizeof(int); }
+bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
+
+// super-block edge: an eighth of the image, rounded up to whole 16-pixel workgroup blocks (<= 8 x 8 super-blocks)
+void superblock_geometry(int IS, int *size, int *nx) {
+    *size = (((IS + 7) / 8) + 15) & ~15;
+    *nx = (IS + *size - 1) / *size;
+}
+
+// workspace pointers + the per-mesh coarse binning pass (after k_face_setup on the same stream)
+void setup_bins(RasterArgs &A, void *workspace, int N, int F, int IS, hipStream_t st) {
+    A.sb_count = nullptr; A.sb_list = nullptr;
+    if (!g_superblocks) return;
+    char *p = (char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F);
+    int *cnt = (int *)p, *lst = (int *)(p + ws_sbcount_bytes(N));
+    superblock_geometry(IS, &A.sb_size, &A.sb_nx);
+    k_superblock_bin<<<dim3(SB_SLOTS, N), 256, 0, st>>>(A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx);
+    A.sb_count = cnt; A.sb_list = lst;
+}
 
 // ---- optional per-kernel timing with library-owned HIP events (umr_profile_*) -------------------
 struct ProfRec { hipEvent_t e0, e1; double bytes; int which; };
@@ -68,6 +89,7 @@ const char *umr_build_id(void) { return UMR_SRC_HASH; }
 int umr_debug_set(const char *key, int value) {
     if (!key) return UMR_ERR_ARG;
     if (std::string(key) == "bwd_pixel_major") { g_bwd_pixel_major = value != 0; return UMR_OK; }
+    if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
     return UMR_ERR_ARG;
 }
 
@@ -96,7 +118,7 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
 
 size_t umr_raster_workspace_bytes(int N, int F) {
     if (N <= 0 || F <= 0) return 0;
-    return ws_bbox_bytes(N, F) + (size_t)N * F * REC * sizeof(float);
+    return ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F);
 }
 
 int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
@@ -140,6 +162,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     const int total = N * F;
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold), near_, far_);
+    setup_bins(A, workspace, N, F, image_size, st);
     const int blocks = N * A.tiles_x * A.tiles_y;
     {
         // algorithmic bytes of one forward launch: 24 IS^2 + F (36 + 12 TS + 16) per mesh
@@ -221,6 +244,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
         if (alpha_only) launch_backward_fm<2>(A, st);
         else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
+            setup_bins(A, workspace, N, F, image_size, st);
             if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
             else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
         } else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);

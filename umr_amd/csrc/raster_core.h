@@ -10,6 +10,7 @@
 #define BLK_W 16   // measured on MI355X (N=128, F=1280, IS=512, soft-max forward): 16x16 1.55 ms, 32x8 / 16x8 1.64,
 #define BLK_H 16   // 32x16 1.81, 32x32 2.08, 8x8 2.28 -- 4 waves share one binning pass and still schedule finely
 #endif
+#define SB_SLOTS 64   // super-block slots per mesh (8 x 8)
 #define BLK_WX (BLK_W / 8)                          // 8x8 wave tiles across / in the workgroup
 #define BLK_THREADS (BLK_WX * (BLK_H / 8) * 64)
 
@@ -46,6 +47,12 @@ struct RasterArgs {
     float inv_gamma;
     int double_side, with_p2f, grad_pooled, need_gf, need_gt;
     int tiles_x, tiles_y;
+    // per-mesh coarse bins written by k_superblock_bin: the image is cut into <= 8 x 8 super-blocks of sb_size^2 pixels
+    // (sb_size a multiple of the 16-pixel workgroup block); sb_list[(n * SB_SLOTS + sb) * F ...] holds, ascending, the
+    // faces whose dilated bbox touches super-block sb, sb_count their number.  NULL = scan all F faces per workgroup.
+    const int *sb_count;
+    const int *sb_list;
+    int sb_size, sb_nx;
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
@@ -341,6 +348,7 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 
 struct Tile {
     int n, lane, wave, xi, row;
+    int bx0, by0;                  // pixel origin of the workgroup's block
     bool valid, wave_on;
     float xp, yp;
     float bxlo, bxhi, bylo, byhi;  // block bounds (pixel centres)
@@ -355,6 +363,7 @@ __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     t.n = wid / A.tiles_y;
     t.lane = threadIdx.x & 63;
     t.wave = threadIdx.x >> 6;
+    t.bx0 = bx * BLK_W; t.by0 = by * BLK_H;
     const int IS = A.IS;
     const int px0 = bx * BLK_W + (t.wave % BLK_WX) * 8, py0 = by * BLK_H + (t.wave / BLK_WX) * 8;
     t.xi = px0 + (t.lane & 7);
@@ -377,14 +386,17 @@ __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     t.wylo = ndc_coord_fast(IS - 1 - min(py0 + 7, IS - 1), IS, inv_is, pow2);
 }
 
-// Block-level binning of faces [f0, f1) into the LDS list, ascending order.  Returns the count.
-__device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4 *__restrict__ bbox_n, int f0,
-                                          int f1, const Tile &t) {
+// Block-level binning into the LDS list, ascending order; returns the count.  Candidates are entries [i0, i1) of `ids`
+// (the super-block's pre-binned face list, ascending) or, with ids == NULL, the faces i0 .. i1-1 themselves.
+__device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4 *__restrict__ bbox_n,
+                                          const int *__restrict__ ids, int i0, int i1, const Tile &t) {
     int count = 0;
-    for (int c = f0; c < f1; c += BLK_THREADS) {
-        const int f = c + (int)threadIdx.x;
+    for (int c = i0; c < i1; c += BLK_THREADS) {
+        const int i = c + (int)threadIdx.x;
         bool pass = false;
-        if (f < f1) {
+        int f = i;
+        if (i < i1) {
+            if (ids) f = ids[i];
             const float4 bb = bbox_n[f];
             // same predicate as the per-pixel reject, applied to the block's extreme pixel centres
             pass = !(t.bxlo > bb.y || t.bxhi < bb.x || t.bylo > bb.w || t.byhi < bb.z);
@@ -404,6 +416,57 @@ __device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4
         __syncthreads();
     }
     return count;
+}
+
+// Super-block of the workgroup's 16x16 block and that super-block's candidate list.
+__device__ __forceinline__ int superblock_list(const RasterArgs &A, const Tile &t, const int *&ids) {
+    if (!A.sb_list) { ids = nullptr; return A.F; }
+    const int sb = (t.by0 / A.sb_size) * A.sb_nx + (t.bx0 / A.sb_size);
+    ids = A.sb_list + ((size_t)t.n * SB_SLOTS + sb) * A.F;
+    return A.sb_count[t.n * SB_SLOTS + sb];
+}
+
+// Coarse binning, once per mesh instead of once per 16x16 workgroup: block (sb, n) scans the mesh's F dilated bounding
+// boxes (coalesced float4) against the pixel-centre bounds of super-block sb and writes the survivors, ascending
+// (ballot + prefix compaction), to sb_list.  The predicate is the workgroup's own (build_list) on a rectangle that
+// contains every workgroup block of the super-block, so no face a workgroup needs is ever missing (NaN boxes pass both).
+__global__ __launch_bounds__(256) void k_superblock_bin(const float4 *__restrict__ bbox, int *__restrict__ sb_count,
+                                                        int *__restrict__ sb_list, int F, int IS, int sb_size, int sb_nx) {
+    __shared__ int s_w[4];
+    const int sb = blockIdx.x, n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sbx = sb % sb_nx, sby = sb / sb_nx;
+    int *out = sb_list + ((size_t)n * SB_SLOTS + sb) * F;
+    if (sby >= sb_nx) { if (threadIdx.x == 0) sb_count[n * SB_SLOTS + sb] = 0; return; }
+    const bool pow2 = (IS & (IS - 1)) == 0;
+    const float inv_is = 1.f / (float)IS;
+    const int px0 = sbx * sb_size, px1 = min(px0 + sb_size - 1, IS - 1), pr0 = sby * sb_size, pr1 = min(pr0 + sb_size - 1, IS - 1);
+    const float xlo = ndc_coord_fast(px0, IS, inv_is, pow2), xhi = ndc_coord_fast(px1, IS, inv_is, pow2);
+    const float yhi = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), ylo = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
+    const float4 *bbox_n = bbox + (size_t)n * F;
+    int count = 0;
+    for (int c = 0; c < F; c += 256) {
+        const int f = c + (int)threadIdx.x;
+        bool pass = false;
+        if (f < F) {
+            const float4 bb = bbox_n[f];
+            pass = !(xlo > bb.y || xhi < bb.x || ylo > bb.w || yhi < bb.z);
+        }
+        const unsigned long long m = __ballot(pass);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int base = count, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int cw = s_w[w];
+            if (w < wave) base += cw;
+            tot += cw;
+        }
+        if (pass) out[base + __popcll(m & ((1ull << lane) - 1ull))] = f;
+        count += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sb_count[n * SB_SLOTS + sb] = count;
 }
 
 }  // namespace

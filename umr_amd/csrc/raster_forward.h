@@ -41,10 +41,12 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
         }
     }
 
-    for (int f0 = 0; f0 < F; f0 += LIST_CAP) {
-        const int f1 = min(F, f0 + LIST_CAP);
+    const int *sb_ids;
+    const int ncand = superblock_list(A, t, sb_ids);      // the super-block's pre-binned faces (or all F)
+    for (int f0 = 0; f0 < ncand; f0 += LIST_CAP) {
+        const int f1 = min(ncand, f0 + LIST_CAP);
         if (f0 > 0) __syncthreads();
-        const int count = build_list(s_list, s_wcnt, bbox_n, f0, f1, t);
+        const int count = build_list(s_list, s_wcnt, bbox_n, sb_ids, f0, f1, t);
         if (!t.wave_on) continue;
         for (int base = 0; base < count; base += 64) {
             const int li = base + t.lane;
