@@ -234,13 +234,23 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
                                                       sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
     {
-        // algorithmic bytes of one backward launch: per mesh (40 | 28 when the gradient
-        // arrives 2x2-pooled: 4 instead of 16 B/pixel) IS^2 + F (180 + 24 TS)
-        const double px = grad_is_pooled ? 28.0 : 40.0;
-        // (silhouette-only launches, id 3: alpha + its gradient per pixel, faces + grad_faces per face)
-        ProfScope ps(st, alpha_only ? 3 : 1,
-                     alpha_only ? (double)N * ((grad_is_pooled ? 5.0 : 8.0) * image_size * image_size + 72.0 * F)
-                                : (double)N * (px * image_size * image_size + (double)F * (180.0 + 24.0 * TS)));
+        // Algorithmic bytes of one backward launch, per VARIANT, by SURVEY.md 8d's rule (every op-boundary buffer the variant
+        // touches, once; fp32): per pixel -- the gradient planes it reads (4 B per plane per COARSE pixel when the gradient
+        // arrives 2x2-pooled, i.e. 1 B per plane per raster pixel), soft_colors only where the colour / alpha terms need it,
+        // aggrs_info (8); per face -- faces (36) + faces_info (108) read, textures read only for vertex gradients of a
+        // soft-max render, grad_faces (36) / grad_textures (12 TS) written only when requested.
+        //   full (vertex + texel grads): (40 | 28) IS^2 + F (180 + 24 TS)          = SURVEY 8d's formula
+        //   vertex grads only:           (40 | 28) IS^2 + F (180 + 12 TS)
+        //   texel grads only:            (20 | 11) IS^2 + F (144 + 12 TS)          (3 colour-gradient planes + aggrs)
+        //   silhouette (id 3):           ( 8 |  5) IS^2 + 72 F
+        const double is2 = (double)image_size * image_size;
+        const bool gp = grad_is_pooled != 0;
+        double per_mesh;
+        if (alpha_only) per_mesh = (gp ? 5.0 : 8.0) * is2 + 72.0 * F;
+        else if (need_grad_faces && need_grad_textures) per_mesh = (gp ? 28.0 : 40.0) * is2 + (double)F * (180.0 + 24.0 * TS);
+        else if (need_grad_faces) per_mesh = (gp ? 28.0 : 40.0) * is2 + (double)F * (180.0 + 12.0 * TS);
+        else per_mesh = (gp ? 11.0 : 20.0) * is2 + (double)F * (144.0 + 12.0 * TS);
+        ProfScope ps(st, alpha_only ? 3 : 1, (double)N * per_mesh);
         const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
         if (alpha_only) launch_backward_fm<2>(A, st);
         else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
