@@ -21,3 +21,28 @@ def test_cpu_baseline_leg_small(oracle_built):
     assert r["unit"] == "images/s" and r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0
     assert "sample" in r and "train_s1" in r["sample"]
     assert b.METRIC.startswith("train images/sec") and b.HBM_PEAK_GBS == 8000.0
+
+
+def test_self_launch_builds_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun re-launches itself under torch.distributed.run: N ranks on this node,
+    rendezvous on 127.0.0.1, the original arguments passed through, dmabuf IPC mode set for RCCL."""
+    import subprocess
+    import sys
+    import pytest
+    b = _load_bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    args = argparse.Namespace(gpus=4, master_port=29511)
+    with pytest.raises(SystemExit) as e:
+        b.self_launch(args)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -19,6 +19,10 @@ def cp(src, dst):
 cp("bench_full.json", tag + "_bench_full.json")
 cp("bench_hotpath_only.json", tag + "_bench_hotpath_only.json")
 cp("bench_s2.json", tag + "_bench_s2.json")
+if os.path.exists(os.path.join(SRC, "bench_hotpath_graph.json")):
+    cp("bench_hotpath_graph.json", tag + "_bench_hotpath_graph.json")
+if os.path.exists(os.path.join(SRC, "valu_ubench.log")):
+    cp("valu_ubench.log", tag + "_valu_ubench.log")
 cp("stats/t_kernel_stats.csv", tag + "_bench_kernel_stats.csv")
 cp("traffic/traffic.json", tag + "_traffic.json")
 cp("traffic/traffic.json", "traffic.json")
@@ -44,7 +48,7 @@ ours = [r for r in rows if "(anonymous namespace)::k_" in r["Name"]]
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")[:92]
 tr = json.load(open(os.path.join(SRC, "traffic", "traffic.json")))
 L = []
-L.append("# Round 1 profile summary (1x MI355X)\n")
+L.append("# Round %s profile summary (1x MI355X)\n" % tag.lstrip("r0"))
 L.append("All files in this directory are produced on the GPU box by `tools/refresh_profiles.sh` and copied here by "
          "`tools/make_summary.py`.\n")
 L.append("Command behind the kernel table: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
@@ -72,6 +76,16 @@ L.append("Full step (`profiles/%s_bench_full.json`): **%.0f images/s**, %.2f ms/
          % (tag, full["value"], full["ms_per_step"], rf["avg_us"], rf["achieved"], 100 * rf["frac"],
             (rf["traffic"] or 0) / 1e6, rf["alg_bytes_per_launch"] / 1e6, full["cpu_baseline"]["value"], full["cpu_baseline"]["cores"]))
 L.append("Hot path only, `--model 0` (`profiles/%s_bench_hotpath_only.json`): **%.0f images/s**, %.2f ms/step.\n" % (tag, hot["value"], hot["ms_per_step"]))
+gpath = os.path.join(SRC, "bench_hotpath_graph.json")
+if os.path.exists(gpath):
+    hg = json.load(open(gpath))
+    L.append("Hot path replayed from one HIP graph, `--model 0 --graph 1` (`profiles/%s_bench_hotpath_graph.json`): **%.0f images/s**, "
+             "%.2f ms/step (host enqueue %.3f ms/step).\n" % (tag, hg["value"], hg["ms_per_step"], hg["config"]["host_enqueue_ms_per_step"]))
+for name, key in (("textured forward", "forward_kernel"), ("silhouette forward", "silhouette_forward"), ("silhouette backward", "silhouette_backward")):
+    k = rf.get(key)
+    if k and k.get("avg_us"):
+        L.append("%s: avg %.1f us/launch, %.0f GB/s algorithmic = %.1f %% of 8 TB/s (%.1f MB/launch).\n"
+                 % (name, k["avg_us"], k["achieved"], 100 * k["frac"], k["alg_bytes_per_launch"] / 1e6))
 L.append("train_s2 sequence, `--workload s2` (`profiles/%s_bench_s2.json`, 10 steps): %.0f images/s, %.1f ms/step.\n" % (tag, s2["value"], s2["ms_per_step"]))
 bk = [r for r in ours if "k_raster_backward_fm<1, false, true" in r["Name"]]
 tsum = os.path.join(SRC, "raster_trace_summary.json")

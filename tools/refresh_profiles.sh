@@ -8,9 +8,11 @@ cd "$R"
 python bench.py --steps 10 --warmup 5 --cpu-baseline 0 > /dev/null 2>&1        # MIOpen first-use search, page-in
 python bench.py > "$O/bench_full.json" 2> "$O/bench_full.err"
 python bench.py --model 0 --cpu-baseline 0 > "$O/bench_hotpath_only.json" 2> "$O/bench_hot.err"
+python bench.py --model 0 --cpu-baseline 0 --graph 1 > "$O/bench_hotpath_graph.json" 2> "$O/bench_hot_graph.err"
 python bench.py --workload s2 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o t -- python "$R/bench.py" --steps 10 --warmup 5 --cpu-baseline 0 > "$O/stats.log" 2>&1)
 tools/collect_traffic.sh "$O/traffic" > "$O/traffic.log" 2>&1
+(hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_ubench.hip -o /tmp/valu_ubench && timeout 150 /tmp/valu_ubench) > "$O/valu_ubench.log" 2>&1
 python tools/microbench.py > "$O/microbench.log" 2>&1
 python tools/microbench.py --alpha >> "$O/microbench.log" 2>&1
 python tools/sweep_fm.py kernel_only > "$O/kernel_only.log" 2>&1
