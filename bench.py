@@ -159,6 +159,13 @@ def main():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                # fresh leaves created ON the side stream: a leaf's AccumulateGrad node is tied to the stream it was first
+                # used on, and make_s1_inputs already used delta_v on the default stream -- the engine would then hop to
+                # the default stream inside the capture (fork / join through events) for that leaf's accumulation
+                outputs["pred_vs"] = None
+                for k in ("delta_v", "cam", "tex_flow"):
+                    outputs[k] = outputs[k].detach().clone().requires_grad_(True)
+                leaves[:] = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
                 eager_total = float(eager_step())
                 eager_terms = {k: float(v) for k, v in last_terms.items()}
                 for _ in range(3):
@@ -169,7 +176,8 @@ def main():
                     l.grad = None
                 torch.cuda.synchronize()
                 hip_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(hip_graph, stream=side):
+                # single-threaded autograd: forward and backward launches of the captured step come from one host thread
+                with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(hip_graph, stream=side):
                     static_total = eager_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
@@ -212,6 +220,11 @@ def main():
     discarded = 0
     while True:
         loss, host_dt, dt = measure()
+        if not use_model:
+            # nothing trains in hot-path-only mode: no trajectory to diverge.  (Also: in --graph mode the tensors the
+            # graph owns are only ever read back with .item() -- an eager torch op on `loss` here, torch.isfinite, was
+            # reproducibly followed by replays whose last reduction returned a stale value; check_replay guards that.)
+            break
         ok = torch.isfinite(loss.detach()).reshape(1).to(torch.float32)
         if world > 1:
             import torch.distributed as dist
@@ -233,6 +246,8 @@ def main():
     barrier()
     _lib.profile_enable(False)
     prof = {k: _lib.profile_collect(k) for k in range(4)}   # 0 fwd, 1 bwd, 2 silhouette/id fwd, 3 silhouette bwd
+    if args.graph and not use_model and world == 1:
+        check_replay("after the profile pass")
     b_ms, b_n, b_bytes = prof[1]
     f_ms, f_n, f_bytes = prof[0]
 

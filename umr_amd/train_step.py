@@ -53,7 +53,7 @@ def gan_labels(module, B, device):
 
 
 def weighted_total(module, terms, weights):
-    """sum_k weights[k] * terms[k] as ONE stack + ONE dot product (and their two backward kernels) instead of a
+    """sum_k weights[k] * terms[k] as ONE stack, ONE multiply and ONE sum (and their backward kernels) instead of a
     multiply and an add per term in each direction: the step's wall time equals its host enqueue time, so every
     elementwise launch on scalars costs ~10 us of it.  `weights`: list of (name, python float); the weight vector is
     uploaded once per device and cached on `module`."""
@@ -62,7 +62,7 @@ def weighted_total(module, terms, weights):
     key = (vals.device, tuple(float(v) for _, v in weights))
     if key not in cache:
         cache[key] = torch.tensor(key[1], dtype=vals.dtype, device=vals.device)
-    return torch.dot(vals, cache[key])
+    return (vals * cache[key]).sum()
 
 
 class RenderCompareS1(nn.Module):
