@@ -10,7 +10,9 @@ python bench.py > "$O/bench_full.json" 2> "$O/bench_full.err"
 python bench.py --model 0 --cpu-baseline 0 > "$O/bench_hotpath_only.json" 2> "$O/bench_hot.err"
 python bench.py --model 0 --cpu-baseline 0 --graph 1 > "$O/bench_hotpath_graph.json" 2> "$O/bench_hot_graph.err"
 python bench.py --workload s2 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o t -- python "$R/bench.py" --steps 10 --warmup 5 --cpu-baseline 0 > "$O/stats.log" 2>&1)
+# the SAME command as the bench line above (default warm-up / steps / profile pass, CPU leg off): the library's HIP events
+# bracket the raster kernels of the last 5 steps (the profile pass), so rocprofv3's last 5 dispatches are the same steps
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o t -- python "$R/bench.py" --cpu-baseline 0 > "$O/stats.log" 2>&1)
 tools/collect_traffic.sh "$O/traffic" > "$O/traffic.log" 2>&1
 (hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_ubench.hip -o /tmp/valu_ubench && timeout 150 /tmp/valu_ubench) > "$O/valu_ubench.log" 2>&1
 python tools/microbench.py > "$O/microbench.log" 2>&1
@@ -20,7 +22,7 @@ tools/pmc_raster.sh "$O/pmc_ts36" 64 3 512 36 > "$O/pmc_ts36.log" 2>&1
 tools/pmc_raster.sh "$O/pmc_ts1" 64 3 512 1 > "$O/pmc_ts1.log" 2>&1
 python - "$O" <<'PY'
 import csv, glob, json, sys, collections
-# per raster kernel: rocprofv3 duration averaged over the LAST 10 dispatches (= the timed steps of the stats run)
+# per raster kernel: rocprofv3 duration averaged over the dispatches of the LAST 5 steps (= bench.py's profile pass)
 out = sys.argv[1]
 d = collections.defaultdict(list)
 for fn in glob.glob(out + "/stats/*kernel_trace.csv"):
@@ -30,10 +32,10 @@ for fn in glob.glob(out + "/stats/*kernel_trace.csv"):
 rep = {}
 for k, v in d.items():
     v.sort()
-    per_step = max(1, len(v) // 15)
-    last = [x[1] for x in v[-10 * per_step:]]
+    per_step = max(1, len(v) // 45)                     # 10 warm-up + 30 timed + 5 profile-pass steps
+    last = [x[1] for x in v[-5 * per_step:]]
     rep[k.replace("(anonymous namespace)::", "")] = {"dispatches": len(v), "avg_us_all": sum(x[1] for x in v) / len(v) / 1e3,
-                                                      "avg_us_last10steps": sum(last) / len(last) / 1e3}
+                                                      "avg_us_profile_pass": sum(last) / len(last) / 1e3}
 json.dump(rep, open(out + "/raster_trace_summary.json", "w"), indent=1)
 PY
 find "$O" -name "*.csv" -size +3M -delete      # keep the merged-back payload small (per-dispatch traces)
