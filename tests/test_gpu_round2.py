@@ -471,3 +471,39 @@ def test_superblock_bins_do_not_change_results():
         for x, y in list(zip(outs[0], outs[1]))[:4]:
             assert torch.equal(x, y)
         assert float((outs[0][4] - outs[1][4]).abs().max()) <= 1e-5      # p2f: float atomics, order not fixed
+
+
+def test_face_start_order_does_not_change_results():
+    """k_face_order only decides WHEN the face-major backward starts the wave of a face (heavy faces first); every face is
+    still reduced by one wave in its own order, so all gradients are bit-identical with the ordering off -- textured
+    (vertex + texel, texel only), hard colour, silhouette; several mesh groups (N > 16), ragged N, image sizes."""
+    from umr_amd import _lib, functional as UF
+    for (n, sub, IS, ts, rgb) in ((18, 2, 128, 4, "softmax"), (3, 3, 256, 36, "softmax"), (2, 2, 200, 1, "hard"), (1, 1, 24, 1, "softmax")):
+        verts, faces, cams, gen = scene(n, sub, seed=IS + 1)
+        _, fv0, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+        tex0 = torch.rand(n, faces.shape[1], ts, 3, generator=gen).to(DEV)
+        w = torch.rand(n, 4, IS, IS, generator=gen).to(DEV)
+        wa = torch.rand(n, IS // 2 if IS % 2 == 0 else IS, IS // 2 if IS % 2 == 0 else IS, generator=gen).to(DEV)
+        outs = []
+        for on in (2, 0):                                                    # 2: ordered start for every variant
+            _lib.debug_set("face_order", on)
+            try:
+                res = []
+                fv = fv0.detach().clone().requires_grad_(True); tex = tex0.clone().requires_grad_(True)
+                sc, _, _ = UF.soft_rasterize(fv, tex, IS, [0.1, 0.2, 0.3], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, rgb)
+                (sc * w).sum().backward()
+                res += [fv.grad.clone(), tex.grad.clone()]
+                tex = tex0.clone().requires_grad_(True)                      # texel gradients only
+                sc, _, _ = UF.soft_rasterize(fv0.detach(), tex, IS, [0.1, 0.2, 0.3], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, rgb)
+                (sc * w).sum().backward()
+                res.append(tex.grad.clone())
+                fv = fv0.detach().clone().requires_grad_(True)               # silhouette
+                a = UF.SilhouetteFunction.apply(fv, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, IS % 2 == 0)
+                (a * wa).sum().backward()
+                res.append(fv.grad.clone())
+                outs.append(res)
+            finally:
+                _lib.debug_set("face_order", 1)
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.isfinite(x).all() and float(x.abs().sum()) > 0
+            assert torch.equal(x, y)

@@ -24,6 +24,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "default"
 if os.environ.get("UMR_SB") == "0":
     _lib.debug_set("superblock_bins", 0)
     tag += " [no super-block bins]"
+if os.environ.get("UMR_FO") == "0":
+    _lib.debug_set("face_order", 0)
+    tag += " [index-order backward]"
+if os.environ.get("UMR_FOG"):
+    _lib.debug_set("face_order_group", int(os.environ["UMR_FOG"]))
+    tag += " [order group %s]" % os.environ["UMR_FOG"]
 out = {"tag": tag}
 out["n16_ts36_texonly_pooled"] = timed(bench, 16, 3, 512, 36, pool=True, need_p2f=False, need_gf=False, iters=20)
 out["n16_ts36_p2f"] = timed(bench, 16, 3, 512, 36, iters=20)

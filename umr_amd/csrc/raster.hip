@@ -25,6 +25,7 @@
 #include "raster_core.h"
 #include "raster_forward.h"
 #include "raster_backward.h"
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -35,6 +36,10 @@ size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 
 size_t ws_rec_bytes(int N, int F) { return (size_t)N * F * REC * sizeof(float); }
 size_t ws_sbcount_bytes(int N) { return (((size_t)N * SB_SLOTS * sizeof(int)) + 255) & ~(size_t)255; }
 size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * F * sizeof(int); }
+size_t ws_order_bytes(int N, int F) { return (size_t)(N + 15) * F * sizeof(int); }   // whole groups of <= 16 meshes
+int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
+int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts its waves in index order,
+                                 // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
 bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
 
 // super-block edge: an eighth of the image, rounded up to whole 16-pixel workgroup blocks (<= 8 x 8 super-blocks)
@@ -90,6 +95,8 @@ int umr_debug_set(const char *key, int value) {
     if (!key) return UMR_ERR_ARG;
     if (std::string(key) == "bwd_pixel_major") { g_bwd_pixel_major = value != 0; return UMR_OK; }
     if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
+    if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
+    if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
     return UMR_ERR_ARG;
 }
 
@@ -118,7 +125,7 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
 
 size_t umr_raster_workspace_bytes(int N, int F) {
     if (N <= 0 || F <= 0) return 0;
-    return ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F);
+    return ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F) + ws_order_bytes(N, F);
 }
 
 int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
@@ -233,6 +240,23 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
+    const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
+    const bool face_major = alpha_only || !(g_bwd_pixel_major || !lds_ok);
+    // Cost-ordered wave start (k_face_order).  Measured on MI355X, us per launch at N = 16 / 128 (F = 1280, IS = 512), index
+    // order -> ordered in groups of 16 | 8 meshes: texel gradients only 137.6 -> 122.3 | 129.7 and 814 -> 838 | 798; vertex +
+    // texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel: with 16 meshes' heavy
+    // faces in flight an XCD's 4 MB L2 no longer holds their state); silhouette unchanged.  So: texel-only variant only,
+    // one group when the launch has <= 16 meshes, groups of 8 otherwise.
+    const int order_mode = alpha_only ? 2 : ((!need_grad_faces && func_id_rgb == 1) ? 1 : 0);
+    if (face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 && F % 8 == 0 &&
+        F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES) {
+        int *order = (int *)((char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) +
+                             ws_sblist_bytes(N, F));
+        int G = std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / (F / 8)));
+        if (g_face_order_group) G = std::min(G, g_face_order_group);
+        k_face_order<<<dim3(8, (N + G - 1) / G), 256, 0, st>>>(A.bbox, A.rec, soft_colors, order, N, F, image_size, G, order_mode);
+        A.order = order; A.order_group = G;
+    }
     {
         // Algorithmic bytes of one backward launch, per VARIANT, by SURVEY.md 8d's rule (every op-boundary buffer the variant
         // touches, once; fp32): per pixel -- the gradient planes it reads (4 B per plane per COARSE pixel when the gradient
@@ -251,7 +275,6 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         else if (need_grad_faces) per_mesh = (gp ? 28.0 : 40.0) * is2 + (double)F * (180.0 + 12.0 * TS);
         else per_mesh = (gp ? 11.0 : 20.0) * is2 + (double)F * (144.0 + 12.0 * TS);
         ProfScope ps(st, alpha_only ? 3 : 1, (double)N * per_mesh);
-        const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
         if (alpha_only) launch_backward_fm<2>(A, st);
         else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
             setup_bins(A, workspace, N, F, image_size, st);

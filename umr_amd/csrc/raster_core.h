@@ -53,6 +53,10 @@ struct RasterArgs {
     const int *sb_count;
     const int *sb_list;
     int sb_size, sb_nx;
+    // face-major backward: start order of the faces (k_face_order).  order[((g * 8 + xcd) * order_group * (F / 8)) + i] =
+    // (mesh - g * order_group) << 16 | face for the i-th wave XCD `xcd` starts within mesh group g; NULL = index order.
+    const int *order;
+    int order_group;
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
