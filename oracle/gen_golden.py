@@ -238,6 +238,45 @@ def gen_part_loss_and_cos_grads(loss_utils, ps_spec):
     print("part_loss_and_cos_grads.npz: loss_avg %.6f loss_weighted %.6f cos %s" % (float(loss_avg), float(loss_w), np_(val)))
 
 
+MODE_CASES = (  # tag, func_id_dist, func_id_alpha, func_id_rgb, texture_sample_type, texture_size, sigma_val
+    ("bary_sum_softmax_vertex", 1, 1, 1, 1, 3, 1e-4),
+    ("hard_hard_hard_surface", 0, 0, 0, 0, 4, 1e-5),
+    ("euclid_sum_hard_vertex", 2, 1, 0, 1, 3, 1e-5),
+    ("bary_prod_softmax_surface", 1, 2, 1, 0, 4, 1e-4),
+    ("hard_prod_softmax_surface", 0, 2, 1, 0, 1, 1e-5),
+    ("euclid_hard_softmax_surface", 2, 0, 1, 0, 9, 1e-5),
+    ("bary_hard_hard_vertex", 1, 0, 0, 1, 3, 1e-4),
+)
+
+
+def gen_raster_modes(sr, geom_utils, softras):
+    """The mode ids UMR never selects but the binding accepts (functional/soft_rasterize.py:21-24): hard / barycentric
+    distance, hard / sum alpha, vertex textures -- forward outputs and gradients straight from the reference kernels."""
+    verts, faces, cams, g = scene(2, 1, seed=57)
+    proj = geom_utils.orthographic_proj_withz(verts, cams, offset_z=5.)
+    proj[:, :, 1] *= -1
+    proj[:, :, 2] += 2.732
+    fv = np_(sr.functional.face_vertices(proj, faces.int()).contiguous())
+    IS = 32
+    gsc = np_(torch.randn(2, 4, IS, IS, generator=g))
+    d = dict(faces=fv, image_size=IS, background=np.float32([0.1, 0.2, 0.3]), grad_soft_colors=gsc,
+             cases=np.array([c[0] for c in MODE_CASES]), near=1., far=100., eps=1e-3,
+             dist_eps_log=float(np.log(1. / 1e-10 - 1.)), gamma_val=1e-4, double_side=True)
+    for tag, fd, fa, fr, tt, ts, sigma in MODE_CASES:
+        tex = np_(torch.rand(2, faces.shape[1], ts, 3, generator=g))
+        cfg = dict(near=1., far=100., eps=1e-3, sigma_val=sigma, dist_eps_log=d["dist_eps_log"], gamma_val=1e-4,
+                   func_id_rgb=fr, double_side=True, func_id_dist=fd, func_id_alpha=fa, texture_sample_type=tt)
+        o = softras.raster_forward(fv, tex, IS, background=(0.1, 0.2, 0.3), backend="ref", **cfg)
+        gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                         gsc, IS, backend="ref", **cfg)
+        assert np.isfinite(gf).all() and np.isfinite(gt).all()
+        d.update({tag + "/modes": np.int32([fd, fa, fr, tt]), tag + "/sigma_val": np.float32(sigma), tag + "/textures": tex,
+                  tag + "/soft_colors": o["soft_colors"], tag + "/aggrs_info": o["aggrs_info"], tag + "/p2f_info": o["p2f_info"],
+                  tag + "/p2f_sum": o["p2f_sum"], tag + "/grad_faces": gf, tag + "/grad_textures": gt})
+        print("raster_modes/%s" % tag, "alpha mean %.4f" % o["soft_colors"][:, 3].mean(), "|gf| %.3e |gt| %.3e" % (np.abs(gf).sum(), np.abs(gt).sum()))
+    np.savez_compressed(os.path.join(OUT, "raster_modes.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     lib, sr, smr, loss_utils, geom_utils, chamfer_python, scops_utils, ps_spec = install_reference()
@@ -248,6 +287,8 @@ def main():
     from oracle import softras  # only for its ctypes helper on the ref .so
     if sys.argv[1:] == ["save_obj"]:
         return gen_save_obj(lib)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "modes":
+        return gen_raster_modes(sr, geom_utils, softras)
 
     # (i) kernel-level: faces in screen space straight into the reference kernels -------------------------
     for tag, ts, rgb in (("softmax_ts36", 36, 1), ("softmax_ts1", 1, 1), ("hard_ts1", 1, 0), ("hard_ts4", 4, 0)):

@@ -24,9 +24,11 @@
  * pattern expression by expression (see the "dbl:" comments) and must be
  * compiled with -ffp-contract=off.
  *
- * Scope: the modes UMR instantiates (nnutils/smr.py:53-66) -- dist_func
- * euclidean (func_id_dist=2), alpha 'prod' (func_id_alpha=2), rgb 'softmax'
- * (1) or 'hard' (0), texture_type 'surface' (0).  Other ids return -1.
+ * Scope: every mode id the binding accepts (functional/soft_rasterize.py:21-24):
+ * dist_func hard (0) / barycentric (1) / euclidean (2), alpha hard (0) / sum (1) /
+ * prod (2), rgb hard (0) / softmax (1), texture_type surface (0) / vertex (1, which
+ * needs texture_size == 3: the reference indexes w[j] for j < texture_size, :215).
+ * UMR itself instantiates euclidean + prod + surface (nnutils/smr.py:53-66).
  *
  * Pinning: validated against the reference's own kernel bodies compiled for
  * the host (oracle/ref_shim -> oracle/_ref/libsoftras_ref.so) and against
@@ -172,9 +174,51 @@ typedef struct {
     int rgb_mode, double_side;
 } oracle_params;
 
-static int modes_supported(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type) {
-    return func_id_dist == 2 && func_id_alpha == 2 && texture_sample_type == 0 &&
-           (func_id_rgb == 0 || func_id_rgb == 1);
+static int modes_supported(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int ts) {
+    if (func_id_dist < 0 || func_id_dist > 2 || func_id_alpha < 0 || func_id_alpha > 2) return 0;
+    if (func_id_rgb != 0 && func_id_rgb != 1) return 0;
+    if (texture_sample_type == 1) return ts == 3;
+    return texture_sample_type == 0;
+}
+
+/* :154-157 -- barycentric "distance": the smallest coordinate, squared with its sign.  pow(float, 2) is the exact
+ * square rounded to float (CUDA's pow(float, int) multiplies; the host overload squares in double and rounds). */
+static inline float bary_dist(const float *w) {
+    float dis = w[0] > w[1] ? (w[1] > w[2] ? w[2] : w[1]) : (w[0] > w[2] ? w[2] : w[0]);
+    dis = dis > 0 ? dis * dis : -(dis * dis);
+    return dis;
+}
+
+/* :24-29 + :351-385 -- barycentrics and the probability map of one (pixel, face) pair for every dist mode.  Returns 1
+ * when the reference `continue`s (:367, :371, :376) or runs into its v0 = -1 case (header).  sign/dx/dy/t are only
+ * defined for the euclidean mode, dis for modes 1 and 2. */
+static inline int fragment(int func_id_dist, float *frag, float *dis, float *sign, float *dx, float *dy, float *w, float *t,
+                           const float *f, const float *fi, float xp, float yp, float threshold, float sigma_val) {
+    for (int k = 0; k < 3; ++k) w[k] = fi[3 * k] * xp + fi[3 * k + 1] * yp + fi[3 * k + 2];
+    *sign = 0.f; *dx = 0.f; *dy = 0.f; *dis = 0.f;
+    t[0] = t[1] = t[2] = 0.f;
+    if (func_id_dist == 0) { /* :365-367 */
+        const int inside = w[0] <= 1 && w[0] >= 0 && w[1] <= 1 && w[1] >= 0 && w[2] <= 1 && w[2] >= 0;
+        *frag = inside ? 1.f : 0.f;
+        return !inside;
+    }
+    if (func_id_dist == 1) { /* :369-372 */
+        *dis = bary_dist(w);
+        if (-*dis >= threshold) return 1;
+        *frag = (float)(1. / (1. + (double)expf(-*dis / sigma_val)));
+        return 0;
+    }
+    if (p2f_euclid(sign, dx, dy, w, t, f, fi, xp, yp)) return 1;
+    *dis = *dx * *dx + *dy * *dy;
+    if (*sign < 0 && *dis >= threshold) return 1; /* :382 */
+    *frag = (float)(1. / (1. + (double)expf(-*sign * *dis / sigma_val))); /* dbl: 1./(1.+float) (:383) */
+    return 0;
+}
+
+/* :178-195 -- colour channel k of a face at clipped barycentrics w */
+static inline float sample_texture(const float *tex, const float *w, int R, int k, int texture_sample_type) {
+    if (texture_sample_type == 0) return tex[texel_index(w, R) * 3 + k];
+    return w[0] * tex[k] + w[1] * tex[3 + k] + w[2] * tex[6 + k]; /* :192 */
 }
 
 /* ---- :286-476 --------------------------------------------------------------
@@ -190,7 +234,7 @@ int oracle_raster_forward(const float *faces, const float *textures, float *face
                           int func_id_dist, float dist_eps, float gamma_val, int func_id_rgb,
                           int func_id_alpha, int texture_sample_type, int double_side,
                           int n_threads) {
-    if (!modes_supported(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return -1;
+    if (!modes_supported(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, texture_size)) return -1;
     oracle_face_info(faces, faces_info, n_meshes, n_faces);
     const int is = image_size, nf = n_faces, ts = texture_size;
     const int R = (int)sqrt((double)ts); /* :687 */
@@ -219,7 +263,8 @@ int oracle_raster_forward(const float *faces, const float *textures, float *face
             const int yi = is - 1 - r;
             const float yp = (float)((2. * yi + 1. - is) / is); /* dbl (:325-326) */
             const float xp = (float)((2. * xi + 1. - is) / is);
-            float col[4] = {1.f, 1.f, 1.f, 1.f}; /* alpha starts at 1 for 'prod' (:335-336) */
+            float col[4] = {1.f, 1.f, 1.f, 0.f}; /* :335 */
+            if (func_id_alpha == 2) col[3] = 1.f; /* alpha starts at 1 for 'prod' (:336) */
             float ssum = expf(eps / gamma_val);   /* :337 */
             float smax = eps;
             for (int k = 0; k < 3; ++k) {
@@ -233,14 +278,15 @@ int oracle_raster_forward(const float *faces, const float *textures, float *face
                 const float *fi = faces_info + ((long)bn * nf + fn) * FI_STRIDE;
                 const float *tex = textures + ((long)bn * nf + fn) * ts * 3;
                 if (outside_bbox(xp, yp, f, thr)) continue;
-                float w[3], wc[3], t[3], sign, dx, dy;
-                for (int k = 0; k < 3; ++k) w[k] = fi[3 * k] * xp + fi[3 * k + 1] * yp + fi[3 * k + 2];
-                if (p2f_euclid(&sign, &dx, &dy, w, t, f, fi, xp, yp)) continue;
-                const float dis = dx * dx + dy * dy;
-                if (sign < 0 && dis >= threshold) continue; /* :382 */
-                /* dbl: 1./(1.+float) (:383) */
-                const float frag = (float)(1. / (1. + (double)expf(-sign * dis / sigma_val)));
-                col[3] = (float)((double)col[3] * (1. - (double)frag)); /* dbl (:396) */
+                float w[3], wc[3], t[3], sign, dx, dy, dis, frag;
+                if (fragment(func_id_dist, &frag, &dis, &sign, &dx, &dy, w, t, f, fi, xp, yp, threshold, sigma_val)) continue;
+                if (func_id_alpha == 0) { /* :390-391 */
+                    if (frag > 0.5) col[3] = 1.f;
+                } else if (func_id_alpha == 1) { /* :393 */
+                    col[3] += frag;
+                } else {
+                    col[3] = (float)((double)col[3] * (1. - (double)frag)); /* dbl (:396) */
+                }
                 for (int k = 0; k < 3; ++k) wc[k] = w[k];
                 bary_clip(wc);
                 const float zp = (float)(1. / (double)(wc[0] / f[2] + wc[1] / f[5] + wc[2] / f[8])); /* dbl (:403) */
@@ -250,8 +296,7 @@ int oracle_raster_forward(const float *faces, const float *textures, float *face
                     if (zp < depth_min && inside && (double_side || front_facing(f))) {
                         depth_min = zp;
                         face_min = fn;
-                        const int tix = texel_index(wc, R);
-                        for (int k = 0; k < 3; ++k) col[k] = tex[tix * 3 + k];
+                        for (int k = 0; k < 3; ++k) col[k] = sample_texture(tex, wc, R, k, texture_sample_type);
                     }
                 } else if (front_facing(f) || double_side) { /* :417-436 */
                     const float zn = (far_ - zp) / (far_ - near_);
@@ -271,11 +316,13 @@ int oracle_raster_forward(const float *faces, const float *textures, float *face
                         float *ps = p2f_sum + ((long)bn * nf + fn) * 2;
                         pi[0] += gx; pi[1] += gy; ps[0] += wgt; ps[1] += wgt;
                     }
-                    const int tix = texel_index(wc, R);
-                    for (int k = 0; k < 3; ++k) col[k] = rescale * col[k] + wgt * tex[tix * 3 + k];
+                    for (int k = 0; k < 3; ++k)
+                        col[k] = rescale * col[k] + wgt * sample_texture(tex, wc, R, k, texture_sample_type);
                 }
             }
-            soft_colors[((long)bn * 4 + 3) * npix + pn] = (float)(1. - (double)col[3]); /* :450 */
+            if (func_id_alpha == 0) soft_colors[((long)bn * 4 + 3) * npix + pn] = col[3]; /* :444 */
+            else if (func_id_alpha == 1) soft_colors[((long)bn * 4 + 3) * npix + pn] = col[3] / nf; /* :447 */
+            else soft_colors[((long)bn * 4 + 3) * npix + pn] = (float)(1. - (double)col[3]); /* :450 */
             if (func_id_rgb == 0) {
                 if (face_min != -1)
                     for (int k = 0; k < 3; ++k) soft_colors[((long)bn * 4 + k) * npix + pn] = col[k];
@@ -311,7 +358,7 @@ int oracle_raster_backward(const float *faces, const float *textures, const floa
                            float gamma_val, int func_id_rgb, int func_id_alpha,
                            int texture_sample_type, int double_side, int n_threads) {
     (void)eps;
-    if (!modes_supported(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type)) return -1;
+    if (!modes_supported(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, texture_size)) return -1;
     const int is = image_size, nf = n_faces, ts = texture_size;
     const int R = (int)sqrt((double)ts);
     const long npix = (long)is * is;
@@ -353,16 +400,15 @@ int oracle_raster_backward(const float *faces, const float *textures, const floa
                 const float *fi = faces_info + ((long)bn * nf + fn) * FI_STRIDE;
                 const float *tex = textures + ((long)bn * nf + fn) * ts * 3;
                 if (outside_bbox(xp, yp, f, thr)) continue;
-                float w[3], w0[3], t[3], sign, dx, dy;
-                for (int k = 0; k < 3; ++k) w[k] = fi[3 * k] * xp + fi[3 * k + 1] * yp + fi[3 * k + 2];
-                if (p2f_euclid(&sign, &dx, &dy, w, t, f, fi, xp, yp)) continue;
-                const float dis = dx * dx + dy * dy;
-                if (sign < 0 && dis >= threshold) continue;
-                const float frag = (float)(1. / (1. + (double)expf(-sign * dis / sigma_val)));
+                float w[3], w0[3], t[3], sign, dx, dy, dis, frag;
+                if (fragment(func_id_dist, &frag, &dis, &sign, &dx, &dy, w, t, f, fi, xp, yp, threshold, sigma_val)) continue;
+                if (func_id_dist == 1)
+                    for (int k = 0; k < 3; ++k) t[k] = w[k]; /* :553: the UNCLIPPED barycentrics */
                 float gv[3][3] = {{0}};
+                float c_alpha = g[3]; /* :577; hard alpha (0) adds it unscaled (:578-580) */
+                if (func_id_alpha == 1) c_alpha /= nf; /* :582 */
                 /* dbl: max(1-frag, 1e-6) is double, so is the quotient and product (:584) */
-                float c_alpha = g[3];
-                c_alpha = (float)((double)c_alpha * ((double)(1 - out_a) / fmax((double)(1 - frag), 1e-6)));
+                else if (func_id_alpha == 2) c_alpha = (float)((double)c_alpha * ((double)(1 - out_a) / fmax((double)(1 - frag), 1e-6)));
                 float c_xy = 0.f;
                 c_xy += c_alpha;
                 for (int k = 0; k < 3; ++k) w0[k] = w[k];
@@ -372,17 +418,23 @@ int oracle_raster_backward(const float *faces, const float *textures, const floa
                 float *gtex = gT + ((long)bn * nf + fn) * ts * 3;
                 if (func_id_rgb == 0) { /* :595-602 */
                     if ((float)fn == smax) {
-                        const int tix = texel_index(w, R);
-                        for (int k = 0; k < 3; ++k) gtex[tix * 3 + k] += g[k];
+                        if (texture_sample_type == 0) {
+                            const int tix = texel_index(w, R);
+                            for (int k = 0; k < 3; ++k) gtex[tix * 3 + k] += g[k];
+                        } else {
+                            for (int k = 0; k < 3; ++k)
+                                for (int j = 0; j < ts; ++j) gtex[3 * j + k] += w[j] * g[k]; /* :215 */
+                        }
                     }
                 } else if (front_facing(f) || double_side) { /* :604-628 */
                     float c_rgb = 0.f;
                     const float zn = (far_ - zp) / (far_ - near_);
                     const float p = frag * expf((zn - smax) / gamma_val) / ssum;
-                    const int tix = texel_index(w, R);
                     for (int k = 0; k < 3; ++k) {
-                        gtex[tix * 3 + k] += p * g[k];
-                        c_rgb += g[k] * (tex[tix * 3 + k] - out_c[k]);
+                        if (texture_sample_type == 0) gtex[texel_index(w, R) * 3 + k] += p * g[k];
+                        else
+                            for (int j = 0; j < ts; ++j) gtex[3 * j + k] += p * (w[j] * g[k]);
+                        c_rgb += g[k] * (sample_texture(tex, w, R, k, texture_sample_type) - out_c[k]);
                     }
                     c_rgb *= p;
                     c_xy += c_rgb / frag;
@@ -392,9 +444,20 @@ int oracle_raster_backward(const float *faces, const float *textures, const floa
                     gv[2][2] = c_z * w[2] / f[8] / f[8];
                 }
                 c_xy *= frag * (1 - frag) / sigma_val; /* :632 */
-                for (int k = 0; k < 3; ++k) {
-                    gv[k][0] = 2 * sign * c_xy * (t[k] + w0[k]) * dx; /* :640 */
-                    gv[k][1] = 2 * sign * c_xy * (t[k] + w0[k]) * dy;
+                if (func_id_dist == 1) { /* :160-175 */
+                    const int pmin = t[0] > t[1] ? (t[1] > t[2] ? 2 : 1) : (t[0] > t[2] ? 2 : 0);
+                    for (int l = 0; l < 2; ++l)
+                        for (int k = 0; k < 3; ++k) {
+                            float gkl = 0.f;
+                            for (int q = 0; q < 3; ++q) gkl += -fi[3 * pmin + l] * fi[3 * k + q] * (q == 0 ? xp : (q == 1 ? yp : 1));
+                            gv[k][l] = gkl * c_xy;
+                            gv[k][l] = (float)((double)gv[k][l] * (dis > 0 ? (2. * sqrtf(dis)) : (2. * sqrtf(-dis)))); /* dbl */
+                        }
+                } else if (func_id_dist == 2) {
+                    for (int k = 0; k < 3; ++k) {
+                        gv[k][0] = 2 * sign * c_xy * (t[k] + w0[k]) * dx; /* :640 */
+                        gv[k][1] = 2 * sign * c_xy * (t[k] + w0[k]) * dy;
+                    }
                 }
                 float *gf = gF + ((long)bn * nf + fn) * 9;
                 for (int k = 0; k < 3; ++k)

@@ -91,7 +91,9 @@ def test_raster_flags_and_fused_pool():
     assert float((c["pooled"] - ref).abs().max()) <= 1e-6
 
 
-def test_raster_rejects_unsupported_modes():
+def test_raster_rejects_undefined_modes():
+    """Mode ids outside the reference binding's maps, vertex textures with texture_size != 3 (the reference would read
+    w[3..], :215), a non-square surface texture size, and the fused fast-path flags combined with a non-UMR mode."""
     from umr_amd import _lib
     L = _lib.lib()
     t = torch.zeros(64, device=DEV)
@@ -99,10 +101,14 @@ def test_raster_rejects_unsupported_modes():
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     p = _lib.ptr
     base = [p(t), p(t), p(t), p(t), p(t), p(t), p(t), p(t), None, 1, 1, 1, 2, 1., 100., 1e-3, 1e-5]
-    tail = [1e-4, 1, 2, 0, 1, 0, None, p(ws), wsb, None]
-    assert L.umr_raster_forward(*base, 1, 23.0, *tail) == -1          # barycentric distance: unsupported
-    assert L.umr_raster_forward(*base, 2, 23.0, 1e-4, 1, 1, 0, 1, 0, None, p(ws), wsb, None) == -1  # alpha 'sum'
-    assert L.umr_raster_forward(*base[:9], 1, 1, 2, 2, 1., 100., 1e-3, 1e-5, 2, 23.0, *tail) == -1  # TS not square
+    assert L.umr_raster_forward(*base, 3, 23.0, 1e-4, 1, 2, 0, 1, 0, None, p(ws), wsb, None) == -1   # func_id_dist 3
+    assert L.umr_raster_forward(*base, 2, 23.0, 1e-4, 1, 3, 0, 1, 0, None, p(ws), wsb, None) == -1   # func_id_alpha 3
+    assert L.umr_raster_forward(*base, 2, 23.0, 1e-4, 1, 2, 1, 1, 0, None, p(ws), wsb, None) == -1   # vertex textures, TS = 1
+    assert L.umr_raster_forward(*base, 1, 23.0, 1e-4, 1, 2, 0, 1, 2, None, p(ws), wsb, None) == -1   # ALPHA_ONLY + barycentric
+    assert L.umr_raster_forward(*base[:9], 1, 1, 2, 2, 1., 100., 1e-3, 1e-5, 2, 23.0, 1e-4, 1, 2, 0, 1, 0, None, p(ws), wsb,
+                                None) == -1                                                        # TS not square
+    assert L.umr_raster_forward(*base, 1, 23.0, 1e-4, 1, 1, 0, 1, 0, None, p(ws), wsb, None) == 0    # barycentric + sum: built
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("name", ["smr_mask_default_light.npz", "smr_tex_ambient.npz", "smr_tex_default_light.npz",

@@ -36,7 +36,7 @@ def _lib(name="libsoftras_ref_gfx950.so"):
     return h
 
 
-def _run_ref(h, faces, tex, IS, cfg, gsc, background=(0., 0., 0.)):
+def _run_ref(h, faces, tex, IS, cfg, gsc, background=(0., 0., 0.), modes=(2, 2, 0)):
     """functional/soft_rasterize.py:47-75, 95-106 around the reference kernels: buffers pre-filled the reference's way."""
     from umr_amd.functional import standard_grid
     N, F = faces.shape[:2]
@@ -49,8 +49,8 @@ def _run_ref(h, faces, tex, IS, cfg, gsc, background=(0., 0., 0.)):
     for k in range(3):
         sc[:, k] *= float(background[k])
     grid = standard_grid(IS, torch.device(DEV))
-    scal = (float(cfg["near"]), float(cfg["far"]), float(cfg["eps"]), float(cfg["sigma_val"]), 2, float(cfg["dist_eps_log"]),
-            float(cfg["gamma_val"]), int(cfg["func_id_rgb"]), 2, 0, int(bool(cfg["double_side"])))
+    scal = (float(cfg["near"]), float(cfg["far"]), float(cfg["eps"]), float(cfg["sigma_val"]), int(modes[0]), float(cfg["dist_eps_log"]),
+            float(cfg["gamma_val"]), int(cfg["func_id_rgb"]), int(modes[1]), int(modes[2]), int(bool(cfg["double_side"])))
     st = torch.cuda.current_stream().cuda_stream
     assert h.refgpu_forward_soft_rasterize(p(faces), p(tex), p(faces_info), p(aggrs), p(grid), p(p2f_info), p(p2f_sum), p(sc),
                                            N, F, IS, TS, *scal, st) == 0
@@ -118,3 +118,79 @@ def test_fma_contraction_sensitivity_of_the_reference_text():
     faces, tex = torch.from_numpy(g["faces"]).to(DEV), torch.from_numpy(g["textures"]).to(DEV)
     o = _run_ref(h, faces, tex, int(g["image_size"]), g, torch.from_numpy(g["grad_soft_colors"]).to(DEV), g["background"])
     assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=0.995, name="refgpu_fma_soft_colors")
+
+
+_DIST = {0: "hard", 1: "barycentric", 2: "euclidean"}
+_ALPHA = {0: "hard", 1: "sum", 2: "prod"}
+_RGB = {0: "hard", 1: "softmax"}
+_TEX = {0: "surface", 1: "vertex"}
+
+
+def _product_modes(faces, tex, IS, sigma, modes, gsc, background):
+    """umr_amd.functional.soft_rasterize with the reference's mode names -> outputs and autograd gradients"""
+    from umr_amd import functional as UF
+    fd, fa, fr, tt = modes
+    fv = faces.view(faces.shape[0], faces.shape[1], 3, 3).clone().requires_grad_(True)
+    tx = tex.clone().requires_grad_(True)
+    sc, p2f, aggr = UF.soft_rasterize(fv, tx, IS, list(background), 1., 100., True, 1e-3, sigma, _DIST[fd], 1e-10, 1e-4,
+                                      _RGB[fr], _ALPHA[fa], _TEX[tt])
+    (sc * gsc).sum().backward()
+    return sc.detach(), p2f.detach(), aggr.detach(), fv.grad.reshape(faces.shape[0], faces.shape[1], 9), tx.grad
+
+
+def _mode_cases():
+    return [str(c) for c in load_golden("raster_modes.npz")["cases"]]
+
+
+@pytest.mark.parametrize("case", _mode_cases())
+def test_other_modes_vs_reference_golden(case):
+    """The mode ids UMR never selects (hard / barycentric distance, hard / sum alpha, vertex textures): the general-mode
+    kernels (csrc/raster_general.h) through the public soft_rasterize against outputs and gradients of the reference
+    kernels themselves (tests/golden/raster_modes.npz, oracle/gen_golden.py --only modes)."""
+    g = load_golden("raster_modes.npz")
+    modes = [int(v) for v in g[case + "/modes"]]
+    faces = torch.from_numpy(g["faces"]).to(DEV)
+    tex = torch.from_numpy(g[case + "/textures"]).to(DEV)
+    gsc = torch.from_numpy(g["grad_soft_colors"]).to(DEV)
+    IS = int(g["image_size"])
+    sc, p2f, aggr, gf, gt = _product_modes(faces, tex, IS, float(g[case + "/sigma_val"]), modes, gsc, g["background"])
+    assert_close_frac(t2n(sc), g[case + "/soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="modes_%s_soft_colors" % case)
+    if modes[2] == 0:     # hard colour: (depth, face id) planes
+        assert np.array_equal(t2n(aggr[:, 1]), g[case + "/aggrs_info"][:, 1])
+        np.testing.assert_allclose(t2n(aggr[:, 0]), g[case + "/aggrs_info"][:, 0], rtol=1e-6)
+    else:
+        assert_close_frac(t2n(aggr), g[case + "/aggrs_info"], atol=0, rtol=1e-5, frac=0.9999, name="modes_%s_aggrs" % case)
+        ref_p2f = g[case + "/p2f_info"] / np.maximum(g[case + "/p2f_sum"], 1e-12)
+        assert_close_frac(t2n(p2f), ref_p2f, atol=1e-5, rtol=1e-4, frac=1.0, name="modes_%s_p2f" % case)
+    rgf, rgt = g[case + "/grad_faces"], g[case + "/grad_textures"]
+    assert_close_frac(t2n(gf), rgf, atol=1e-5 * max(np.abs(rgf).max(), 1e-30), rtol=2e-4, frac=0.999, name="modes_%s_grad_faces" % case)
+    assert_close_frac(t2n(gt), rgt, atol=1e-5 * np.abs(rgt).max(), rtol=2e-4, frac=0.999, name="modes_%s_grad_textures" % case)
+    if modes[0] == 0:
+        assert float(gf[:, :, [0, 1, 3, 4, 6, 7]].abs().max()) == 0.0       # 'hard' distance has no x / y gradient (:634-642)
+
+
+@pytest.mark.parametrize("modes,ts,sigma", [((1, 1, 1, 1), 3, 1e-4), ((0, 0, 0, 0), 16, 1e-5), ((2, 1, 1, 1), 3, 1e-5),
+                                            ((1, 2, 0, 0), 4, 3e-5)])
+def test_other_modes_vs_reference_device_code_full_size(modes, ts, sigma):
+    """Same, side by side with the reference's own device code on the GPU at 2 x 1280 faces x 256^2."""
+    h = _lib()
+    verts, faces_i, cams, gen = scene(2, 3, seed=5 + modes[0])
+    from umr_amd import functional as UF
+    _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces_i.int().to(DEV), 5.0, -2.732, False)
+    faces = fv.reshape(2, -1, 9).contiguous()
+    tex = torch.rand(2, faces.shape[1], ts, 3, generator=gen).to(DEV)
+    IS = 256
+    gsc = torch.randn(2, 4, IS, IS, generator=gen).to(DEV)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=sigma, dist_eps_log=math.log(1. / 1e-10 - 1.), gamma_val=1e-4,
+               func_id_rgb=modes[2], double_side=True)
+    bg = (0.1, 0.2, 0.3)
+    o = _run_ref(h, faces, tex, IS, cfg, gsc, bg, modes=(modes[0], modes[1], modes[3]))
+    sc, p2f, aggr, gf, gt = _product_modes(faces, tex, IS, sigma, modes, gsc, bg)
+    tag = "modes%d%d%d%d" % tuple(modes)
+    assert_close_frac(t2n(sc), t2n(o["soft_colors"]), atol=1e-4, frac=0.9999, max_outlier=2e-3, name=tag + "_soft_colors")
+    if modes[2] == 0:
+        same = (aggr[:, 1] == o["aggrs_info"][:, 1]).float().mean().item()
+        assert same >= 0.9999, same
+    rgf, rgt = t2n(o["grad_faces"]), t2n(o["grad_textures"])
+    assert_close_frac(t2n(gf), rgf, atol=3e-4 * max(np.abs(rgf).max(), 1e-30), rtol=5e-3, frac=0.995, name=tag + "_grad_faces")
+    assert_close_frac(t2n(gt), rgt, atol=3e-4 * np.abs(rgt).max(), rtol=5e-3, frac=0.995, name=tag + "_grad_textures")

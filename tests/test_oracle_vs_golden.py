@@ -51,10 +51,39 @@ def test_raster_port_single_thread_is_bit_exact(oracle_built):
 
 
 def test_unsupported_modes_rejected(oracle_built):
+    """vertex textures index w[j] for j < texture_size (:215): only texture_size == 3 is defined; unknown ids refused"""
     from oracle import softras
     g = load_golden("raster_softmax_ts1.npz")
     with pytest.raises(RuntimeError):
-        softras.raster_forward(g["faces"], g["textures"], 16, func_id_dist=1, **_cfg(g))
+        softras.raster_forward(g["faces"], g["textures"], 16, texture_sample_type=1, **_cfg(g))
+    with pytest.raises(RuntimeError):
+        softras.raster_forward(g["faces"], g["textures"], 16, func_id_dist=3, **_cfg(g))
+
+
+def mode_cases():
+    g = load_golden("raster_modes.npz")
+    return [str(c) for c in g["cases"]]
+
+
+@pytest.mark.parametrize("case", mode_cases())
+def test_raster_port_other_modes_bit_exact(oracle_built, case):
+    """The mode ids UMR does not select (hard / barycentric distance, hard / sum alpha, vertex textures,
+    soft_rasterize_cuda_kernel.cu:154-218, :365-398, :444-447, :577-583, :634-636): the single-thread restatement
+    reproduces the reference kernels' outputs and gradients to the bit."""
+    from oracle import softras
+    g = load_golden("raster_modes.npz")
+    fd, fa, fr, tt = [int(v) for v in g[case + "/modes"]]
+    cfg = dict(near=float(g["near"]), far=float(g["far"]), eps=float(g["eps"]), sigma_val=float(g[case + "/sigma_val"]),
+               dist_eps_log=float(g["dist_eps_log"]), gamma_val=float(g["gamma_val"]), func_id_rgb=fr, double_side=True,
+               func_id_dist=fd, func_id_alpha=fa, texture_sample_type=tt)
+    IS = int(g["image_size"])
+    o = softras.raster_forward(g["faces"], g[case + "/textures"], IS, background=tuple(g["background"]), backend="port",
+                               n_threads=1, **cfg)
+    for k in ("soft_colors", "aggrs_info", "p2f_info", "p2f_sum"):
+        assert np.array_equal(o[k], g[case + "/" + k]), k
+    gf, gt = softras.raster_backward(g["faces"], g[case + "/textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
+                                     g["grad_soft_colors"], IS, backend="port", n_threads=1, **cfg)
+    assert np.array_equal(gf, g[case + "/grad_faces"]) and np.array_equal(gt, g[case + "/grad_textures"])
 
 
 @pytest.mark.parametrize("name", ["smr_mask_default_light.npz", "smr_tex_ambient.npz", "smr_tex_default_light.npz",

@@ -25,6 +25,7 @@
 #include "raster_core.h"
 #include "raster_forward.h"
 #include "raster_backward.h"
+#include "raster_general.h"
 #include <algorithm>
 #include <mutex>
 #include <string>
@@ -145,7 +146,9 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     if (!faces || (!soft_colors && !ids_only) || !workspace) return UMR_ERR_ARG;
     if (!alpha_only && !ids_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
-    if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
+    bool general = false;
+    if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R, &general)) return UMR_ERR_ARG;
+    if (general && (alpha_only || ids_only || pooled_out)) return UMR_ERR_ARG;   // fused variants exist for UMR's modes only
     if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
     const int with_p2f = func_id_rgb == 1 && !alpha_only && !(flags & UMR_RASTER_NO_P2F);
     if (with_p2f && (!grid || !p2f_info || !p2f_sum)) return UMR_ERR_ARG;
@@ -166,6 +169,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     if (background) { A.bg_arg = 1; A.bg0 = background[0]; A.bg1 = background[1]; A.bg2 = background[2]; }
+    A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     const int total = N * F;
     k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold), near_, far_);
@@ -179,7 +183,9 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                      : ids_only ? (double)N * (8.0 * image_size * image_size + 36.0 * F)
                                 : (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
         // p2f accumulation and face culling are compile-time: as run-time flags they cost SGPRs in every variant
-        if (ids_only) {
+        if (general) {
+            k_raster_forward_general<<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else if (ids_only) {
             if (double_side) k_raster_forward<3, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
             else k_raster_forward<3, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
         } else if (alpha_only) {
@@ -217,7 +223,9 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     if (alpha_only && (need_grad_textures || !need_grad_faces)) return UMR_ERR_ARG;
     if ((need_grad_faces && !grad_faces) || (need_grad_textures && !grad_textures)) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
-    if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R)) return UMR_ERR_ARG;
+    bool general = false;
+    if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R, &general)) return UMR_ERR_ARG;
+    if (general && (alpha_only || grad_is_pooled)) return UMR_ERR_ARG;
     if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
     if (grad_is_pooled && (image_size & 1)) return UMR_ERR_ARG;
     if (!need_grad_faces && !need_grad_textures) return UMR_OK;
@@ -234,6 +242,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
     A.tex_group = tex_group;
+    A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     const int total = N * F;
@@ -241,7 +250,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
                                                       sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
     const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
-    const bool face_major = alpha_only || !(g_bwd_pixel_major || !lds_ok);
+    const bool face_major = !general && (alpha_only || !(g_bwd_pixel_major || !lds_ok));
     // Cost-ordered wave start (k_face_order).  Measured on MI355X, us per launch at N = 16 / 128 (F = 1280, IS = 512), index
     // order -> ordered in groups of 16 | 8 meshes: texel gradients only 137.6 -> 122.3 | 129.7 and 814 -> 838 | 798; vertex +
     // texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel: with 16 meshes' heavy
@@ -275,7 +284,10 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         else if (need_grad_faces) per_mesh = (gp ? 28.0 : 40.0) * is2 + (double)F * (180.0 + 12.0 * TS);
         else per_mesh = (gp ? 11.0 : 20.0) * is2 + (double)F * (144.0 + 12.0 * TS);
         ProfScope ps(st, alpha_only ? 3 : 1, (double)N * per_mesh);
-        if (alpha_only) launch_backward_fm<2>(A, st);
+        if (general) {
+            setup_bins(A, workspace, N, F, image_size, st);
+            k_raster_backward_general<<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else if (alpha_only) launch_backward_fm<2>(A, st);
         else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
             setup_bins(A, workspace, N, F, image_size, st);
             if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);

@@ -599,9 +599,17 @@ void launch_backward_fm(const RasterArgs &A, hipStream_t st) {
     else launch_backward_fm2<RGB, false>(A, st);
 }
 
-bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int TS, int *R) {
-    if (func_id_dist != 2 || func_id_alpha != 2 || texture_sample_type != 0) return false;
+// Mode ids of the reference binding (functional/soft_rasterize.py:21-24).  *general = anything but the combination UMR
+// instantiates (euclidean distance, 'prod' alpha, surface textures), which has the specialised kernels.
+bool modes_ok(int func_id_dist, int func_id_rgb, int func_id_alpha, int texture_sample_type, int TS, int *R, bool *general) {
+    if (func_id_dist < 0 || func_id_dist > 2 || func_id_alpha < 0 || func_id_alpha > 2) return false;
     if (func_id_rgb != 0 && func_id_rgb != 1) return false;
+    if (texture_sample_type != 0 && texture_sample_type != 1) return false;
+    *general = !(func_id_dist == 2 && func_id_alpha == 2 && texture_sample_type == 0);
+    if (texture_sample_type == 1) {   // vertex colours: the reference reads w[j] for j < texture_size (:215)
+        *R = 1;
+        return TS == 3;
+    }
     int r = 1;
     while (r * r < TS) ++r;
     if (r * r != TS) return false;

@@ -58,6 +58,9 @@ struct RasterArgs {
     const int *order;
     int order_group;
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
+    // read by the general-mode kernels only (raster_general.h): the reference's func_id_dist / func_id_alpha /
+    // func_id_rgb and texture_sample_type
+    int dist_mode, alpha_mode, rgb_mode, tex_vertex;
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
 };

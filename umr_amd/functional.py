@@ -64,15 +64,18 @@ class SoftRasterizeFunction:
               pool=False, need_p2f=True):
         from . import ops  # noqa: F401  (registers torch.ops.umr.*)
         _check_raster_shapes(face_vertices, textures)
-        if _FUNC_DIST[dist_func] != 2 or _FUNC_ALPHA[aggr_func_alpha] != 2 or _FUNC_SAMPLE[texture_type] != 0:
-            raise RuntimeError("soft_rasterize: only dist_func='euclidean', aggr_func_alpha='prod', texture_type='surface' "
-                               "(the modes UMR instantiates, nnutils/smr.py:53-66) are built")
+        modes = ops.pack_modes(_FUNC_RGB[aggr_func_rgb], _FUNC_DIST[dist_func], _FUNC_ALPHA[aggr_func_alpha],
+                               _FUNC_SAMPLE[texture_type])
+        if modes > 1 and pool:
+            raise RuntimeError("soft_rasterize: the fused 2x2 pool exists for UMR's own modes only (dist_func='euclidean', "
+                               "aggr_func_alpha='prod', texture_type='surface')")
+        if _FUNC_SAMPLE[texture_type] == 1 and textures.shape[2] != 3:
+            raise RuntimeError("soft_rasterize: texture_type='vertex' needs textures [N,F,3,3]; got %s" % (tuple(textures.shape),))
         if not face_vertices.is_cuda:
             raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
         image, p2f, aggrs, _ = torch.ops.umr.soft_rasterize(
             face_vertices, textures, int(image_size), [float(c) for c in background_color], float(near), float(far),
-            bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), _FUNC_RGB[aggr_func_rgb],
-            bool(pool), bool(need_p2f))
+            bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), modes, bool(pool), bool(need_p2f))
         return image, p2f, aggrs
 
 

@@ -15,7 +15,8 @@ so the hot-path step is visible to PyTorch's graph machinery as ordinary operato
 SoftRenderer route through these ops.
 
   umr::soft_rasterize(face_vertices[N,F,3,3], textures[N/G,F,TS,3], image_size, background[3], near, far, fill_back, eps,
-                      sigma_val, dist_eps, gamma_val, rgb_mode{0 hard,1 softmax}, pool, need_p2f)
+                      sigma_val, dist_eps, gamma_val, modes (pack_modes: 0 hard / 1 soft-max colour with UMR's euclidean +
+                      prod + surface modes; the other ids of the reference binding in the upper bits), pool, need_p2f)
         -> (image [N,4,S,S] (S = image_size or image_size/2 when pool), p2f [N,F,2], aggrs_info [N,2,IS,IS],
             soft_colors [N,4,IS,IS] (saved state; == image when not pool))
   umr::soft_rasterize_backward(face_vertices, textures, soft_colors, aggrs_info, grad_image, <same scalars>,
@@ -39,16 +40,28 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-def _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode):
-    # the 12 scalars of soft_rasterize_cuda.cpp:71-82 (dist 'euclidean' = 2, alpha 'prod' = 2, surface textures = 0)
-    return (int(image_size), float(near), float(far), float(eps), float(sigma_val), 2, float(math.log(1. / dist_eps - 1.)),
-            float(gamma_val), int(rgb_mode), 2, 0, 1 if fill_back else 0)
+def pack_modes(func_id_rgb, func_id_dist=2, func_id_alpha=2, texture_sample_type=0):
+    """The four mode ids of the reference binding (functional/soft_rasterize.py:21-24) in one op argument.  Distance and
+    alpha are stored relative to UMR's own choice (euclidean = 2, prod = 2), so a plain 0 / 1 means "hard / soft-max colour
+    with UMR's modes"."""
+    return int(func_id_rgb) | ((int(func_id_dist) ^ 2) << 4) | ((int(func_id_alpha) ^ 2) << 8) | (int(texture_sample_type) << 12)
+
+
+def unpack_modes(modes):
+    return modes & 0xf, ((modes >> 4) & 0xf) ^ 2, ((modes >> 8) & 0xf) ^ 2, (modes >> 12) & 0xf   # rgb, dist, alpha, texture
+
+
+def _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes):
+    # the 12 scalars of soft_rasterize_cuda.cpp:71-82
+    rgb, dist, alpha, tex = unpack_modes(int(modes))
+    return (int(image_size), float(near), float(far), float(eps), float(sigma_val), dist, float(math.log(1. / dist_eps - 1.)),
+            float(gamma_val), rgb, alpha, tex, 1 if fill_back else 0)
 
 
 @custom_op("umr::soft_rasterize", mutates_args=(), device_types="cuda")
 def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
                       near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
-                      gamma_val: float, rgb_mode: int, pool: bool, need_p2f: bool
+                      gamma_val: float, modes: int, pool: bool, need_p2f: bool
                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     from .functional import standard_grid
     L = _lib.lib()
@@ -68,11 +81,11 @@ def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image
     soft_colors = torch.empty(N, 4, IS, IS, device=dev, dtype=torch.float32)
     bg = (ctypes.c_float * 3)(float(background[0]), float(background[1]), float(background[2]))
     pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
-    with_p2f = need_p2f and rgb_mode == 1
+    with_p2f = need_p2f and (modes & 0xf) == 1
     grid = standard_grid(IS, dev) if with_p2f else None
     ws_bytes = L.umr_raster_workspace_bytes(N, F)
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-    sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode)
+    sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
     rc = L.umr_raster_forward(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_acc[0]), ptr(p2f_acc[1]),
                               ptr(soft_colors), ptr(pooled), N, F, TS, *sc, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
                               ws_bytes, _lib.stream_ptr(dev))
@@ -84,7 +97,7 @@ def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image
 
 
 @soft_rasterize_op.register_fake
-def _(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode,
+def _(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes,
       pool, need_p2f):
     N, F = face_vertices.shape[:2]
     IS = int(image_size)
@@ -97,7 +110,7 @@ def _(face_vertices, textures, image_size, background, near, far, fill_back, eps
 def soft_rasterize_backward_op(face_vertices: torch.Tensor, textures: torch.Tensor, soft_colors: torch.Tensor,
                                aggrs_info: torch.Tensor, grad_image: torch.Tensor, image_size: int, near: float, far: float,
                                fill_back: bool, eps: float, sigma_val: float, dist_eps: float, gamma_val: float,
-                               rgb_mode: int, pool: bool, need_grad_faces: bool, need_grad_textures: bool
+                               modes: int, pool: bool, need_grad_faces: bool, need_grad_textures: bool
                                ) -> Tuple[torch.Tensor, torch.Tensor]:
     L = _lib.lib()
     fv, tex = _f32c(face_vertices), _f32c(textures)
@@ -110,7 +123,7 @@ def soft_rasterize_backward_op(face_vertices: torch.Tensor, textures: torch.Tens
     g = grad_image.to(torch.float32).contiguous()
     ws_bytes = L.umr_raster_workspace_bytes(N, F)
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-    sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode)
+    sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
     rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
                                ptr(grad_textures), ptr(g), (1 if pool else 0) | (G << 8), 1 if need_grad_faces else 0,
                                1 if need_grad_textures else 0, N, F, TS, *sc, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
@@ -123,16 +136,16 @@ def soft_rasterize_backward_op(face_vertices: torch.Tensor, textures: torch.Tens
 
 @soft_rasterize_backward_op.register_fake
 def _(face_vertices, textures, soft_colors, aggrs_info, grad_image, image_size, near, far, fill_back, eps, sigma_val,
-      dist_eps, gamma_val, rgb_mode, pool, need_grad_faces, need_grad_textures):
+      dist_eps, gamma_val, modes, pool, need_grad_faces, need_grad_textures):
     f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
     return (f(*face_vertices.shape) if need_grad_faces else f(0)), (f(*textures.shape) if need_grad_textures else f(0))
 
 
 def _raster_setup(ctx, inputs, output):
-    (fv, tex, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode, pool, need_p2f) = inputs
+    (fv, tex, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool, need_p2f) = inputs
     image, p2f, aggrs, saved = output
     ctx.save_for_backward(fv, tex, (saved if pool else image), aggrs)
-    ctx.cfg = (image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, rgb_mode, pool)
+    ctx.cfg = (image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool)
 
 
 def _raster_backward(ctx, g_image, g_p2f, g_aggrs, g_saved):
