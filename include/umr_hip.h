@@ -63,9 +63,13 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  *   pooled_out   [N,4,IS/2,IS/2] or NULL: fused 2x2 average pool of soft_colors
  *                (anti-aliasing, rasterizer.py:52-53); requires even IS            out, optional
  *
- * Supported modes (the ones nnutils/smr.py:53-66 instantiates): func_id_dist=2 (euclidean),
- * func_id_alpha=2 (prod), texture_sample_type=0 (surface), func_id_rgb in {0 hard, 1 softmax};
- * TS must be a perfect square.  Anything else returns UMR_ERR_ARG.
+ * Modes: every id the reference binding accepts (functional/soft_rasterize.py:21-24) -- func_id_dist {0 hard,
+ * 1 barycentric, 2 euclidean}, func_id_alpha {0 hard, 1 sum, 2 prod}, func_id_rgb {0 hard, 1 softmax},
+ * texture_sample_type {0 surface: TS a perfect square; 1 vertex: TS == 3, the reference reads w[j] for j < TS,
+ * soft_rasterize_cuda_kernel.cu:215}.  The combination UMR instantiates (nnutils/smr.py:53-66: euclidean, prod,
+ * surface) runs the specialised kernels; any other runs the general-mode kernels (csrc/raster_general.h), for which the
+ * fused extras (pooled_out, UMR_RASTER_ALPHA_ONLY / FACE_ID_ONLY, UMR_BWD_GRAD_POOLED / ALPHA_ONLY) are not offered.
+ * Anything else returns UMR_ERR_ARG.
  * dist_eps is the value the reference binding receives: log(1/eps_dist - 1).
  *
  * background: NULL = the reference contract above (soft_colors pre-filled by the caller).  A HOST pointer to
