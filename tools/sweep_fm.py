@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.microbench import bench, bench_alpha  # noqa: E402
 from umr_amd import _lib  # noqa: E402
 
+if os.environ.get("UMR_LIB_VARIANT"):   # a library built by tools/build_variants.py
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "variants", os.environ["UMR_LIB_VARIANT"], "libumr_hip.so")
+
 
 def timed(fn, *a, ids=(0, 1), **k):
     fn(*a, **dict(k, iters=2))                  # module load, allocator warm-up
@@ -27,6 +30,9 @@ if os.environ.get("UMR_SB") == "0":
 if os.environ.get("UMR_FO") == "0":
     _lib.debug_set("face_order", 0)
     tag += " [index-order backward]"
+if os.environ.get("UMR_XCD") == "0":
+    _lib.debug_set("xcd_remap", 0)
+    tag += " [no xcd remap]"
 if os.environ.get("UMR_FOG"):
     _lib.debug_set("face_order_group", int(os.environ["UMR_FOG"]))
     tag += " [order group %s]" % os.environ["UMR_FOG"]

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
         for (int j = lane; j < FM_TEXCOPY * FM_TEX_STRIDE(TS); j += 64) wave_tex[j] = 0.f;
     float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // TS == 1 texel gradient
+    bool visited = false;                   // wave-uniform: some sub-tile survived the culling pass
     if (live) {
         // VGPR-resident operands where the register budget of 7 waves / SIMD has room for them (silhouette and
         // texel-gradient-only variants: 56-60 VGPRs with them; the full variant would spill)
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
 #endif
                 }
                 unsigned long long tm = __ballot(want);
+                visited |= tm != 0;
                 while (tm) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
                     int mine = -1;
@@ -555,6 +557,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
             }
         }
     }
+#ifndef FM_SKIP_EMPTY
+#define FM_SKIP_EMPTY 1   // a face none of whose sub-tiles survived the culling pass (half the mesh under a texel-gradient
+#endif                    // launch) adds exact zeros: skip its lane reductions, LDS read-out and read-modify-write stores
+    if (FM_SKIP_EMPTY && FM_WAVES == 1 && !visited) return;
     if (NEED_GF) {
         float mine = 0.f;
 #pragma unroll

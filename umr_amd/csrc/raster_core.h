@@ -61,6 +61,7 @@ struct RasterArgs {
     // read by the general-mode kernels only (raster_general.h): the reference's func_id_dist / func_id_alpha /
     // func_id_rgb and texture_sample_type
     int dist_mode, alpha_mode, rgb_mode, tex_vertex;
+    int no_xcd_remap;   // A/B switch (umr_debug_set("xcd_remap", 0)): pixel-major work items in plain blockIdx order
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
 };
@@ -364,7 +365,7 @@ struct Tile {
 
 __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     const int total = A.N * A.tiles_x * A.tiles_y;
-    int wid = xcd_remap(blockIdx.x, total);
+    int wid = A.no_xcd_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, total);
     const int bx = wid % A.tiles_x; wid /= A.tiles_x;
     const int by = wid % A.tiles_y;
     t.n = wid / A.tiles_y;
