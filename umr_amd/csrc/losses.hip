@@ -460,61 +460,67 @@ __device__ __forceinline__ void up2_taps(int o, int n, int &i0, int &i1, float &
     w1 = src - (float)i0;
 }
 
-__global__ void k_upsample2x_fwd(const float *__restrict__ in, float *__restrict__ out, long planes, int H, int W) {
-    const int OW = 2 * W, OH = 2 * H;
-    const long total = planes * OH * OW;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
-        const long p = i / ((long)OW * OH);
-        int x0, x1, y0, y1; float wx, wy;
-        up2_taps(ox, W, x0, x1, wx);
-        up2_taps(oy, H, y0, y1, wy);
-        const float *s = in + p * H * W;
-        const float a = s[(long)y0 * W + x0], b = s[(long)y0 * W + x1], c = s[(long)y1 * W + x0], d = s[(long)y1 * W + x1];
-        out[i] = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
-    }
+// grid (ceil(OH * OW / 256), planes): 32-bit index arithmetic, one udiv (a shift when the width is a power of two).  The
+// first version used one flat 64-bit index -- two 64-bit div/mod pairs per element, ~300 instructions around 4 loads.
+__global__ void k_upsample2x_fwd(const float *__restrict__ in, float *__restrict__ out, int H, int W, int wshift) {
+    const unsigned OW = 2u * W, OH = 2u * H;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OW * OH) return;
+    const unsigned oy = wshift >= 0 ? i >> wshift : i / OW, ox = i - oy * OW;
+    int x0, x1, y0, y1; float wx, wy;
+    up2_taps((int)ox, W, x0, x1, wx);
+    up2_taps((int)oy, H, y0, y1, wy);
+    const float *s = in + (size_t)blockIdx.y * H * W;
+    const float a = s[y0 * W + x0], b = s[y0 * W + x1], c = s[y1 * W + x0], d = s[y1 * W + x1];
+    out[(size_t)blockIdx.y * OH * OW + i] = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
 }
 
 // gather form of the transpose: every input pixel sums its (<= 4x4) output contributions -> deterministic, no atomics
-__global__ void k_upsample2x_bwd(const float *__restrict__ gout, float *__restrict__ gin, long planes, int H, int W) {
+__global__ void k_upsample2x_bwd(const float *__restrict__ gout, float *__restrict__ gin, int H, int W, int wshift) {
     const int OW = 2 * W, OH = 2 * H;
-    const long total = planes * H * W;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        const long p = i / ((long)W * H);
-        const float *g = gout + p * OH * OW;
-        float acc = 0.f;
-        for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, OH - 1); ++oy) {
-            int y0, y1; float wy;
-            up2_taps(oy, H, y0, y1, wy);
-            const float cy = (y0 == y ? 1.f - wy : 0.f) + (y1 == y ? wy : 0.f);
-            if (cy == 0.f) continue;
-            for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, OW - 1); ++ox) {
-                int x0, x1; float wx;
-                up2_taps(ox, W, x0, x1, wx);
-                const float cx = (x0 == x ? 1.f - wx : 0.f) + (x1 == x ? wx : 0.f);
-                acc += cy * cx * g[(long)oy * OW + ox];
-            }
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)(W * H)) return;
+    const int y = wshift >= 0 ? (int)(i >> wshift) : (int)(i / (unsigned)W), x = (int)i - y * W;
+    const float *g = gout + (size_t)blockIdx.y * OH * OW;
+    float acc = 0.f;
+    for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, OH - 1); ++oy) {
+        int y0, y1; float wy;
+        up2_taps(oy, H, y0, y1, wy);
+        const float cy = (y0 == y ? 1.f - wy : 0.f) + (y1 == y ? wy : 0.f);
+        if (cy == 0.f) continue;
+        for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, OW - 1); ++ox) {
+            int x0, x1; float wx;
+            up2_taps(ox, W, x0, x1, wx);
+            const float cx = (x0 == x ? 1.f - wx : 0.f) + (x1 == x ? wx : 0.f);
+            acc += cy * cx * g[oy * OW + ox];
         }
-        gin[i] = acc;
     }
+    gin[(size_t)blockIdx.y * H * W + i] = acc;
 }
 }  // namespace
 
 extern "C" {
+static int pow2_shift(int v) { return (v > 0 && (v & (v - 1)) == 0) ? __builtin_ctz(v) : -1; }
+
 int umr_upsample2x_bilinear_forward(const float *in, float *out, long planes, int H, int W, void *stream) {
-    if (!in || !out || planes <= 0 || H <= 0 || W <= 0) return UMR_ERR_ARG;
-    const long total = planes * 4L * H * W;
-    const int blocks = (int)min((long)8192, (total + 255) / 256);
-    k_upsample2x_fwd<<<blocks, 256, 0, (hipStream_t)stream>>>(in, out, planes, H, W);
+    if (!in || !out || planes <= 0 || H <= 0 || W <= 0 || (long)H * W > (1L << 27)) return UMR_ERR_ARG;
+    const unsigned per = 4u * H * W;
+    for (long p0 = 0; p0 < planes; p0 += 65535) {          // grid.y limit
+        const long np = planes - p0 < 65535 ? planes - p0 : 65535;
+        k_upsample2x_fwd<<<dim3((per + 255) / 256, (unsigned)np), 256, 0, (hipStream_t)stream>>>(
+            in + (size_t)p0 * H * W, out + (size_t)p0 * per, H, W, pow2_shift(2 * W));
+    }
     return umr_launch_status();
 }
 
 int umr_upsample2x_bilinear_backward(const float *grad_out, float *grad_in, long planes, int H, int W, void *stream) {
-    if (!grad_out || !grad_in || planes <= 0 || H <= 0 || W <= 0) return UMR_ERR_ARG;
-    const long total = planes * (long)H * W;
-    const int blocks = (int)min((long)8192, (total + 255) / 256);
-    k_upsample2x_bwd<<<blocks, 256, 0, (hipStream_t)stream>>>(grad_out, grad_in, planes, H, W);
+    if (!grad_out || !grad_in || planes <= 0 || H <= 0 || W <= 0 || (long)H * W > (1L << 27)) return UMR_ERR_ARG;
+    const unsigned per = (unsigned)H * W;
+    for (long p0 = 0; p0 < planes; p0 += 65535) {
+        const long np = planes - p0 < 65535 ? planes - p0 : 65535;
+        k_upsample2x_bwd<<<dim3((per + 255) / 256, (unsigned)np), 256, 0, (hipStream_t)stream>>>(
+            grad_out + (size_t)p0 * 4 * per, grad_in + (size_t)p0 * per, H, W, pow2_shift(W));
+    }
     return umr_launch_status();
 }
 }

@@ -12,7 +12,7 @@ namespace {
 constexpr int COS_MAX_TAPS = UMR_COS_MAX_TAPS;
 
 struct CosTapDev { const float *f0, *f1; float *g0, *g1; float *stats; int C, P; };
-struct CosArgs { CosTapDev tap[COS_MAX_TAPS]; int ntaps, N, chunks; float eps; };
+struct CosArgs { CosTapDev tap[COS_MAX_TAPS]; int ntaps, N, chunks; float eps; int bwd_start[COS_MAX_TAPS + 1]; };
 
 // Forward: a 256-thread block owns 64 consecutive pixels of sample n, tap t; lane = pixel (the channel loop reads
 // f[n, c, p]: consecutive lanes consecutive p = coalesced 256-byte rows), wave w = channels w, w+4, w+8, ... so that the
@@ -79,13 +79,21 @@ __global__ void k_cos_finalize(const CosArgs A, const float *__restrict__ partia
 // d val[n] / d f1[c] at pixel p = -(1/P) [ f0[c] i0 i1 - s01 i0 i1^2 f1[c] / r1 ],  i = 1 / (r + eps)  (and symmetrically
 // for f0).  A zero feature vector (r = 0) gets the derivative of its norm defined as 0: torch's sqrt backward gives
 // 0 * inf = NaN there -- a defined deviation, listed in oracle/README.md.
-// Pure element-wise map over [C, P] with three per-pixel coefficients: one thread per (channel group, pixel), lane = pixel.
+// Pure element-wise map over [C, P] with three per-pixel coefficients.  A block owns 64 pixels x COS_BWD_CH channels of
+// (sample, tap): lane = pixel (coalesced 256-byte rows), wave w = channels w, w+4, ... of the block's channel slab, all of
+// a wave's loads issued before the first use.  (One block per 64 pixels looping over ALL channels -- 96 dependent
+// load/store rounds for the 384-channel tap on 4 x N blocks -- ran 94 us per B = 16 step against ~30 us of HBM time.)
+constexpr int COS_BWD_CH = 32;
 __global__ __launch_bounds__(256) void k_cos_backward(const CosArgs A, const float *__restrict__ gval) {
-    const int t = blockIdx.z, n = blockIdx.y;
+    const int n = blockIdx.y;
+    int t = 0;                                                      // blocks of all taps are laid out back to back
+    while (t + 1 < A.ntaps && (int)blockIdx.x >= A.bwd_start[t + 1]) ++t;
     const CosTapDev T = A.tap[t];
     const int C = T.C, P = T.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+    const int pchunks = (P + 63) / 64, local = (int)blockIdx.x - A.bwd_start[t];
+    const int p = (local % pchunks) * 64 + lane;
+    const int c0 = (local / pchunks) * COS_BWD_CH;
     if (p >= P) return;
     const float g = -gval[n] / (float)P;
     const float *st = T.stats + ((size_t)n * P + p) * 3;
@@ -96,10 +104,21 @@ __global__ __launch_bounds__(256) void k_cos_backward(const CosArgs A, const flo
     const size_t base = (size_t)n * C * P + p;
     const float *a = T.f0 + base, *b = T.f1 + base;
     float *g0 = T.g0 ? T.g0 + base : nullptr, *g1 = T.g1 ? T.g1 + base : nullptr;
-    for (int c = wave; c < C; c += 4) {
-        const float x = a[(size_t)c * P], y = b[(size_t)c * P];
-        if (g0) g0[(size_t)c * P] = k * (y - m0 * x);
-        if (g1) g1[(size_t)c * P] = k * (x - m1 * y);
+    constexpr int PER = COS_BWD_CH / 4;
+    float x[PER], y[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = c0 + wave + 4 * j;
+        x[j] = c < C ? a[(size_t)c * P] : 0.f;
+        y[j] = c < C ? b[(size_t)c * P] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = c0 + wave + 4 * j;
+        if (c < C) {
+            if (g0) g0[(size_t)c * P] = k * (y[j] - m0 * x[j]);
+            if (g1) g1[(size_t)c * P] = k * (x[j] - m1 * y[j]);
+        }
     }
 }
 
@@ -405,7 +424,10 @@ int umr_cos_sim_backward(int ntaps, const float *const *f0, const float *const *
     int maxp = 0;
     for (int t = 0; t < ntaps; ++t) maxp = P[t] > maxp ? P[t] : maxp;
     if ((maxp + 63) / 64 > UMR_COS_CHUNKS) return UMR_ERR_ARG;
-    k_cos_backward<<<dim3((maxp + 63) / 64, N, ntaps), 256, 0, (hipStream_t)stream>>>(A, grad_val);
+    A.bwd_start[0] = 0;
+    for (int t = 0; t < ntaps; ++t)
+        A.bwd_start[t + 1] = A.bwd_start[t] + ((P[t] + 63) / 64) * ((C[t] + COS_BWD_CH - 1) / COS_BWD_CH);
+    k_cos_backward<<<dim3(A.bwd_start[ntaps], N), 256, 0, (hipStream_t)stream>>>(A, grad_val);
     return umr_launch_status();
 }
 

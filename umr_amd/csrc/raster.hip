@@ -175,7 +175,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     A.no_xcd_remap = g_xcd_remap ? 0 : 1;
     const int total = N * F;
-    k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
+    k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold), near_, far_);
     setup_bins(A, workspace, N, F, image_size, st);
     const int blocks = N * A.tiles_x * A.tiles_y;
@@ -250,7 +250,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     const int total = N * F;
-    k_face_setup<<<(total + 255) / 256, 256, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
+    k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
     const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
