@@ -207,10 +207,13 @@ def main():
             step_fn()
         barrier()
         t0 = time.perf_counter()
+        history = []
         for _ in range(args.steps):
             loss = step_fn()
+            history.append(loss)                # device scalars, read only if the run has to be discarded
         host_dt = time.perf_counter() - t0      # time to ENQUEUE the steps (host side); dt below includes the drain
         barrier()
+        measure.history = history
         return loss, host_dt, time.perf_counter() - t0
 
     # Training on synthetic (random) images is chaotic -- float-atomic summation order alone changes the trajectory -- and
@@ -232,6 +235,10 @@ def main():
         if bool(ok.item()) or discarded >= 2 or not use_model:
             break
         discarded += 1
+        if rank == 0:     # what the discarded trajectory looked like (stderr: the JSON line on stdout stays alone)
+            hist = [float(x) for x in torch.stack([h.detach().reshape(()) for h in measure.history]).tolist()]
+            sys.stderr.write("bench.py: measurement %d discarded, loss per timed step: %s\n"
+                             % (discarded, " ".join("%.4g" % v for v in hist)))
         torch.manual_seed(4321 + 17 * discarded + rank)
         step_fn = build_step()
     if args.graph and not use_model and world == 1:

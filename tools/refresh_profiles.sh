@@ -12,7 +12,14 @@ python bench.py --model 0 --cpu-baseline 0 --graph 1 > "$O/bench_hotpath_graph.j
 python bench.py --workload s2 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
 # the SAME command as the bench line above (default warm-up / steps / profile pass, CPU leg off): the library's HIP events
 # bracket the raster kernels of the last 5 steps (the profile pass), so rocprofv3's last 5 dispatches are the same steps
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o t -- python "$R/bench.py" --cpu-baseline 0 > "$O/stats.log" 2>&1)
+# (training on random images is chaotic; about one run in 25 diverges and bench.py then repeats the measurement on a fresh
+# model -- a profile that contains such a discarded run is thrown away and taken again)
+for attempt in 1 2 3; do
+  rm -rf "$O/stats"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o t -- python "$R/bench.py" --cpu-baseline 0 > "$O/stats.log" 2>&1)
+  grep -q '"discarded_nonfinite_runs": 0' "$O/stats.log" && break
+  echo "stats run $attempt contained a discarded (diverged) measurement; repeating" >> "$O/stats_retries.log"
+done
 tools/collect_traffic.sh "$O/traffic" > "$O/traffic.log" 2>&1
 (hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_ubench.hip -o /tmp/valu_ubench && timeout 150 /tmp/valu_ubench) > "$O/valu_ubench.log" 2>&1
 python tools/microbench.py > "$O/microbench.log" 2>&1

@@ -37,7 +37,9 @@ size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 
 size_t ws_rec_bytes(int N, int F) { return (size_t)N * F * REC * sizeof(float); }
 size_t ws_sbcount_bytes(int N) { return (((size_t)N * SB_SLOTS * sizeof(int)) + 255) & ~(size_t)255; }
 size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * F * sizeof(int); }
-size_t ws_order_bytes(int N, int F) { return (size_t)(N + 15) * F * sizeof(int); }   // whole groups of <= 16 meshes
+size_t ws_order_bytes(int N, int F) {   // start order in whole groups of <= 16 meshes + the per-face work estimates
+    return (size_t)(N + 15) * F * sizeof(int) + (((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255);
+}
 bool g_xcd_remap = true;         // umr_debug_set("xcd_remap", 0): pixel-major kernels take work items in blockIdx order (A/B:
                                  // forward 12-25 % slower -- one mesh's records then live in all eight L2s)
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
@@ -250,8 +252,6 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     const int total = N * F;
-    k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
-                                                      sqrtf(A.threshold), near_, far_);
     const int blocks = N * A.tiles_x * A.tiles_y;
     const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
     const bool face_major = !general && (alpha_only || !(g_bwd_pixel_major || !lds_ok));
@@ -261,13 +261,16 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     // faces in flight an XCD's 4 MB L2 no longer holds their state); silhouette unchanged.  So: texel-only variant only,
     // one group when the launch has <= 16 meshes, groups of 8 otherwise.
     const int order_mode = alpha_only ? 2 : ((!need_grad_faces && func_id_rgb == 1) ? 1 : 0);
-    if (face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 && F % 8 == 0 &&
-        F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES) {
-        int *order = (int *)((char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) +
-                             ws_sblist_bytes(N, F));
+    const bool ordered = face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 &&
+                         F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
+    int *order = (int *)((char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F));
+    unsigned short *cost = (unsigned short *)(order + (size_t)(N + 15) * F);
+    k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
+                                                   sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size);
+    if (ordered) {
         int G = std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / (F / 8)));
         if (g_face_order_group) G = std::min(G, g_face_order_group);
-        k_face_order<<<dim3(8, (N + G - 1) / G), 256, 0, st>>>(A.bbox, A.rec, soft_colors, order, N, F, image_size, G, order_mode);
+        k_face_order<<<dim3(8, (N + G - 1) / G), ORDER_THREADS, 0, st>>>(cost, A.rec, soft_colors, order, N, F, image_size, G, order_mode);
         A.order = order; A.order_group = G;
     }
     {

@@ -142,52 +142,46 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // The order changes no result (every face is still reduced by one wave in its own fixed order).
 #define ORDER_KEYS 1024
 #define ORDER_MAX_ENTRIES 16384
-__global__ __launch_bounds__(256) void k_face_order(const float4 *__restrict__ bbox, const float *__restrict__ rec,
-                                                    const float *__restrict__ alpha, int *__restrict__ order, int N, int F,
-                                                    int IS, int G, int mode) {
+#define ORDER_THREADS 1024
+__global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned short *__restrict__ cost, const float *__restrict__ rec,
+                                                              const float *__restrict__ alpha, int *__restrict__ order, int N,
+                                                              int F, int IS, int G, int mode) {
     __shared__ int s_hist[ORDER_KEYS];
-    __shared__ int s_wsum[4];
+    __shared__ int s_wsum[ORDER_THREADS / 64];
     __shared__ unsigned short s_key[ORDER_MAX_ENTRIES];
     const int xcd = blockIdx.x, g = blockIdx.y, per = F >> 3;
     const int m0 = g * G, gl = min(G, N - m0), E = gl * per;
-    for (int k = threadIdx.x; k < ORDER_KEYS; k += 256) s_hist[k] = 0;
+    for (int k = threadIdx.x; k < ORDER_KEYS; k += ORDER_THREADS) s_hist[k] = 0;
     __syncthreads();
     const float h = 0.5f * IS;
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
         const int ml = e / per, f = xcd * per + e % per;
         const size_t fi = (size_t)(m0 + ml) * F + f;
-        const float4 bb = bbox[fi];
-        int key = ORDER_KEYS - 1;                                    // NaN bounds: the wave walks the whole image
-        if (bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w) {
-            const int x0 = max((int)floorf(bb.x * h + h - 0.5f) - 1, 0), x1 = min((int)ceilf(bb.y * h + h - 0.5f) + 1, IS - 1);
-            const int y0 = max((int)floorf(bb.z * h + h - 0.5f) - 1, 0), y1 = min((int)ceilf(bb.w * h + h - 0.5f) + 1, IS - 1);
-            int nt = 0;
-            if (x0 <= x1 && y0 <= y1) nt = ((x1 >> 2) - (x0 >> 2) + 1) * ((y1 >> 2) - (y0 >> 2) + 1);
+        const unsigned c = cost[fi];                       // k_face_setup: sub-tiles under the bbox | front << 15
+        int nt = (int)(c & 0x7fffu);
+        if (mode == 1 && !(c & 0x8000u)) nt >>= 3;
+        if (mode == 2 && nt > 0) {
             const float *r = rec + fi * REC;
-            if (mode == 1 && r[R_FRONT] == 0.f) nt >>= 3;
-            if (mode == 2 && nt > 0) {
-                const float *ap = alpha + (size_t)(m0 + ml) * IS * IS;
-                const float cx[4] = {r[R_X0], r[R_X1], r[R_X2], (r[R_X0] + r[R_X1] + r[R_X2]) * (1.f / 3.f)};
-                const float cy[4] = {r[R_Y0], r[R_Y1], r[R_Y2], (r[R_Y0] + r[R_Y1] + r[R_Y2]) * (1.f / 3.f)};
-                bool opaque = true;
+            const float *ap = alpha + (size_t)(m0 + ml) * IS * IS;
+            const float cx[4] = {r[R_X0], r[R_X1], r[R_X2], (r[R_X0] + r[R_X1] + r[R_X2]) * (1.f / 3.f)};
+            const float cy[4] = {r[R_Y0], r[R_Y1], r[R_Y2], (r[R_Y0] + r[R_Y1] + r[R_Y2]) * (1.f / 3.f)};
+            bool opaque = true;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int xi = min(max((int)(cx[c] * h + h), 0), IS - 1), yi = min(max((int)(cy[c] * h + h), 0), IS - 1);
-                    opaque &= ap[(size_t)(IS - 1 - yi) * IS + xi] == 1.f;
-                }
-                if (opaque) nt >>= 3;
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int xi = min(max((int)(cx[c4] * h + h), 0), IS - 1), yi = min(max((int)(cy[c4] * h + h), 0), IS - 1);
+                opaque &= ap[(size_t)(IS - 1 - yi) * IS + xi] == 1.f;
             }
-            key = min(nt, ORDER_KEYS - 1);
+            if (opaque) nt >>= 3;
         }
+        const int key = min(nt, ORDER_KEYS - 1);
         s_key[e] = (unsigned short)key;
         atomicAdd(&s_hist[key], 1);
     }
     __syncthreads();
-    // exclusive prefix over DESCENDING keys: thread t owns keys 1023 - 4t .. 1020 - 4t
+    // exclusive prefix over DESCENDING keys: thread t owns key 1023 - t
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kb = ORDER_KEYS - 1 - 4 * (int)threadIdx.x;
-    const int c0 = s_hist[kb], c1 = s_hist[kb - 1], c2 = s_hist[kb - 2], c3 = s_hist[kb - 3];
-    const int mine = c0 + c1 + c2 + c3;
+    const int kb = ORDER_KEYS - 1 - (int)threadIdx.x;
+    const int mine = s_hist[kb];
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -199,10 +193,10 @@ __global__ __launch_bounds__(256) void k_face_order(const float4 *__restrict__ b
     int base = incl - mine;
     for (int w = 0; w < wave; ++w) base += s_wsum[w];
     __syncthreads();
-    s_hist[kb] = base; s_hist[kb - 1] = base + c0; s_hist[kb - 2] = base + c0 + c1; s_hist[kb - 3] = base + c0 + c1 + c2;
+    s_hist[kb] = base;
     __syncthreads();
     int *out = order + ((size_t)g * 8 + xcd) * ((size_t)G * per);
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
         const int pos = atomicAdd(&s_hist[s_key[e]], 1);
         out[pos] = ((e / per) << 16) | (xcd * per + e % per);
     }

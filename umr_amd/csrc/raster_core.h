@@ -69,7 +69,7 @@ struct RasterArgs {
 // ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
 __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
                              float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
-                             float near_, float far_) {
+                             float near_, float far_, unsigned short *__restrict__ cost = nullptr, int IS = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float *f = faces + (size_t)i * 9;
@@ -103,6 +103,21 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     const float xlo = fminf(fminf(x0, x1), x2) - thr, xhi = fmaxf(fmaxf(x0, x1), x2) + thr;
     const float ylo = fminf(fminf(y0, y1), y2) - thr, yhi = fmaxf(fmaxf(y0, y1), y2) + thr;
     bbox[i] = make_float4(xlo, xhi, ylo, yhi);
+    if (cost) {
+        // work estimate for the face-major backward's start order (k_face_order): 4x4 sub-tiles under the dilated bbox
+        // (the window of raster_backward.h), bit 15 = front-facing.  NaN bounds: the wave walks the whole image.
+        int key = 1023;
+        if (xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) {
+            const float h = 0.5f * IS;
+            const int px0 = max((int)floorf(xlo * h + h - 0.5f) - 1, 0), px1 = min((int)ceilf(xhi * h + h - 0.5f) + 1, IS - 1);
+            const int py0 = max((int)floorf(ylo * h + h - 0.5f) - 1, 0), py1 = min((int)ceilf(yhi * h + h - 0.5f) + 1, IS - 1);
+            int nt = 0;
+            if (px0 <= px1 && py0 <= py1) nt = ((px1 >> 2) - (px0 >> 2) + 1) * ((py1 >> 2) - (py0 >> 2) + 1);
+            key = min(nt, 1023);
+        }
+        const bool front = (y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0);
+        cost[i] = (unsigned short)(key | (front ? 0x8000 : 0));
+    }
     // ---- packed record: three 64-byte lines, fetched by the raster kernels with 3 x s_load_dwordx16 ----
     float *r = rec + (size_t)i * REC;
     r[R_XLO] = xlo; r[R_XHI] = xhi; r[R_YLO] = ylo; r[R_YHI] = yhi;
