@@ -30,9 +30,9 @@ if os.environ.get("UMR_SB") == "0":
 if os.environ.get("UMR_FO") == "0":
     _lib.debug_set("face_order", 0)
     tag += " [index-order backward]"
-if os.environ.get("UMR_XCD") == "0":
-    _lib.debug_set("xcd_remap", 0)
-    tag += " [no xcd remap]"
+if os.environ.get("UMR_XCD"):
+    _lib.debug_set("xcd_remap", int(os.environ["UMR_XCD"]))
+    tag += " [xcd_remap %s]" % os.environ["UMR_XCD"]
 if os.environ.get("UMR_FOG"):
     _lib.debug_set("face_order_group", int(os.environ["UMR_FOG"]))
     tag += " [order group %s]" % os.environ["UMR_FOG"]

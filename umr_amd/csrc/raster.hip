@@ -40,8 +40,10 @@ size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * F * sizeof(
 size_t ws_order_bytes(int N, int F) {   // start order in whole groups of <= 16 meshes + the per-face work estimates
     return (size_t)(N + 15) * F * sizeof(int) + (((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255);
 }
-bool g_xcd_remap = true;         // umr_debug_set("xcd_remap", 0): pixel-major kernels take work items in blockIdx order (A/B:
-                                 // forward 12-25 % slower -- one mesh's records then live in all eight L2s)
+int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping of the pixel-major kernels.  2 (default): XCD x takes
+                                 // block rows x, x + 8, ... of every mesh; 1: each XCD a contiguous run of (mesh, block) items
+                                 // (forward 3-7 % slower than 2 at N = 16: two whole meshes per XCD balance worse); 0: plain
+                                 // blockIdx order (12-25 % slower: one mesh's records then live in all eight L2s)
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
 int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts its waves in index order,
                                  // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
@@ -100,7 +102,7 @@ int umr_debug_set(const char *key, int value) {
     if (!key) return UMR_ERR_ARG;
     if (std::string(key) == "bwd_pixel_major") { g_bwd_pixel_major = value != 0; return UMR_OK; }
     if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
-    if (std::string(key) == "xcd_remap") { g_xcd_remap = value != 0; return UMR_OK; }
+    if (std::string(key) == "xcd_remap") { g_xcd_remap = value; return UMR_OK; }   // 0 off, 1 contiguous runs, 2 row-interleaved
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
     return UMR_ERR_ARG;
@@ -175,7 +177,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
     if (background) { A.bg_arg = 1; A.bg0 = background[0]; A.bg1 = background[1]; A.bg2 = background[2]; }
     A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
-    A.no_xcd_remap = g_xcd_remap ? 0 : 1;
+    A.no_xcd_remap = g_xcd_remap == 1 ? 0 : (g_xcd_remap == 0 ? 1 : 2);
     const int total = N * F;
     k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
                                                       sqrtf(A.threshold), near_, far_);

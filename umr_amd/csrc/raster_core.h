@@ -380,10 +380,22 @@ struct Tile {
 
 __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     const int total = A.N * A.tiles_x * A.tiles_y;
-    int wid = A.no_xcd_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, total);
-    const int bx = wid % A.tiles_x; wid /= A.tiles_x;
-    const int by = wid % A.tiles_y;
-    t.n = wid / A.tiles_y;
+    int bx, by;
+    if (A.no_xcd_remap == 2 && A.tiles_y % 8 == 0) {
+        // XCD x (= blockIdx % 8) takes block rows x, x + 8, x + 16, ... of EVERY mesh: the dense middle rows of each mesh are
+        // spread over all eight XCDs (balance at small N) while horizontally adjacent blocks -- which share most of their
+        // faces' records -- stay in one L2
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_mesh = (A.tiles_y >> 3) * A.tiles_x;
+        t.n = slot / per_mesh;
+        const int rem = slot - t.n * per_mesh;
+        by = (rem / A.tiles_x) * 8 + xcd;
+        bx = rem % A.tiles_x;
+    } else {
+        int wid = A.no_xcd_remap ? (int)blockIdx.x : xcd_remap(blockIdx.x, total);
+        bx = wid % A.tiles_x; wid /= A.tiles_x;
+        by = wid % A.tiles_y;
+        t.n = wid / A.tiles_y;
+    }
     t.lane = threadIdx.x & 63;
     t.wave = threadIdx.x >> 6;
     t.bx0 = bx * BLK_W; t.by0 = by * BLK_H;
