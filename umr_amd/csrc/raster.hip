@@ -269,10 +269,12 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     unsigned short *cost = (unsigned short *)(order + (size_t)(N + 15) * F);
     k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                    sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size);
+    // light variants at small N: four runs of faces per XCD instead of one (fm_owned_face)
+    A.fm_split = (face_major && N <= 16 && (alpha_only || !need_grad_faces) && F % 32 == 0) ? 4 : 1;
     if (ordered) {
         int G = std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / (F / 8)));
         if (g_face_order_group) G = std::min(G, g_face_order_group);
-        k_face_order<<<dim3(8, (N + G - 1) / G), ORDER_THREADS, 0, st>>>(cost, A.rec, soft_colors, order, N, F, image_size, G, order_mode);
+        k_face_order<<<dim3(8, (N + G - 1) / G), ORDER_THREADS, 0, st>>>(cost, A.rec, soft_colors, order, N, F, image_size, G, order_mode, A.fm_split);
         A.order = order; A.order_group = G;
     }
     {

@@ -140,12 +140,25 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // drains on cheap ones.  Work estimate: 4x4 sub-tiles under the dilated bbox; / 8 for faces the state cull will remove --
 // mode 1 (texel gradients only): back faces; mode 2 (silhouette): faces whose corners and centroid all sit on alpha == 1.
 // The order changes no result (every face is still reduced by one wave in its own fixed order).
+// Face ownership of the face-major backward: XCD `xcd` owns, of every mesh, `split` contiguous runs of per / split faces
+// (run q of XCD x = chunk q * 8 + x of the mesh's 8 * split chunks); j = 0 .. per-1 enumerates them.  Contiguous index runs
+// are spatial patches of a subdivided mesh, so the saved state an XCD's waves re-read stays in its L2; but with one run
+// per XCD whole patches are front- or back-facing and the XCDs' loads differ 0.3x .. 1.8x per mesh.  Measured (N = 16,
+// split 1 -> 4): texel gradients only 122.9 -> 119.0 us, silhouette 77.7 -> 74.1 us, vertex + texel gradients 204 -> 228 us
+// (28 B of state per pixel: locality wins); no gain at N = 128.  raster.hip picks 4 for the two light variants at N <= 16.
+__device__ __forceinline__ int fm_owned_face(int xcd, int j, int per, int split) {
+    if (split > 1) {
+        const int c = per / split, q = j / c;
+        return (q * 8 + xcd) * c + (j - q * c);
+    }
+    return xcd * per + j;
+}
 #define ORDER_KEYS 1024
 #define ORDER_MAX_ENTRIES 16384
 #define ORDER_THREADS 1024
 __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned short *__restrict__ cost, const float *__restrict__ rec,
                                                               const float *__restrict__ alpha, int *__restrict__ order, int N,
-                                                              int F, int IS, int G, int mode) {
+                                                              int F, int IS, int G, int mode, int split) {
     __shared__ int s_hist[ORDER_KEYS];
     __shared__ int s_wsum[ORDER_THREADS / 64];
     __shared__ unsigned short s_key[ORDER_MAX_ENTRIES];
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
     __syncthreads();
     const float h = 0.5f * IS;
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
-        const int ml = e / per, f = xcd * per + e % per;
+        const int ml = e / per, f = fm_owned_face(xcd, e % per, per, split);
         const size_t fi = (size_t)(m0 + ml) * F + f;
         const unsigned c = cost[fi];                       // k_face_setup: sub-tiles under the bbox | front << 15
         int nt = (int)(c & 0x7fffu);
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
     int *out = order + ((size_t)g * 8 + xcd) * ((size_t)G * per);
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
         const int pos = atomicAdd(&s_hist[s_key[e]], 1);
-        out[pos] = ((e / per) << 16) | (xcd * per + e % per);
+        out[pos] = ((e / per) << 16) | fm_owned_face(xcd, e % per, per, split);
     }
 }
 
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
     if (fblocks % 8 == 0 && (A.N * fblocks) % 8 == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = fblocks >> 3;
         nb = slot / per;
-        fb = xcd * per + slot % per;
+        fb = __builtin_amdgcn_readfirstlane(fm_owned_face(xcd, slot % per, per, A.fm_split));   // (uniform; the division hides it)
     }
     int fidx = fb * FM_WAVES + wave;
     if (FM_WAVES == 1 && A.order) {   // cost-ordered start (k_face_order): same XCD ownership, heavy faces first

@@ -57,6 +57,7 @@ struct RasterArgs {
     // (mesh - g * order_group) << 16 | face for the i-th wave XCD `xcd` starts within mesh group g; NULL = index order.
     const int *order;
     int order_group;
+    int fm_split;      // runs of faces per XCD and mesh in the face-major backward (fm_owned_face); 0 / 1 = one
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
     // read by the general-mode kernels only (raster_general.h): the reference's func_id_dist / func_id_alpha /
     // func_id_rgb and texture_sample_type
