@@ -96,12 +96,23 @@ if os.path.exists(tsum):
     kk = [k for k in tj if "k_raster_backward_fm<1, false, true" in k]
     if kk:
         L.append("HIP-event average (profile pass = steps 41-45 of the un-profiled bench run) vs rocprofv3 over the same five "
-                 "steps of the profiled run of the same command for `%s`: %.1f us vs %.1f us (%.1f us over all 45 steps: the "
-                 "network's meshes grow on screen as it trains, so the kernel's duration depends on the step index); "
-                 "`profiles/%s_raster_trace_summary.json`.  The two are different processes: training on synthetic images is "
-                 "chaotic (float-atomic summation order), so the meshes of step 41-45 are not identical between runs.\n"
+                 "steps of the profiled run of the same command for `%s`: %.1f us vs %.1f us (%.1f us over all 45 steps); "
+                 "`profiles/%s_raster_trace_summary.json`.  The two are different processes on different trajectories "
+                 "(training on synthetic images is chaotic: float-atomic summation order), and un-profiled the fp32 MIOpen "
+                 "network keeps the GPU busy back to back, while the profiler slows the host down and leaves it idle between "
+                 "launches -- these VALU-bound kernels follow the clock.\n"
                  % (kk[0].split("(")[0], rf["avg_us"], tj[kk[0]].get("avg_us_profile_pass", tj[kk[0]].get("avg_us_last10steps", 0.0)),
                     tj[kk[0]]["avg_us_all"], tag))
+        hs = os.path.join(SRC, "raster_hot_stats.json")
+        if os.path.exists(hs):
+            shutil.copyfile(hs, os.path.join(P, tag + "_raster_hot_stats.json"))
+            hj = json.load(open(hs))
+            hk = [k for k in hj if "k_raster_backward_fm<1, false, true" in k]
+            if hk:
+                L.append("Where both see the same work -- the hot path alone (`--model 0`: the same scene every step) -- they "
+                         "agree: HIP events %.1f us (`profiles/%s_bench_hotpath_only.json`) vs rocprofv3 %.1f us over %d "
+                         "dispatches (`profiles/%s_raster_hot_stats.json`).\n"
+                         % (hot["roofline"]["avg_us"], tag, hj[hk[0]]["avg_us"], hj[hk[0]]["calls"], tag))
 elif bk:
     L.append("HIP-event average vs rocprofv3 average for `k_raster_backward_fm<1, false, true, ...>`: %.1f us vs %.1f us.\n"
              % (rf["avg_us"], float(bk[0]["AverageNs"]) / 1e3))

@@ -20,6 +20,10 @@ for attempt in 1 2 3; do
   grep -q '"discarded_nonfinite_runs": 0' "$O/stats.log" && break
   echo "stats run $attempt contained a discarded (diverged) measurement; repeating" >> "$O/stats_retries.log"
 done
+# the hot path alone under the profiler as well: every step renders the SAME scene there, so the library's HIP-event
+# average and rocprofv3's kernel average must agree (in the full step they sit ~25 % apart: different trajectories and a
+# GPU that the fp32 MIOpen network keeps at a lower clock when nothing slows the host down)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_hot" -o t -- python "$R/bench.py" --model 0 --cpu-baseline 0 > "$O/stats_hot.log" 2>&1)
 tools/collect_traffic.sh "$O/traffic" > "$O/traffic.log" 2>&1
 (hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_ubench.hip -o /tmp/valu_ubench && timeout 150 /tmp/valu_ubench) > "$O/valu_ubench.log" 2>&1
 python tools/microbench.py > "$O/microbench.log" 2>&1
@@ -44,6 +48,12 @@ for k, v in d.items():
     rep[k.replace("(anonymous namespace)::", "")] = {"dispatches": len(v), "avg_us_all": sum(x[1] for x in v) / len(v) / 1e3,
                                                       "avg_us_profile_pass": sum(last) / len(last) / 1e3}
 json.dump(rep, open(out + "/raster_trace_summary.json", "w"), indent=1)
+hot = {}
+for fn in glob.glob(out + "/stats_hot/*kernel_stats.csv"):
+    for r in csv.DictReader(open(fn)):
+        if "k_raster" in r["Name"]:
+            hot[r["Name"].replace("(anonymous namespace)::", "")] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+json.dump(hot, open(out + "/raster_hot_stats.json", "w"), indent=1)
 PY
 find "$O" -name "*.csv" -size +3M -delete      # keep the merged-back payload small (per-dispatch traces)
 ls -la "$O"
