@@ -216,10 +216,15 @@ def main():
         measure.history = history
         return loss, host_dt, time.perf_counter() - t0
 
-    # Training on synthetic (random) images is chaotic -- float-atomic summation order alone changes the trajectory -- and
-    # a run can diverge to a non-finite loss, after which every render degenerates (NaN geometry) and the timing means
-    # nothing.  Such a measurement is discarded and repeated on a freshly initialised model (all ranks decide together);
-    # the number of discarded attempts is reported in config.discarded_nonfinite_runs.
+    # About one full-step measurement in 20 ends with a non-finite loss: the per-step history of such a run (printed to
+    # stderr below) shows an ordinary, slowly falling loss and then NaN from one step on -- not a gradual divergence.  It
+    # has only ever been seen with the network in the loop, in fresh processes: 12 000 hot-path-only steps in 8 processes
+    # agree to 1 ulp (config.hot_path_loss_spread), and 180 fresh models trained for 45 steps each inside one process
+    # (tools/debug/nan_async.py with per-term tripwires, nan_plain.py without) never showed it, so its origin -- the fp32
+    # MIOpen / hipBLASLt network, this repo's 2x up-sampling kernels inside it, or a rare input to a render kernel -- is
+    # not established.  After a NaN every render degenerates (NaN geometry) and the timing means nothing, so such a
+    # measurement is discarded and repeated on a freshly initialised model (all ranks decide together); the number of
+    # discarded attempts is reported in config.discarded_nonfinite_runs.
     discarded = 0
     while True:
         loss, host_dt, dt = measure()
@@ -243,6 +248,13 @@ def main():
         step_fn = build_step()
     if args.graph and not use_model and world == 1:
         check_replay("after the timed replays")      # back-to-back replays must still compute the eager step's numbers
+    # hot-path-only mode renders the SAME scene every step: the per-step totals may differ by float-atomic summation order
+    # only.  Their relative spread over the timed steps is reported (config.hot_path_loss_spread) -- a sporadic wrong result
+    # of any kernel on the path would show here.
+    loss_spread = None
+    if not use_model and not args.graph:
+        hist = torch.stack([h.detach().reshape(()) for h in measure.history]).double()
+        loss_spread = float(((hist.max() - hist.min()) / hist.mean().abs()).item()) if bool(torch.isfinite(hist).all()) else float("nan")
     # roofline pass: the same steps again, untimed, with the library recording a HIP-event pair around every raster
     # main kernel on its launch stream (event creation / bookkeeping stays out of `value`)
     _lib.profile_enable(True)
@@ -322,7 +334,8 @@ def main():
         "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                         "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
                         "final_loss": float(loss.detach()), "discarded_nonfinite_runs": discarded,
-                        "hip_graph": bool(args.graph and not use_model and world == 1)}, **rccl),
+                        "hip_graph": bool(args.graph and not use_model and world == 1),
+                        "hot_path_loss_spread": loss_spread}, **rccl),
         # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
         # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the
         # variant touches, once) / its mean HIP-event duration over the profile pass.

@@ -98,7 +98,7 @@ if os.path.exists(tsum):
         L.append("HIP-event average (profile pass = steps 41-45 of the un-profiled bench run) vs rocprofv3 over the same five "
                  "steps of the profiled run of the same command for `%s`: %.1f us vs %.1f us (%.1f us over all 45 steps); "
                  "`profiles/%s_raster_trace_summary.json`.  The two are different processes on different trajectories "
-                 "(training on synthetic images is chaotic: float-atomic summation order), and un-profiled the fp32 MIOpen "
+                 "(float-atomic summation order differs), and un-profiled the fp32 MIOpen "
                  "network keeps the GPU busy back to back, while the profiler slows the host down and leaves it idle between "
                  "launches -- these VALU-bound kernels follow the clock.\n"
                  % (kk[0].split("(")[0], rf["avg_us"], tj[kk[0]].get("avg_us_profile_pass", tj[kk[0]].get("avg_us_last10steps", 0.0)),
