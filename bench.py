@@ -312,7 +312,7 @@ def main():
                 if use_model else "; network excluded")
     if args.workload == "s1":
         wl = ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: 4 raster fwd + 3 bwd per image (mask + "
-              "unseen-view silhouettes, textured soft-max render with p2f, hard visibility render) + IoU / AlexNet-perceptual "
+              "unseen-view silhouettes in one launch, textured soft-max render with p2f carrying the hard visibility render) + IoU / AlexNet-perceptual "
               "texture / texture-dt / tex-cycle / Laplacian / flatten / GAN losses, fwd+bwd, epoch %d%s"
               % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], args.epoch, net_note))
     else:

@@ -111,6 +111,19 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                        int flags, const float *background, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* umr_raster_forward plus one more output: visibility [N,2,IS,IS] = (nearest depth, its face id | -1), the aggrs_info planes
+ * a func_id_rgb = 0 ('hard') render of the SAME faces would write (soft_rasterize_cuda_kernel.cu:408-411, :463-464),
+ * bit-identical to UMR_RASTER_FACE_ID_ONLY.  train_s1 renders the textured soft-max image (train_s1.py:217) and, from the
+ * same mesh and camera, the hard render of which only the face-id plane is read (:223-224): here the second falls out of
+ * the first's visits.  Soft-max colour with UMR's modes only; visibility == NULL is umr_raster_forward. */
+int umr_raster_forward_vis(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
+                           const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,
+                           float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
+                           float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                           int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                           int flags, const float *background, void *workspace, size_t workspace_bytes,
+                           void *stream, float *visibility);
+
 /*   grad_faces    [N,F,9], grad_textures [N,F,TS,3]   zero-filled by the caller; contributions are ADDED
  *   grad_soft_colors [N,4,IS,IS], or -- when grad_is_pooled != 0 -- the gradient of the 2x2-pooled
  *                 image [N,4,IS/2,IS/2] (the avg_pool2d backward is fused: each pixel sees g/4)

@@ -368,12 +368,12 @@ def test_registered_custom_ops_schema_and_fake_kernels():
     _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
     tex = torch.rand(1, faces.shape[1], 4, 3, generator=gen).to(DEV)           # one texture set shared by both views
     args = (fv.detach().requires_grad_(True), tex.requires_grad_(True), 32, [0., 0., 0.], 1., 100., True, 1e-3, 1e-5, 1e-10,
-            1e-4, 1, True, True)
+            1e-4, 1, True, True, True)
     opcheck(torch.ops.umr.soft_rasterize.default, args, test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
     opcheck(torch.ops.umr.silhouette.default, (fv.detach().requires_grad_(True), 32, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, True),
             test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
-    img, p2f, aggr, saved = torch.ops.umr.soft_rasterize(*args)
-    assert img.shape == (2, 4, 16, 16) and saved.shape == (2, 4, 32, 32) and aggr.shape == (2, 2, 32, 32)
+    img, p2f, aggr, saved, vis = torch.ops.umr.soft_rasterize(*args)
+    assert img.shape == (2, 4, 16, 16) and saved.shape == (2, 4, 32, 32) and aggr.shape == (2, 2, 32, 32) and vis.shape == aggr.shape
     img.sum().backward()
     assert args[0].grad.shape == fv.shape and args[1].grad.shape == tex.shape     # texture gradient summed over the group
 
@@ -507,3 +507,24 @@ def test_face_start_order_does_not_change_results():
         for x, y in zip(outs[0], outs[1]):
             assert torch.isfinite(x).all() and float(x.abs().sum()) > 0
             assert torch.equal(x, y)
+
+
+def test_visibility_planes_from_the_textured_render_equal_the_hard_render():
+    """train_s1.py:217-224 renders the textured soft-max image and, for the same mesh and camera, the hard image of which
+    only aggrs_info's face-id plane is read.  umr_raster_forward_vis produces those planes inside the soft-max render's own
+    visits: bit-identical to the hard render's aggrs_info and to the visibility-only kernel, the soft-max outputs
+    unchanged -- power-of-two, ragged and tiny images, one-sided faces, shared texture sets."""
+    from umr_amd import functional as UF
+    for (n, sub, IS, ts, fill_back, G, pool) in ((3, 3, 512, 36, True, 1, True), (2, 2, 200, 1, False, 1, False),
+                                                 (1, 1, 24, 4, True, 1, True), (4, 2, 136, 9, True, 2, True)):
+        verts, faces, cams, gen = scene(n, sub, seed=IS + 5)
+        _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+        tex = torch.rand(n // G, faces.shape[1], ts, 3, generator=gen).to(DEV)
+        args = (IS, [0.1, 0.2, 0.3], 1, 100, fill_back, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
+        sc, p2f, aggr, vis = UF.soft_rasterize(fv, tex, *args, 'softmax', pool=pool, want_visibility=True)
+        sc0, p2f0, aggr0 = UF.soft_rasterize(fv, tex, *args, 'softmax', pool=pool)
+        assert torch.equal(sc, sc0) and torch.equal(aggr, aggr0)
+        _, _, hard = UF.soft_rasterize(fv, tex.repeat_interleave(G, 0), *args, 'hard')
+        assert torch.equal(vis, hard)
+        assert torch.equal(vis, UF.visibility(fv, IS, 1., 100., fill_back, 1e-3, 1e-5, 1e-10, 1e-4))
+        assert float((vis[:, 1] >= 0).float().mean()) > 0.05            # the meshes are on screen

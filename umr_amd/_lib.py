@@ -23,6 +23,8 @@ SIGNATURES = {
     "umr_raster_workspace_bytes": ([_I, _I], _Z),
     "umr_raster_forward": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I,
                             ctypes.POINTER(ctypes.c_float), _P, _Z, _P], _I),
+    "umr_raster_forward_vis": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I,
+                                ctypes.POINTER(ctypes.c_float), _P, _Z, _P, _P], _I),
     "umr_raster_backward": ([_P] * 8 + [_I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _P, _Z, _P], _I),
     "umr_project_faces_forward": ([_P] * 5 + [_I, _I, _I, _F, _F, _I, _P], _I),
     "umr_project_faces_lit_forward": ([_P] * 6 + [_I, _I, _I, _F, _F, _I, _F, _F, ctypes.POINTER(_F), ctypes.POINTER(_F), _P], _I),

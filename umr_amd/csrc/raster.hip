@@ -143,6 +143,19 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
                        int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
                        int flags, const float *background, void *workspace, size_t workspace_bytes,
                        void *stream) {
+    return umr_raster_forward_vis(faces, textures, faces_info, aggrs_info, grid, p2f_info, p2f_sum, soft_colors, pooled_out,
+                                  N, F, TS, image_size, near_, far_, eps, sigma_val, func_id_dist, dist_eps, gamma_val,
+                                  func_id_rgb, func_id_alpha, texture_sample_type, double_side, flags, background, workspace,
+                                  workspace_bytes, stream, nullptr);
+}
+
+int umr_raster_forward_vis(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
+                           const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,
+                           float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
+                           float eps, float sigma_val, int func_id_dist, float dist_eps, float gamma_val,
+                           int func_id_rgb, int func_id_alpha, int texture_sample_type, int double_side,
+                           int flags, const float *background, void *workspace, size_t workspace_bytes,
+                           void *stream, float *visibility) {
     int R = 0;
     const bool alpha_only = (flags & UMR_RASTER_ALPHA_ONLY) != 0;
     const bool ids_only = (flags & UMR_RASTER_FACE_ID_ONLY) != 0;
@@ -156,6 +169,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     bool general = false;
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R, &general)) return UMR_ERR_ARG;
     if (general && (alpha_only || ids_only || pooled_out)) return UMR_ERR_ARG;   // fused variants exist for UMR's modes only
+    if (visibility && (general || alpha_only || ids_only || func_id_rgb != 1)) return UMR_ERR_ARG;
     if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
     const int with_p2f = func_id_rgb == 1 && !alpha_only && !(flags & UMR_RASTER_NO_P2F);
     if (with_p2f && (!grid || !p2f_info || !p2f_sum)) return UMR_ERR_ARG;
@@ -167,7 +181,7 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
     A.bbox = (const float4 *)workspace;
     A.rec = (const float *)((char *)workspace + ws_bbox_bytes(N, F));
     A.textures = textures; A.grid = grid; A.aggrs = aggrs_info; A.p2f_info = p2f_info; A.p2f_sum = p2f_sum;
-    A.soft_colors = soft_colors; A.pooled = pooled_out;
+    A.soft_colors = soft_colors; A.pooled = pooled_out; A.vis = visibility;
     A.N = N; A.F = F; A.IS = image_size; A.TS = TS; A.R = R;
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;  // :332
@@ -201,6 +215,14 @@ int umr_raster_forward(const float *faces, const float *textures, float *faces_i
         } else if (func_id_rgb == 0) {
             if (double_side) k_raster_forward<0, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
             else k_raster_forward<0, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+        } else if (visibility) {
+            if (with_p2f) {
+                if (double_side) k_raster_forward<1, true, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+                else k_raster_forward<1, true, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+            } else {
+                if (double_side) k_raster_forward<1, false, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+                else k_raster_forward<1, false, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+            }
         } else if (with_p2f) {
             if (double_side) k_raster_forward<1, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
             else k_raster_forward<1, true, false><<<blocks, BLK_THREADS, 0, st>>>(A);

@@ -62,6 +62,8 @@ struct RasterArgs {
     // read by the general-mode kernels only (raster_general.h): the reference's func_id_dist / func_id_alpha /
     // func_id_rgb and texture_sample_type
     int dist_mode, alpha_mode, rgb_mode, tex_vertex;
+    float *vis;         // k_raster_forward<1, .., VIS>: hard z-buffer planes [N,2,IS,IS] = (nearest depth, its face id | -1),
+                        // written next to the soft-max render of the same faces (umr_raster_forward_vis)
     int no_xcd_remap;   // A/B switch (umr_debug_set("xcd_remap", 0)): pixel-major work items in plain blockIdx order
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;

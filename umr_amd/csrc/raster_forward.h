@@ -5,7 +5,7 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-template <int RGB, bool P2F, bool TWO_SIDED>  // 0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
+template <int RGB, bool P2F, bool TWO_SIDED, bool VIS = false>  // VIS (RGB == 1): also the hard z-buffer planes.  0 = hard z-buffer colour (:408-416), 1 = soft-max over depth (:417-437),
                     // 2 = silhouette only: alpha plane, no depth / colour / p2f (soft_colors is then [N,IS,IS]),
                     // 3 = visibility only: the hard z-buffer's (depth, face id) planes, nothing else
 // Register budget for 7 waves per SIMD: the default allocation (106 SGPRs) admits 6; the kernels are VALU-issue bound
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
                     if (!(zp < A.near_ || zp > A.far_)) {
+                        if (VIS) {   // the z-buffer winner of the hard render (:408-411) of the same faces, on the side
+                            const bool incl = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
+                            if (zp < depth_min && incl && (TWO_SIDED || fc.front())) { depth_min = zp; face_min = f; }
+                        }
                         if (RGB == 0) {
                             const bool inside = p.w0 <= 1 && p.w0 >= 0 && p.w1 <= 1 && p.w1 >= 0 && p.w2 <= 1 && p.w2 >= 0;
                             if (zp < depth_min && inside && (TWO_SIDED || fc.front())) {
@@ -173,6 +177,11 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
         float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
         ag[0] = RGB == 0 ? depth_min : ssum;
         ag[npix] = RGB == 0 ? (float)face_min : smax;
+        if (VIS) {
+            float *vg = A.vis + (size_t)t.n * 2 * npix + pn;
+            vg[0] = depth_min;
+            vg[npix] = (float)face_min;
+        }
     }
     if (A.pooled) {  // fused anti-aliasing 2x2 average (rasterizer.py:52-53); IS is even here
         float v[4] = {o0, o1, o2, o3};

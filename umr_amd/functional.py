@@ -55,13 +55,15 @@ class SoftRasterizeFunction:
       pool:       also return/consume the 2x2 average-pooled image (anti-aliasing fused into the kernels;
                   the first output is then [N,4,IS/2,IS/2] and its gradient is consumed at that size)
       need_p2f:   False skips the p2f accumulators (returned as zeros)
+      want_visibility: a 4th output [N,2,IS,IS] = the aggrs_info of the 'hard' render of the same faces (nearest depth, its
+                  face id | -1), produced by the same kernel visits (soft-max colour only)
     """
 
     @staticmethod
     def apply(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
               fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
               gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-              pool=False, need_p2f=True):
+              pool=False, need_p2f=True, want_visibility=False):
         from . import ops  # noqa: F401  (registers torch.ops.umr.*)
         _check_raster_shapes(face_vertices, textures)
         modes = ops.pack_modes(_FUNC_RGB[aggr_func_rgb], _FUNC_DIST[dist_func], _FUNC_ALPHA[aggr_func_alpha],
@@ -73,10 +75,13 @@ class SoftRasterizeFunction:
             raise RuntimeError("soft_rasterize: texture_type='vertex' needs textures [N,F,3,3]; got %s" % (tuple(textures.shape),))
         if not face_vertices.is_cuda:
             raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
-        image, p2f, aggrs, _ = torch.ops.umr.soft_rasterize(
+        if want_visibility and modes != 1:
+            raise RuntimeError("soft_rasterize: want_visibility needs aggr_func_rgb='softmax' with UMR's own modes")
+        image, p2f, aggrs, _, vis = torch.ops.umr.soft_rasterize(
             face_vertices, textures, int(image_size), [float(c) for c in background_color], float(near), float(far),
-            bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), modes, bool(pool), bool(need_p2f))
-        return image, p2f, aggrs
+            bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), modes, bool(pool), bool(need_p2f),
+            bool(want_visibility))
+        return (image, p2f, aggrs, vis) if want_visibility else (image, p2f, aggrs)
 
 
 class SilhouetteFunction:
@@ -119,7 +124,7 @@ def visibility(face_vertices, image_size, near=1., far=100., fill_back=True, eps
 def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-                   pool=False, need_p2f=True):
+                   pool=False, need_p2f=True, want_visibility=False):
     """Same signature and return as soft_renderer.functional.soft_rasterize
     (functional/soft_rasterize.py:111-125): (soft_colors [N,4,IS,IS], p2f_info [N,F,2], aggrs_info)."""
     if not face_vertices.is_cuda:
@@ -127,7 +132,7 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
         raise TypeError('Rasterize module supports only GPU (ROCm) tensors')
     return SoftRasterizeFunction.apply(face_vertices, textures, image_size, background_color, near, far,
                                        fill_back, eps, sigma_val, dist_func, dist_eps, gamma_val,
-                                       aggr_func_rgb, aggr_func_alpha, texture_type, pool, need_p2f)
+                                       aggr_func_rgb, aggr_func_alpha, texture_type, pool, need_p2f, want_visibility)
 
 
 class ProjectFacesFunction(Function):

@@ -16,9 +16,10 @@ SoftRenderer route through these ops.
 
   umr::soft_rasterize(face_vertices[N,F,3,3], textures[N/G,F,TS,3], image_size, background[3], near, far, fill_back, eps,
                       sigma_val, dist_eps, gamma_val, modes (pack_modes: 0 hard / 1 soft-max colour with UMR's euclidean +
-                      prod + surface modes; the other ids of the reference binding in the upper bits), pool, need_p2f)
+                      prod + surface modes; the other ids of the reference binding in the upper bits), pool, need_p2f,
+                      want_visibility (soft-max colour with UMR's modes: also the hard render's z-buffer planes))
         -> (image [N,4,S,S] (S = image_size or image_size/2 when pool), p2f [N,F,2], aggrs_info [N,2,IS,IS],
-            soft_colors [N,4,IS,IS] (saved state; == image when not pool))
+            soft_colors [N,4,IS,IS] (saved state; == image when not pool), visibility [N,2,IS,IS] | empty)
   umr::soft_rasterize_backward(face_vertices, textures, soft_colors, aggrs_info, grad_image, <same scalars>,
                                need_grad_faces, need_grad_textures) -> (grad_face_vertices, grad_textures)
   umr::silhouette(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
@@ -61,8 +62,8 @@ def _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_v
 @custom_op("umr::soft_rasterize", mutates_args=(), device_types="cuda")
 def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
                       near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
-                      gamma_val: float, modes: int, pool: bool, need_p2f: bool
-                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                      gamma_val: float, modes: int, pool: bool, need_p2f: bool, want_visibility: bool
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     from .functional import standard_grid
     L = _lib.lib()
     dev = face_vertices.device
@@ -86,24 +87,28 @@ def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image
     ws_bytes = L.umr_raster_workspace_bytes(N, F)
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
-    rc = L.umr_raster_forward(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_acc[0]), ptr(p2f_acc[1]),
-                              ptr(soft_colors), ptr(pooled), N, F, TS, *sc, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
-                              ws_bytes, _lib.stream_ptr(dev))
-    _lib.check(rc, "umr_raster_forward")
+    # the hard render's (depth, face id) planes of the same faces, from the same visits (umr_raster_forward_vis)
+    vis = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32) if want_visibility else None
+    rc = L.umr_raster_forward_vis(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_acc[0]), ptr(p2f_acc[1]),
+                                  ptr(soft_colors), ptr(pooled), N, F, TS, *sc, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
+                                  ws_bytes, _lib.stream_ptr(dev), ptr(vis))
+    _lib.check(rc, "umr_raster_forward_vis")
     p2f = p2f_acc[0] / p2f_acc[1].clamp_min(1e-12)  # functional/soft_rasterize.py:73
     # custom-op outputs may not alias each other: without the fused pool the image IS the saved state, returned once more
     # as an empty placeholder in the 4th slot
-    return (pooled if pool else soft_colors), p2f, aggrs_info, (soft_colors if pool else soft_colors.new_empty(0))
+    return ((pooled if pool else soft_colors), p2f, aggrs_info, (soft_colors if pool else soft_colors.new_empty(0)),
+            (vis if want_visibility else soft_colors.new_empty(0)))
 
 
 @soft_rasterize_op.register_fake
 def _(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes,
-      pool, need_p2f):
+      pool, need_p2f, want_visibility):
     N, F = face_vertices.shape[:2]
     IS = int(image_size)
     S = IS // 2 if pool else IS
     f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
-    return f(N, 4, S, S), f(N, F, 2), f(N, 2, IS, IS), (f(N, 4, IS, IS) if pool else f(0))
+    return (f(N, 4, S, S), f(N, F, 2), f(N, 2, IS, IS), (f(N, 4, IS, IS) if pool else f(0)),
+            (f(N, 2, IS, IS) if want_visibility else f(0)))
 
 
 @custom_op("umr::soft_rasterize_backward", mutates_args=(), device_types="cuda")
@@ -142,20 +147,21 @@ def _(face_vertices, textures, soft_colors, aggrs_info, grad_image, image_size, 
 
 
 def _raster_setup(ctx, inputs, output):
-    (fv, tex, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool, need_p2f) = inputs
-    image, p2f, aggrs, saved = output
+    (fv, tex, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool, need_p2f,
+     want_visibility) = inputs
+    image, p2f, aggrs, saved, vis = output
     ctx.save_for_backward(fv, tex, (saved if pool else image), aggrs)
     ctx.cfg = (image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool)
 
 
-def _raster_backward(ctx, g_image, g_p2f, g_aggrs, g_saved):
+def _raster_backward(ctx, g_image, g_p2f, g_aggrs, g_saved, g_vis):
     # grad_p2f_info / grad_aggrs_info are ignored, as in the reference (functional/soft_rasterize.py:78): p2f is forward-only
     fv, tex, soft_colors, aggrs = ctx.saved_tensors
     need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     if not (need_gf or need_gt):
-        return (None,) * 14
+        return (None,) * 15
     gf, gt = torch.ops.umr.soft_rasterize_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg, need_gf, need_gt)
-    return (gf if need_gf else None, gt if need_gt else None) + (None,) * 12
+    return (gf if need_gf else None, gt if need_gt else None) + (None,) * 13
 
 
 soft_rasterize_op.register_autograd(_raster_backward, setup_context=_raster_setup)

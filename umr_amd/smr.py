@@ -73,12 +73,15 @@ class SoftRenderer(torch.nn.Module):
         return UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
                                            self.dist_eps, self.gamma_val, self.anti_aliasing)
 
-    def forward(self, vertices, faces, cams, textures=None):
+    def forward(self, vertices, faces, cams, textures=None, with_visibility=False):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
         textures None | [N,F,TS,3].
         K camera hypotheses per mesh without the reference's x K repeats (loss_utils.py:260-262, 303-306): pass
         vertices / faces as [N/K,...] and / or textures as [N/K,F,TS,3] with cams [N,7] ordered mesh-major
-        (view n = mesh n // K); outputs are per view, gradients come back summed over the K views."""
+        (view n = mesh n // K); outputs are per view, gradients come back summed over the K views.
+        with_visibility (soft-max renders): a 4th return value, the aggrs_info [N,2,IS,IS] = (nearest depth, face id | -1) a
+        SoftRenderer(img_size, 'hard') would return for the same mesh and cameras -- train_s1.py:217-224 renders both; here
+        the z-buffer falls out of the textured render's own kernel visits."""
         faces = faces.int().contiguous()                                  # smr.py:81
         N = cams.shape[0]
         if self.ids_only and self.render_type == 'hard':
@@ -118,7 +121,9 @@ class SoftRenderer(torch.nn.Module):
             if self.light_intensity_ambient != 1 or any(c != 1 for c in self.light_color):
                 textures = textures * (self.light_intensity_ambient * self._const(textures, self.light_color))
         size = self.img_size * (2 if self.anti_aliasing else 1)          # rasterizer.py:43
+        if with_visibility and self.render_type != 'softmax':
+            raise RuntimeError("with_visibility: only for render_type 'softmax'")
         return UF.soft_rasterize(face_out, textures, size, self.background_color, self.near, self.far, True,
                                  self.eps, self.sigma_val, 'euclidean', self.dist_eps, self.gamma_val,
                                  self.render_type, 'prod', 'surface', pool=self.anti_aliasing,
-                                 need_p2f=self.need_p2f)
+                                 need_p2f=self.need_p2f, want_visibility=with_visibility)

@@ -130,11 +130,13 @@ class RenderCompareS1(nn.Module):
         tex = geom_utils.sample_textures(tex_flow, imgs)
         bs, fs = tex.shape[:2]
         tex = tex.reshape(bs, fs, -1, 3)
-        texture_rgba, p2f_info, _ = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex)
+        # :217 textured soft-max render and :223-224 the hard render of the SAME mesh and camera of which only the face-id
+        # plane is read: one launch (the z-buffer winner is tracked during the soft-max render's own visits)
+        texture_rgba, p2f_info, _, aggr_info = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex,
+                                                                 with_visibility=True)
         texture_pred = texture_rgba[:, 0:3]
         terms["tex"] = self.texture_loss(texture_pred, imgs, masks, mask_pred_seen)
         terms["tex_dt"] = loss_utils.texture_dt_loss(tex_flow, dts)
-        _, _, aggr_info = self.hard_renderer(pred_vs.detach(), faces, proj_cam.detach())
         aggr_ids = aggr_info[:, 1].reshape(bs, -1)
         tex_cycle, _ = self.texture_cycle_fn(tex_flow, p2f_info.detach(), aggr_ids.detach())
         terms["tex_cycle"] = tex_cycle
