@@ -97,10 +97,9 @@ if os.path.exists(tsum):
     if kk:
         L.append("HIP-event average (profile pass = steps 41-45 of the un-profiled bench run) vs rocprofv3 over the same five "
                  "steps of the profiled run of the same command for `%s`: %.1f us vs %.1f us (%.1f us over all 45 steps); "
-                 "`profiles/%s_raster_trace_summary.json`.  The two are different processes on different trajectories "
-                 "(float-atomic summation order differs), and un-profiled the fp32 MIOpen "
-                 "network keeps the GPU busy back to back, while the profiler slows the host down and leaves it idle between "
-                 "launches -- these VALU-bound kernels follow the clock.\n"
+                 "`profiles/%s_raster_trace_summary.json`.  The two are different processes on different training trajectories "
+                 "(float-atomic summation order differs, so the meshes of steps 41-45 are not the same meshes) and at "
+                 "different clock states; over this round's refreshes the ratio of the two ranged 0.94 - 1.27.\n"
                  % (kk[0].split("(")[0], rf["avg_us"], tj[kk[0]].get("avg_us_profile_pass", tj[kk[0]].get("avg_us_last10steps", 0.0)),
                     tj[kk[0]]["avg_us_all"], tag))
         hs = os.path.join(SRC, "raster_hot_stats.json")
