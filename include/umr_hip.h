@@ -282,6 +282,17 @@ int umr_visible_face_mask(const float *face_ids, float *mask, int B, long P, int
 #define UMR_COS_MAX_TAPS 8
 #define UMR_COS_CHUNKS 1024   /* 64-pixel chunks per feature map: maps of up to 65536 pixels (256 x 256) */
 size_t umr_cos_sim_workspace_bytes(int ntaps, int N, const int *P);
+
+/* Input side of the perceptual texture term in one pass per image stack (img [B,C<=3,H,W], mask [B,H,W], HW = H*W):
+ *   out = ((2 * (img * mask) - 1) - shift_c) / scale_c
+ * = nnutils/loss_utils.py:141-146 (image * mask), nnutils/perceptual_loss.py:52-54 (2 x - 1) and
+ * external/PerceptualSimilarity/models/networks_basic.py:45-46 ((x - shift) / scale), every step rounded to fp32 in the
+ * reference's order.  shift3 / scale3: HOST pointers to 3 floats.  backward: grad_img [B,C,H,W] and / or grad_mask [B,H,W]
+ * (either may be NULL), fully written. */
+int umr_perceptual_prologue_forward(const float *img, const float *mask, float *out, int B, int C, long HW,
+                                    const float *shift3, const float *scale3, void *stream);
+int umr_perceptual_prologue_backward(const float *grad_out, const float *img, const float *mask, float *grad_img,
+                                     float *grad_mask, int B, int C, long HW, const float *scale3, void *stream);
 int umr_cos_sim_forward(int ntaps, const float *const *f0, const float *const *f1, const int *C, const int *P, int N,
                         float eps, float *val, void *workspace, size_t workspace_bytes, void *stream);
 int umr_cos_sim_backward(int ntaps, const float *const *f0, const float *const *f1, float *const *g0, float *const *g1,

@@ -52,6 +52,8 @@ SIGNATURES = {
                              _Z, _P], _I),
     "umr_cos_sim_backward": ([_I, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P),
                               ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _F, _P, _P, _Z, _P], _I),
+    "umr_perceptual_prologue_forward": ([_P, _P, _P, _I, _I, ctypes.c_long, ctypes.POINTER(_F), ctypes.POINTER(_F), _P], _I),
+    "umr_perceptual_prologue_backward": ([_P, _P, _P, _P, _P, _I, _I, ctypes.c_long, ctypes.POINTER(_F), _P], _I),
     "umr_part_match_workspace_bytes": ([_I, _I, _I], _Z),
     "umr_part_match_forward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(_F), _F, _F, _P, _P, _P, _Z, _P], _I),
     "umr_part_match_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(_F), _F, _F, _P, _P, _P, _P, _P, _Z, _P], _I),

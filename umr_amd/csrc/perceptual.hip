@@ -122,6 +122,46 @@ __global__ __launch_bounds__(256) void k_cos_backward(const CosArgs A, const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------ perceptual prologue
+// Input side of the perceptual texture term, three reference steps in one pass per image stack:
+//   loss_utils.py:141-146   x1 = img * mask            (mask [B,H,W] broadcast over the channels)
+//   perceptual_loss.py:52-54  x2 = 2 * x1 - 1
+//   networks_basic.py:45-46   y  = (x2 - shift_c) / scale_c
+// each rounded to fp32 on its own, in that order (no contraction) -> the values torch's five element-wise kernels produce.
+// Backward (autograd of the same chain): g2 = g_y / scale_c; g1 = 2 g2; g_img = g1 * mask; g_mask = sum_c g1 * img_c.
+__global__ __launch_bounds__(256) void k_pp_forward(const float *__restrict__ img, const float *__restrict__ mask,
+                                                    float *__restrict__ out, int C, unsigned HW, float3 shift, float3 scale) {
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= HW) return;
+    const size_t b = blockIdx.y;
+    const float m = mask[b * HW + p];
+    const float sh[3] = {shift.x, shift.y, shift.z}, sc[3] = {scale.x, scale.y, scale.z};
+    for (int c = 0; c < C; ++c) {
+        const size_t i = (b * C + c) * HW + p;
+        const float x1 = img[i] * m;
+        const float x2 = 2.f * x1 - 1.f;
+        out[i] = (x2 - sh[c % 3]) / sc[c % 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pp_backward(const float *__restrict__ gout, const float *__restrict__ img,
+                                                     const float *__restrict__ mask, float *__restrict__ gimg,
+                                                     float *__restrict__ gmask, int C, unsigned HW, float3 scale) {
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= HW) return;
+    const size_t b = blockIdx.y;
+    const float m = mask[b * HW + p];
+    const float sc[3] = {scale.x, scale.y, scale.z};
+    float gm = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const size_t i = (b * C + c) * HW + p;
+        const float g1 = 2.f * (gout[i] / sc[c % 3]);
+        if (gimg) gimg[i] = g1 * m;
+        gm += g1 * img[i];
+    }
+    if (gmask) gmask[b * HW + p] = gm;
+}
+
 // ------------------------------------------------------------------------------------------------ part matching
 // proj plane c (c = 1..4) of sample b: planes 1-3 = channels 0-2 of render A, plane 4 = channel 0 of render B (both
 // [B,4,H,W], the pooled raster output); plane 0 is the constant background 0.1 (loss_utils.py:372-373, 399).
@@ -428,6 +468,25 @@ int umr_cos_sim_backward(int ntaps, const float *const *f0, const float *const *
     for (int t = 0; t < ntaps; ++t)
         A.bwd_start[t + 1] = A.bwd_start[t] + ((P[t] + 63) / 64) * ((C[t] + COS_BWD_CH - 1) / COS_BWD_CH);
     k_cos_backward<<<dim3(A.bwd_start[ntaps], N), 256, 0, (hipStream_t)stream>>>(A, grad_val);
+    return umr_launch_status();
+}
+
+int umr_perceptual_prologue_forward(const float *img, const float *mask, float *out, int B, int C, long HW,
+                                    const float *shift3, const float *scale3, void *stream) {
+    if (!img || !mask || !out || !shift3 || !scale3 || B <= 0 || C <= 0 || C > 3 || HW <= 0 || HW > 0x7fffffffL || B > 65535)
+        return UMR_ERR_ARG;
+    k_pp_forward<<<dim3((unsigned)((HW + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+        img, mask, out, C, (unsigned)HW, make_float3(shift3[0], shift3[1], shift3[2]), make_float3(scale3[0], scale3[1], scale3[2]));
+    return umr_launch_status();
+}
+
+int umr_perceptual_prologue_backward(const float *grad_out, const float *img, const float *mask, float *grad_img,
+                                     float *grad_mask, int B, int C, long HW, const float *scale3, void *stream) {
+    if (!grad_out || !img || !mask || !scale3 || B <= 0 || C <= 0 || C > 3 || HW <= 0 || HW > 0x7fffffffL || B > 65535)
+        return UMR_ERR_ARG;
+    if (!grad_img && !grad_mask) return UMR_OK;
+    k_pp_backward<<<dim3((unsigned)((HW + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+        grad_out, img, mask, grad_img, grad_mask, C, (unsigned)HW, make_float3(scale3[0], scale3[1], scale3[2]));
     return umr_launch_status();
 }
 

@@ -405,6 +405,38 @@ class Upsample2xBilinearFunction(Function):
         return gi
 
 
+class PerceptualPrologueFunction(Function):
+    """img [B,C<=3,H,W], mask [B,H,W] -> ((2 (img * mask) - 1) - shift_c) / scale_c: the input side of the perceptual texture
+    term (loss_utils.py:141-146, perceptual_loss.py:52-54, networks_basic.py:45-46) in one launch each way instead of
+    five element-wise kernels forward and as many backward.  shift / scale: 3 python floats each."""
+
+    @staticmethod
+    def forward(ctx, img, mask, shift, scale):
+        L = _lib.lib()
+        x, m = _f32c(img), _f32c(mask)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        sh, sc = (ctypes.c_float * 3)(*[float(v) for v in shift]), (ctypes.c_float * 3)(*[float(v) for v in scale])
+        _lib.check(L.umr_perceptual_prologue_forward(ptr(x), ptr(m), ptr(out), B, C, H * W, sh, sc, _lib.stream_ptr(x.device)),
+                   "umr_perceptual_prologue_forward")
+        ctx.save_for_backward(x, m)
+        ctx.scale = [float(v) for v in scale]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, m = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.to(torch.float32).contiguous()
+        gi = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gm = torch.empty_like(m) if ctx.needs_input_grad[1] else None
+        sc = (ctypes.c_float * 3)(*ctx.scale)
+        _lib.check(L.umr_perceptual_prologue_backward(ptr(g), ptr(x), ptr(m), ptr(gi), ptr(gm), B, C, H * W, sc,
+                                                      _lib.stream_ptr(x.device)), "umr_perceptual_prologue_backward")
+        return gi, gm, None, None
+
+
 class CosSimDistanceFunction(Function):
     """PNet head (networks_basic.py:42-64 + util/util.py:71-83): apply(eps, *feats0, *feats1) with 2 T feature maps
     [N,C_t,X_t,Y_t] -> val [N] = sum_t (1 - mean_xy cos(f0_t, f1_t)).  One launch for all taps each way."""

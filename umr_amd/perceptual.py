@@ -49,14 +49,18 @@ class PNet(nn.Module):
         self.net = AlexNetFeatures()
 
     def forward(self, in0, in1):
+        return self.forward_scaled((in0 - self.shift) / self.scale, (in1 - self.shift) / self.scale)
+
+    def forward_scaled(self, x0, x1):
+        """forward() behind the scaling layer (:45-46): x = (in - shift) / scale already applied by the caller."""
         # two passes as in the reference (:43-47); a side that carries no gradient (the ground-truth image) records
         # no autograd graph, so the convolutions' backward runs over the predicted half only
         def taps(x):
             if x.requires_grad:
-                return self.net((x - self.shift) / self.scale)
+                return self.net(x)
             with torch.no_grad():
-                return self.net((x - self.shift) / self.scale)
-        return cos_sim_distance(taps(in0), taps(in1))
+                return self.net(x)
+        return cos_sim_distance(taps(x0), taps(x1))
 
 
 class PerceptualLoss(object):
@@ -84,9 +88,18 @@ class PerceptualTextureLoss(object):
         self.perceptual_loss = PerceptualLoss(device)
 
     def __call__(self, img_pred, img_gt, mask_gt, mask_pred=None, avg=True):
-        mask_gt = mask_gt.unsqueeze(1)
-        if mask_pred is not None:
-            dist = self.perceptual_loss(img_pred * mask_pred.unsqueeze(1), img_gt * mask_gt)
+        m_pred = mask_gt if mask_pred is None else mask_pred
+        if img_pred.is_cuda and img_pred.dim() == 4 and img_pred.shape[1] == 3:
+            # image * mask (:141-146), 2 x - 1 (perceptual_loss.py:52-54) and PNet's scaling layer
+            # (networks_basic.py:45-46) in one launch per side (umr_perceptual_prologue_*), same rounding sequence
+            net = self.perceptual_loss.model
+            if getattr(net, "_host_consts", None) is None:     # read the two buffers back once, not once per step
+                net._host_consts = (net.shift.flatten().tolist(), net.scale.flatten().tolist())
+            sh, sc = net._host_consts
+            x_pred = UF.PerceptualPrologueFunction.apply(img_pred, m_pred, sh, sc)
+            with torch.no_grad():
+                x_gt = UF.PerceptualPrologueFunction.apply(img_gt, mask_gt, sh, sc)
+            dist = net.forward_scaled(x_gt, x_pred)          # forward_pair(target, pred)
         else:
-            dist = self.perceptual_loss(img_pred * mask_gt, img_gt * mask_gt)
+            dist = self.perceptual_loss(img_pred * m_pred.unsqueeze(1), img_gt * mask_gt.unsqueeze(1))
         return dist.mean() if avg else dist
