@@ -207,3 +207,30 @@ def test_rasterize_rejects_mismatched_texture_batch():
     for tex in (torch.zeros(2, 42, 4, 3), torch.zeros(3, 80, 4, 3), torch.zeros(2, 80, 4)):   # [1,80,4,3] = a group of 2
         with pytest.raises(RuntimeError, match="face_vertices must be"):
             SoftRasterizeFunction.apply(fv, tex, 64)          # shape check precedes any device access
+
+
+def test_mode_ids_pack_into_one_op_argument():
+    """torch.ops.umr.soft_rasterize takes the reference binding's four mode ids (functional/soft_rasterize.py:21-24) as one
+    integer; 0 / 1 keep meaning hard / soft-max colour with UMR's own modes."""
+    from umr_amd import ops
+    assert ops.pack_modes(0) == 0 and ops.pack_modes(1) == 1
+    assert ops.unpack_modes(1) == (1, 2, 2, 0) and ops.unpack_modes(0) == (0, 2, 2, 0)
+    for rgb in (0, 1):
+        for dist in (0, 1, 2):
+            for alpha in (0, 1, 2):
+                for tex in (0, 1):
+                    assert ops.unpack_modes(ops.pack_modes(rgb, dist, alpha, tex)) == (rgb, dist, alpha, tex)
+    import math
+    sc = ops._scalars(64, 1, 100, True, 1e-3, 1e-5, 1e-10, 1e-4, ops.pack_modes(1, 1, 0, 1))
+    assert sc[0] == 64 and sc[5] == 1 and sc[8] == 1 and sc[9] == 0 and sc[10] == 1 and sc[11] == 1
+    assert abs(sc[6] - math.log(1. / 1e-10 - 1.)) < 1e-9
+
+
+def test_soft_rasterize_refuses_cpu_tensors_and_bad_vertex_textures():
+    from umr_amd import functional as UF
+    fv = torch.zeros(1, 4, 3, 3)
+    with pytest.raises(TypeError):
+        UF.soft_rasterize(fv, torch.zeros(1, 4, 1, 3), 8)
+    with pytest.raises(RuntimeError):      # texture_type 'vertex' needs [N,F,3,3] (the reference reads w[j], j < texture_size)
+        UF.SoftRasterizeFunction.apply(fv, torch.zeros(1, 4, 4, 3), 8, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-4, 1e-4,
+                                       'softmax', 'prod', 'vertex')
