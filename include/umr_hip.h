@@ -205,8 +205,10 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
  *   loss[n] = 1 - sum(p*t) / (sum(p + t - p*t) + 1e-6)      predict/target [N,P], loss [N]
  * predict may be a strided channel view: element (n,i) at predict[n*predict_stride + i].
  * backward: grad_predict (same striding, ADDED into) = grad_loss[n] * d loss[n] / d p.
- * sums [N,2] = (intersect, union+1e-6) is written by forward and read by backward.
+ * sums [N, umr_neg_iou_sums_stride(P)]: forward scratch (per-block partial sums, added in a fixed order: no float
+ * atomics, bit-reproducible) whose first two floats per row, (intersect, union + 1e-6), backward reads.
  * -------------------------------------------------------------------------------------------*/
+long umr_neg_iou_sums_stride(long P);
 int umr_neg_iou_forward(const float *predict, long predict_stride, const float *target, float *loss,
                         float *sums, int N, long P, void *stream);
 int umr_neg_iou_backward(const float *predict, long predict_stride, const float *target, const float *sums,

@@ -5,13 +5,19 @@
 namespace {
 
 // ------------------------------------------------------------------ neg_iou (loss_utils.py:41-48)
+// Two stages, no atomics: block k of image n writes its partial (intersection, union) sums into that image's row of
+// `sums`, k_iou_finalize adds them in index order -> the loss is bit-reproducible run to run (float atomics were not).
+// Row layout (IOU_STRIDE(P) floats): [I, U + 1e-6, I_0 .. I_{nb-1}, U_0 .. U_{nb-1}].
+#define IOU_PER_BLOCK 2048
+__host__ __device__ inline int iou_blocks(long P) { return (int)((P + IOU_PER_BLOCK - 1) / IOU_PER_BLOCK); }
+__host__ __device__ inline long iou_stride(long P) { return 2 + 2L * iou_blocks(P); }
+
 __global__ __launch_bounds__(256) void k_iou_partial(const float *__restrict__ predict, long pstride,
-                                                     const float *__restrict__ target, float *__restrict__ sums,
-                                                     long P, int per_block) {
+                                                     const float *__restrict__ target, float *__restrict__ sums, long P) {
     __shared__ float smem[16];
-    const int n = blockIdx.y;
-    const long start = (long)blockIdx.x * per_block;
-    const long end = min(P, start + per_block);
+    const int n = blockIdx.y, nb = gridDim.x;
+    const long start = (long)blockIdx.x * IOU_PER_BLOCK;
+    const long end = min(P, start + IOU_PER_BLOCK);
     const float *p = predict + (size_t)n * pstride;
     const float *t = target + (size_t)n * P;
     float si = 0.f, su = 0.f;
@@ -23,22 +29,31 @@ __global__ __launch_bounds__(256) void k_iou_partial(const float *__restrict__ p
     }
     const float ri = block_sum(si, smem);
     const float ru = block_sum(su, smem);
-    if (threadIdx.x == 0) { atomicAdd(&sums[n * 2], ri); atomicAdd(&sums[n * 2 + 1], ru); }
+    if (threadIdx.x == 0) {
+        float *row = sums + (size_t)n * iou_stride(P);
+        row[2 + blockIdx.x] = ri;
+        row[2 + nb + blockIdx.x] = ru;
+    }
 }
 
-__global__ void k_iou_finalize(float *__restrict__ sums, float *__restrict__ loss, int N) {
+__global__ void k_iou_finalize(float *__restrict__ sums, float *__restrict__ loss, int N, long P) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float u = sums[n * 2 + 1] + 1e-6f;
-    sums[n * 2 + 1] = u;
-    loss[n] = 1.f - sums[n * 2] / u;
+    float *row = sums + (size_t)n * iou_stride(P);
+    const int nb = iou_blocks(P);
+    float I = 0.f, U = 0.f;
+    for (int k = 0; k < nb; ++k) { I += row[2 + k]; U += row[2 + nb + k]; }
+    U += 1e-6f;
+    row[0] = I; row[1] = U;
+    loss[n] = 1.f - I / U;
 }
 
 __global__ void k_iou_backward(const float *__restrict__ predict, long pstride, const float *__restrict__ target,
                                const float *__restrict__ sums, const float *__restrict__ grad_loss,
                                float *__restrict__ grad_predict, long gstride, long P) {
     const int n = blockIdx.y;
-    const float I = sums[n * 2], U = sums[n * 2 + 1], g = grad_loss[n];
+    const float *row = sums + (size_t)n * iou_stride(P);
+    const float I = row[0], U = row[1], g = grad_loss[n];
     const float inv_u = 1.f / U, r = I * inv_u * inv_u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long)gridDim.x * blockDim.x) {
         const float t = target[(size_t)n * P + i];
@@ -332,15 +347,15 @@ __global__ void k_visible_mask(const float *__restrict__ ids, float *__restrict_
 
 extern "C" {
 
+long umr_neg_iou_sums_stride(long P) { return P > 0 ? iou_stride(P) : 0; }
+
 int umr_neg_iou_forward(const float *predict, long predict_stride, const float *target, float *loss,
                         float *sums, int N, long P, void *stream) {
     if (!predict || !target || !loss || !sums || N <= 0 || P <= 0 || predict_stride < P) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (!umr_zero_async(sums, (size_t)N * 2 * sizeof(float), st)) return UMR_ERR_LAUNCH;
-    const int per_block = 8192;   // (few float atomics per image: the sums stay reproducible; 2048 was 10 us faster at B = 16, not bit-stable)
-    dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)N);
-    k_iou_partial<<<grid, 256, 0, st>>>(predict, predict_stride, target, sums, P, per_block);
-    k_iou_finalize<<<(N + 63) / 64, 64, 0, st>>>(sums, loss, N);
+    dim3 grid((unsigned)iou_blocks(P), (unsigned)N);
+    k_iou_partial<<<grid, 256, 0, st>>>(predict, predict_stride, target, sums, P);
+    k_iou_finalize<<<(N + 63) / 64, 64, 0, st>>>(sums, loss, N, P);
     return umr_launch_status();
 }
 

@@ -239,7 +239,7 @@ class NegIoUFunction(Function):
         t = _f32c(target).view(target.shape[0], -1)
         N, P = p.shape
         loss = torch.empty(N, device=p.device, dtype=torch.float32)
-        sums = torch.empty(N, 2, device=p.device, dtype=torch.float32)
+        sums = torch.empty(N, L.umr_neg_iou_sums_stride(P), device=p.device, dtype=torch.float32)
         _lib.check(L.umr_neg_iou_forward(ptr(p), P, ptr(t), ptr(loss), ptr(sums), N, P, _lib.stream_ptr(p.device)),
                    "umr_neg_iou_forward")
         ctx.save_for_backward(p, t, sums)
