@@ -441,7 +441,7 @@ int umr_flatten_forward(const float *x, const int *quads, float *loss, int B, in
     if (!x || !quads || !loss || B <= 0 || V <= 0 || E <= 0) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (!umr_zero_async(loss, (size_t)B * sizeof(float), st)) return UMR_ERR_LAUNCH;
-    dim3 g((E + 255) / 256, B);
+    dim3 g(1, B);   // one block per mesh (grid-stride over the edges): a single add into loss[b] -> bit-reproducible
     k_flatten<false><<<g, 256, 0, st>>>(x, quads, loss, nullptr, nullptr, V, E);
     return umr_launch_status();
 }
