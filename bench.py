@@ -220,7 +220,8 @@ def main():
     # stderr below) shows an ordinary, slowly falling loss and then NaN from one step on -- not a gradual divergence.  It
     # has only ever been seen with the network in the loop, in fresh processes: 12 000 hot-path-only steps in 8 processes
     # agree to 1 ulp (config.hot_path_loss_spread), and 180 fresh models trained for 45 steps each inside one process
-    # (tools/debug/nan_async.py with per-term tripwires, nan_plain.py without) never showed it, so its origin -- the fp32
+    # (tools/debug/nan_async.py with per-term tripwires, nan_plain.py without) never showed it, nor did the step run on
+    # NaN-poisoned memory (nan_poison.py: nothing reads what it did not write), so its origin -- the fp32
     # MIOpen / hipBLASLt network, this repo's 2x up-sampling kernels inside it, or a rare input to a render kernel -- is
     # not established.  After a NaN every render degenerates (NaN geometry) and the timing means nothing, so such a
     # measurement is discarded and repeated on a freshly initialised model (all ranks decide together); the number of
