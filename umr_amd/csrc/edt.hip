@@ -98,11 +98,14 @@ __global__ void k_edt_rows(const int *__restrict__ g, float *__restrict__ out, i
         if (sq_out) sq_out[o] = bo;
         if (sq_in) sq_in[o] = bi;
         const float diff = (sqrtf((float)bo) - sqrtf((float)bi)) * inv_max;
+        UMR_TRAP_IF(umr_bad(1.f / (1.f + expf(-k * diff))), 40);
         out[o] = 1.f / (1.f + expf(-k * diff));
     }
 }
 
 }  // namespace
+
+UMR_TRAP_ACCESSOR(umr_trap_read_edt)
 
 extern "C" {
 

@@ -53,6 +53,7 @@ __global__ void k_project_faces(const float *__restrict__ verts, const float *__
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float *v = verts + ((size_t)m * V + fi[c]) * 3;
+        UMR_TRAP_IF(umr_bad(v[0]) | umr_bad(v[1]) | umr_bad(v[2]) | umr_bad(cm.s) | umr_bad(cm.tx) | umr_bad(cm.w), 10);
         float r1, r2, r3;
         quat_rot(cm, v[0], v[1], v[2], r1, r2, r3);
         P[c * 3] = cm.s * r1 + cm.tx;
@@ -107,6 +108,7 @@ __global__ void k_scatter_face_grads(const float *__restrict__ g_out, const floa
     float g[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) g[k] = g_out[(size_t)i * 9 + k] + (g_pre ? g_pre[(size_t)i * 9 + k] : 0.f);
+    UMR_TRAP_IF(umr_bad(g[0]) | umr_bad(g[1]) | umr_bad(g[2]) | umr_bad(g[3]) | umr_bad(g[4]) | umr_bad(g[5]) | umr_bad(g[6]) | umr_bad(g[7]) | umr_bad(g[8]), 11);
     if (g_light) {
         const float *P = face_out + (size_t)i * 9;
         const float ax = P[0] - P[3], ay = P[1] - P[4], az = P[2] - P[5];
@@ -215,11 +217,14 @@ __global__ __launch_bounds__(256) void k_project_backward(const float *__restric
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const float s = block_sum(acc[k], smem);
+        UMR_TRAP_IF(threadIdx.x == 0 && umr_bad(s), 12);
         if (threadIdx.x == 0) grad_cams[(size_t)n * 7 + k] = k < 3 ? s : 2.f * q.s * s;
     }
 }
 
 }  // namespace
+
+UMR_TRAP_ACCESSOR(umr_trap_read_geometry)
 
 extern "C" {
 

@@ -45,6 +45,7 @@ __global__ void k_iou_finalize(float *__restrict__ sums, float *__restrict__ los
     for (int k = 0; k < nb; ++k) { I += row[2 + k]; U += row[2 + nb + k]; }
     U += 1e-6f;
     row[0] = I; row[1] = U;
+    UMR_TRAP_IF(umr_bad(I) | umr_bad(U), 20);
     loss[n] = 1.f - I / U;
 }
 
@@ -54,6 +55,7 @@ __global__ void k_iou_backward(const float *__restrict__ predict, long pstride, 
     const int n = blockIdx.y;
     const float *row = sums + (size_t)n * iou_stride(P);
     const float I = row[0], U = row[1], g = grad_loss[n];
+    UMR_TRAP_IF(umr_bad(g), 21);
     const float inv_u = 1.f / U, r = I * inv_u * inv_u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long)gridDim.x * blockDim.x) {
         const float t = target[(size_t)n * P + i];
@@ -151,6 +153,7 @@ __global__ void k_grid_sample_fwd(const float *__restrict__ image, const float *
         if (bne) v += ic[(size_t)y0 * W + x1] * ne;
         if (bsw) v += ic[(size_t)y1 * W + x0] * sw;
         if (bse) v += ic[(size_t)y1 * W + x1] * se;
+        UMR_TRAP_IF(umr_bad(v), 22);
         o[c] = v;
     }
 }
@@ -174,6 +177,7 @@ __global__ void k_grid_sample_bwd(const float *__restrict__ image, const float *
     float gix = 0.f, giy = 0.f;
     for (int c = 0; c < C; ++c) {
         const float gv = go[c];
+        UMR_TRAP_IF(umr_bad(gv), 23);
         const size_t co = (size_t)c * H * W;
         if (bnw) {
             const float v = img[co + (size_t)y0 * W + x0];
@@ -196,6 +200,7 @@ __global__ void k_grid_sample_bwd(const float *__restrict__ image, const float *
             if (gi) atomicAdd(&gi[co + (size_t)y1 * W + x1], wx * wy * gv);
         }
     }
+    UMR_TRAP_IF(umr_bad(gix) | umr_bad(giy), 24);
     if (grad_grid) {
         float *gg = grad_grid + ((size_t)b * P + p) * 2;
         gg[0] = gix * ((W - 1) / 2.f);
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(256) void k_laplacian_fwd(const float *__restrict__
         for (int k = s; k < e; ++k) { const float *u = xb + (size_t)nbr[k] * 3; sx += u[0]; sy += u[1]; sz += u[2]; }
         const float inv = e > s ? 1.f / (float)(e - s) : 0.f;
         const float lx = xb[v * 3] - sx * inv, ly = xb[v * 3 + 1] - sy * inv, lz = xb[v * 3 + 2] - sz * inv;
+        UMR_TRAP_IF(umr_bad(lx) | umr_bad(ly) | umr_bad(lz), 25);
         float *l = lap + ((size_t)b * V + v) * 3;
         l[0] = lx; l[1] = ly; l[2] = lz;
         acc += lx * lx + ly * ly + lz * lz;
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(256) void k_flatten(const float *__restrict__ x, co
         const FlatSide s2 = flat_side(a, sub(ld3(xb + (size_t)i3 * 3), v0), al2, al1, eps);
         const float nn = dot(s1.cb, s2.cb), dd = s1.cbl1 * s2.cbl1 + eps;
         const float cosd = nn / dd;
+        UMR_TRAP_IF(umr_bad(cosd), 26);
         if (!BWD) {
             acc += (cosd + 1.f) * (cosd + 1.f);
         } else {
@@ -344,6 +351,8 @@ __global__ void k_visible_mask(const float *__restrict__ ids, float *__restrict_
 }
 
 }  // namespace
+
+UMR_TRAP_ACCESSOR(umr_trap_read_losses)
 
 extern "C" {
 
@@ -487,6 +496,7 @@ __global__ void k_upsample2x_fwd(const float *__restrict__ in, float *__restrict
     up2_taps((int)oy, H, y0, y1, wy);
     const float *s = in + (size_t)blockIdx.y * H * W;
     const float a = s[y0 * W + x0], b = s[y0 * W + x1], c = s[y1 * W + x0], d = s[y1 * W + x1];
+    UMR_TRAP_IF(umr_bad(a), 27);
     out[(size_t)blockIdx.y * OH * OW + i] = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
 }
 
@@ -510,6 +520,7 @@ __global__ void k_upsample2x_bwd(const float *__restrict__ gout, float *__restri
             acc += cy * cx * g[oy * OW + ox];
         }
     }
+    UMR_TRAP_IF(umr_bad(acc), 28);
     gin[(size_t)blockIdx.y * H * W + i] = acc;
 }
 }  // namespace

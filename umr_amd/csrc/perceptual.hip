@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void k_cos_forward(const CosArgs A, float *__r
             const float x = a[(size_t)c * P], y = b[(size_t)c * P];
             s00 = fmaf(x, x, s00); s11 = fmaf(y, y, s11); s01 = fmaf(x, y, s01);
         }
+        UMR_TRAP_IF(umr_bad(s00) | umr_bad(s11), 30);
     }
     s_part[wave][0][lane] = s00; s_part[wave][1][lane] = s11; s_part[wave][2][lane] = s01;
     __syncthreads();
@@ -73,6 +74,7 @@ __global__ void k_cos_finalize(const CosArgs A, const float *__restrict__ partia
         for (int k = 0; k < used; ++k) s += partial[((size_t)t * A.N + n) * A.chunks + k];
         v += 1.f - s / (float)A.tap[t].P;
     }
+    UMR_TRAP_IF(umr_bad(v), 31);
     val[n] = v;
 }
 
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void k_cos_backward(const CosArgs A, const flo
     for (int j = 0; j < PER; ++j) {
         const int c = c0 + wave + 4 * j;
         if (c < C) {
+            UMR_TRAP_IF(umr_bad(k * (y[j] - m0 * x[j])), 32);
             if (g0) g0[(size_t)c * P] = k * (y[j] - m0 * x[j]);
             if (g1) g1[(size_t)c * P] = k * (x[j] - m1 * y[j]);
         }
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256) void k_pp_forward(const float *__restrict__ im
     for (int c = 0; c < C; ++c) {
         const size_t i = (b * C + c) * HW + p;
         const float x1 = img[i] * m;
+        UMR_TRAP_IF(umr_bad(x1), 33);
         const float x2 = 2.f * x1 - 1.f;
         out[i] = (x2 - sh[c % 3]) / sc[c % 3];
     }
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(256) void k_pp_backward(const float *__restrict__ g
     for (int c = 0; c < C; ++c) {
         const size_t i = (b * C + c) * HW + p;
         const float g1 = 2.f * (gout[i] / sc[c % 3]);
+        UMR_TRAP_IF(umr_bad(g1), 34);
         if (gimg) gimg[i] = g1 * m;
         gm += g1 * img[i];
     }
@@ -414,6 +419,8 @@ __global__ __launch_bounds__(256) void k_part_backward(const PartArgs A) {
 int part_chunks(int HW) { return max(1, min(64, (HW + 1023) / 1024)); }
 
 }  // namespace
+
+UMR_TRAP_ACCESSOR(umr_trap_read_perceptual)
 
 extern "C" {
 

@@ -89,6 +89,21 @@ struct ProfScope {  // brackets exactly one kernel launch on `st`
 
 }  // namespace
 
+UMR_TRAP_ACCESSOR(umr_trap_read_raster)
+#if UMR_TRAP
+extern "C" unsigned long long umr_trap_read_geometry(int), umr_trap_read_losses(int), umr_trap_read_perceptual(int), umr_trap_read_edt(int);
+// earliest non-finite report of the whole library: site id (0 = none), *when = its device wall-clock stamp
+extern "C" int umr_debug_trap(int reset, unsigned long long *when) {
+    (void)hipDeviceSynchronize();
+    unsigned long long best = ~0ull;
+    const unsigned long long v[5] = {umr_trap_read_raster(reset), umr_trap_read_geometry(reset), umr_trap_read_losses(reset),
+                                     umr_trap_read_perceptual(reset), umr_trap_read_edt(reset)};
+    for (int i = 0; i < 5; ++i) best = v[i] < best ? v[i] : best;
+    if (when) *when = best >> 8;
+    return best == ~0ull ? 0 : (int)(best & 0xff);
+}
+#endif
+
 extern "C" {
 
 const char *umr_version(void) { return "umr_hip 0.2 gfx950"; }

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                             if (zq < c_near || zq > c_far) continue;  // :592
                         }
                         const float ga = (pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
+                        UMR_TRAP_IF(umr_bad(ga), 3);
                         const float oa = ld_u(sc_n, pn4);
                         float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
                         c_a *= p.frag * (1.f - p.frag) * (-c_nis);
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                     const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
                                 g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
                     const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
+                    UMR_TRAP_IF(umr_bad(g0) | umr_bad(g1) | umr_bad(g2) | umr_bad(g3), 3);
                     const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
                     float c_xy = 0.f;
                     if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
             const float sv = wave_sum_full(gv[k]);
             if (lane == k) mine = sv;
         }
+        UMR_TRAP_IF(umr_bad(mine), 4);
         if (live && lane < 9) A.grad_faces[((size_t)n * F + f) * 9 + lane] += mine;
     }
     if (NEED_GT) {
@@ -589,6 +592,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                     float acc = wave_tex[j];
 #pragma unroll
                     for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
+                    UMR_TRAP_IF(umr_bad(acc), 4);
                     dst[j] += acc;
                 }
             }

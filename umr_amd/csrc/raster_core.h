@@ -77,6 +77,7 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     if (i >= total) return;
     const float *f = faces + (size_t)i * 9;
     const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
+    UMR_TRAP_IF(umr_bad(x0) | umr_bad(y0) | umr_bad(z0) | umr_bad(x1) | umr_bad(y1) | umr_bad(z1) | umr_bad(x2) | umr_bad(y2) | umr_bad(z2), 1);
     float adj[9] = {y1 - y2, x2 - x1, x1 * y2 - x2 * y1,
                     y2 - y0, x0 - x2, x2 * y0 - x0 * y2,
                     y0 - y1, x1 - x0, x0 * y1 - x1 * y0};

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
         return;
     }
     const float o3 = 1.f - alpha;
+    UMR_TRAP_IF(t.valid && umr_bad(o3), 2);
     if (RGB == 2) {
         if (t.valid) A.soft_colors[(size_t)t.n * npix + pn] = o3;
         if (A.pooled) {
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
     float o0, o1, o2;
     if (RGB == 0) { o0 = c0; o1 = c1; o2 = c2; }
     else { o0 = c0 / ssum; o1 = c1 / ssum; o2 = c2 / ssum; }
+    UMR_TRAP_IF(t.valid && (umr_bad(o0) | umr_bad(o1) | umr_bad(o2) | umr_bad(ssum) | umr_bad(smax)), 2);
     if (t.valid) {
         float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
         if (RGB == 1 || face_min != -1 || A.bg_arg) { sc[0] = o0; sc[npix] = o1; sc[2 * npix] = o2; }

@@ -62,3 +62,37 @@ static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {   // 
     umr_k_zero<<<blocks, 256, 0, st>>>((unsigned *)p, words);
     return hipGetLastError() == hipSuccess;
 }
+
+// ---- non-finite tripwire (debug builds only: -DUMR_TRAP=1, tools/debug/bench_trap.py) -----------------------------------
+// Kernels report the FIRST non-finite value they read or write without adding a launch or a host synchronisation: one
+// 64-bit word per translation unit holds min over reports of (device wall clock << 8 | site id); umr_debug_trap() returns
+// the earliest site of all translation units.  Compiled out of the product build (UMR_TRAP undefined).
+#ifndef UMR_TRAP
+#define UMR_TRAP 0
+#endif
+#if UMR_TRAP
+static __device__ unsigned long long g_umr_trap = ~0ull;
+__device__ __forceinline__ bool umr_bad(float x) { return !(fabsf(x) <= 3.0e38f); }   // NaN or inf
+__device__ __forceinline__ void umr_trap(bool nonfinite, unsigned site) {
+    if (nonfinite) atomicMin(&g_umr_trap, ((unsigned long long)wall_clock64() << 8) | (unsigned long long)(site & 0xffu));
+}
+#define UMR_TRAP_IF(cond, site) umr_trap((cond), (site))
+#define UMR_TRAP_ACCESSOR(name)                                                                              \
+    extern "C" unsigned long long name(int reset) {                                                          \
+        unsigned long long v = ~0ull;                                                                        \
+        (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_umr_trap), sizeof(v), 0, hipMemcpyDeviceToHost);          \
+        if (reset) { const unsigned long long z = ~0ull;                                                     \
+                     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_umr_trap), &z, sizeof(z), 0, hipMemcpyHostToDevice); } \
+        return v;                                                                                            \
+    }
+#else
+#define UMR_TRAP_IF(cond, site) ((void)0)
+#define UMR_TRAP_ACCESSOR(name)
+__device__ __forceinline__ bool umr_bad(float) { return false; }
+#endif
+// site ids: 1 raster face setup: non-finite vertex in | 2 raster forward: non-finite pixel out | 3 raster backward: non-finite
+// incoming gradient | 4 raster backward: non-finite gradient out | 10 projection: vertex / camera in | 11 projection backward:
+// incoming gradient | 12 projection backward: gradient out | 20 IoU loss out | 21 IoU backward incoming | 22 grid-sample out |
+// 23 grid-sample backward incoming | 24 grid-sample backward out | 25 Laplacian in | 26 flatten in | 27 up-sampling in |
+// 28 up-sampling backward incoming | 30 PNet head: feature in | 31 PNet head: value out | 32 PNet backward: gradient out |
+// 33 perceptual prologue in | 34 perceptual prologue backward incoming | 40 distance transform out
