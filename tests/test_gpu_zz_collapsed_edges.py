@@ -1,0 +1,62 @@
+"""GPU: faces with an edge seen end-on.  Below ~3e-4 screen units an edge loses its squared length in the cancellation of
+soft_rasterize_cuda_kernel.cu:82-84 (den = a0[v0] - a0[v1] comes out as exactly 0 about every second time), so the edge
+parameter of :86 is inf or NaN.  The reference's inside branch is immune (it keeps the smallest distance over the three edge
+lines with `dis < dis_min`, false for NaN / inf); a kernel that picks the edge first and evaluates only that one is not --
+this is what turned one training run in twenty into NaN (tripwire build).  Here: 64 such faces, each
+built around a pixel centre so that the pixel lies (up to rounding) inside the triangle and nearest to the collapsed edge."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+f32 = np.float32
+
+
+def _den_collapsed(pa, pb, pc):
+    """den of edge (0, 1) exactly as k_face_setup / the reference compute it (fp32, :236-238, :82-84)"""
+    px, py = [pa[0], pb[0], pc[0]], [pa[1], pb[1], pc[1]]
+    sym = [[f32(f32(f32(px[j] * px[k]) + f32(py[j] * py[k])) + f32(1)) for k in range(3)] for j in range(3)]
+    a = [f32(sym[0][j] - sym[1][j]) for j in range(3)]
+    return f32(a[0] - a[1])
+
+
+def collapsed_edge_faces(IS, count, seed=0):
+    rng = np.random.default_rng(seed)
+    faces, pixels = [], []
+    while len(faces) < count:
+        i, j = int(rng.integers(8, IS - 8)), int(rng.integers(8, IS - 8))
+        P = np.array([(2 * i + 1 - IS) / IS, (2 * j + 1 - IS) / IS], np.float64)
+        d, e = rng.uniform(1e-5, 4e-5), rng.uniform(5e-7, 2e-6)
+        A = (P + [-d, -e]).astype(f32)
+        B = (P + [+d, -e]).astype(f32)
+        C = (P + [rng.uniform(-0.01, 0.01), rng.uniform(0.03, 0.08)]).astype(f32)
+        if _den_collapsed(A, B, C) != 0:
+            continue
+        faces.append([[A[0], A[1], 7.5], [B[0], B[1], 7.6], [C[0], C[1], 7.7]])
+        pixels.append((i, j))
+    return np.asarray(faces, np.float32), pixels
+
+
+def test_collapsed_edges_stay_finite_and_follow_the_reference(oracle_built):
+    from oracle import softras
+    from umr_amd import functional as UF
+    IS = 64
+    fv_np, pixels = collapsed_edge_faces(IS, 64)
+    tex_np = np.random.default_rng(1).random((1, 64, 4, 3), dtype=np.float32)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(np.log(1. / 1e-10 - 1.)), gamma_val=1e-4,
+               func_id_rgb=1, double_side=True)
+    ref = softras.raster_forward(fv_np[None].reshape(1, 64, 9), tex_np, IS, background=(0.1, 0.2, 0.3), backend="port", **cfg)
+    assert np.isfinite(ref["soft_colors"]).all()                       # the reference's algorithm is immune
+    fv = torch.from_numpy(fv_np[None]).to(DEV).requires_grad_(True)
+    tex = torch.from_numpy(tex_np).to(DEV).requires_grad_(True)
+    sc, p2f, aggr = UF.soft_rasterize(fv, tex, IS, [0.1, 0.2, 0.3], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax')
+    sc.sum().backward()
+    alpha = UF.SilhouetteFunction.apply(fv.detach(), IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, False)
+    for name, t in (("soft_colors", sc), ("aggrs_info", aggr), ("p2f", p2f), ("alpha", alpha), ("grad_faces", fv.grad),
+                    ("grad_textures", tex.grad)):
+        assert bool(torch.isfinite(t).all()), name + " has non-finite values"
+    # the render follows the reference's (same smallest-finite-distance choice); the barycentrics of such needles carry ~1e-3
+    # of rounding noise, so whether a pixel counts as inside is itself noise -- a few pixels may differ, none may be wild
+    err = np.abs(sc.detach().cpu().numpy() - ref["soft_colors"])
+    assert (err <= 1e-4).mean() >= 0.98, (float((err <= 1e-4).mean()), float(err.max()))

@@ -296,21 +296,46 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
     kout = ((m == m_ob) & ovr) ? k_ob : kout;
     const int ksel = inside ? kin : kout;
     const bool kvalid = ksel >= 0;  // k = -1: reference UB (index -1); defined here and in the oracle as "skip"
-    const int k = max(ksel, 0);
     // t[v0] = (w . a - a[v1]) / (a[v0] - a[v1]) in the reference's operation order (:86,:137); IEEE-exact
     // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
     // D ~ exp(-d^2/sigma) ~ 1e-9, amplifying rounding noise in d^2 ~20x: parity there needs the reference's
     // own noise, i.e. its own arithmetic, not just the same formula.
-    const unsigned ko = (unsigned)k * 32u;
-    const float4 ea = ld_u4(fc.edges, ko), eb = ld_u4(fc.edges, ko + 16u);  // {a0,a1,a2,a[v1]}, {den, 1/den, -, -}
-    const float tv = div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
+    auto edge_param = [&](int kk) {   // {a0,a1,a2,a[v1]}, {den, 1/den, -, -} of edge kk -> t[v0]
+        const unsigned ko = (unsigned)kk * 32u;
+        const float4 ea = ld_u4(fc.edges, ko), eb = ld_u4(fc.edges, ko + 16u);
+        return div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
+    };
+    int k = max(ksel, 0);
+    float tv = edge_param(k);
+    // An edge whose screen-space length is below ~3e-4 (an edge seen end-on) loses its squared length in the cancellation of
+    // :82-84 -- den comes out as exactly 0 about every second time -- and t[v0] is then inf or NaN.  Outside the triangle the
+    // clamp below absorbs that, as in the reference.  INSIDE, the reference evaluates all three edge lines and keeps the
+    // smallest distance with `dis < dis_min` (:99), which is false for NaN and inf: a collapsed edge is simply never the
+    // winner.  Here the edge was picked beforehand (by its line distance m), so it has to be skipped explicitly -- next
+    // edge by line distance; with no usable edge the reference ends with dis_x = dis_y = 0 (:72-73,:105-106).
+    bool no_edge = false;
+    if (__any(inside & !(fabsf(tv) <= 3.0e38f))) {   // rare: not on the visit's critical path
+        if (inside & !(fabsf(tv) <= 3.0e38f)) {
+            const float mk[3] = {m0, m1, m2};
+            int ka = k == 0 ? 1 : 0, kb = k == 2 ? 1 : 2;
+            if (mk[kb] < mk[ka]) { const int s_ = ka; ka = kb; kb = s_; }
+            float ta = edge_param(ka);
+            if (fabsf(ta) <= 3.0e38f) { k = ka; tv = ta; }
+            else {
+                ta = edge_param(kb);
+                if (fabsf(ta) <= 3.0e38f) { k = kb; tv = ta; }
+                else { no_edge = true; tv = 0.f; }
+            }
+        }
+    }
     const bool k0 = k == 0, k1 = k == 1;
     const float tb = 1.f - tv;
     const float ba = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f);  // unclamped inside (:86-88), clamped outside (:142-145)
     const float bb = inside ? tb : fminf(fmaxf(tb, 0.f), 1.f);
-    const float b0 = k0 ? ba : (k1 ? 0.f : bb);
-    const float b1 = k0 ? bb : (k1 ? ba : 0.f);
-    const float b2 = k0 ? 0.f : (k1 ? bb : ba);
+    float b0 = k0 ? ba : (k1 ? 0.f : bb);
+    float b1 = k0 ? bb : (k1 ? ba : 0.f);
+    float b2 = k0 ? 0.f : (k1 ? bb : ba);
+    if (no_edge) { b0 = w0; b1 = w1; b2 = w2; }   // closest point := the pixel itself -> dis_x = dis_y = 0
     const float t0 = b0 - w0, t1 = b1 - w1, t2 = b2 - w2;
     const float dx = (t0 * fc.template xy<0>() + t1 * fc.template xy<2>()) + t2 * fc.template xy<4>();  // :95-96, :148-149
     const float dy = (t0 * fc.template xy<1>() + t1 * fc.template xy<3>()) + t2 * fc.template xy<5>();
