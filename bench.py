@@ -216,16 +216,12 @@ def main():
         measure.history = history
         return loss, host_dt, time.perf_counter() - t0
 
-    # About one full-step measurement in 20 ends with a non-finite loss: the per-step history of such a run (printed to
-    # stderr below) shows an ordinary, slowly falling loss and then NaN from one step on -- not a gradual divergence.  It
-    # has only ever been seen with the network in the loop, in fresh processes: 12 000 hot-path-only steps in 8 processes
-    # agree to 1 ulp (config.hot_path_loss_spread), and 180 fresh models trained for 45 steps each inside one process
-    # (tools/debug/nan_async.py with per-term tripwires, nan_plain.py without) never showed it, nor did the step run on
-    # NaN-poisoned memory (nan_poison.py: nothing reads what it did not write), so its origin -- the fp32
-    # MIOpen / hipBLASLt network, this repo's 2x up-sampling kernels inside it, or a rare input to a render kernel -- is
-    # not established.  After a NaN every render degenerates (NaN geometry) and the timing means nothing, so such a
-    # measurement is discarded and repeated on a freshly initialised model (all ranks decide together); the number of
-    # discarded attempts is reported in config.discarded_nonfinite_runs.
+    # A measurement that ends with a non-finite loss is discarded and repeated on a freshly initialised model (all ranks decide
+    # together; config.discarded_nonfinite_runs counts them, the per-step loss history goes to stderr): after a NaN every
+    # render degenerates (NaN geometry) and the timing means nothing.  Round 2 saw one such process in ~20; the cause -- a face
+    # edge seen end-on makes the reference's own `den` exactly 0, and the inside branch of eval_pair did not skip that edge the
+    # way the reference's min-over-edges does -- is fixed (tests/test_gpu_zz_collapsed_edges.py); the
+    # guard stays.
     discarded = 0
     while True:
         loss, host_dt, dt = measure()

@@ -12,8 +12,8 @@ python bench.py --model 0 --cpu-baseline 0 --graph 1 > "$O/bench_hotpath_graph.j
 python bench.py --workload s2 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
 # the SAME command as the bench line above (default warm-up / steps / profile pass, CPU leg off): the library's HIP events
 # bracket the raster kernels of the last 5 steps (the profile pass), so rocprofv3's last 5 dispatches are the same steps
-# (about one full-step run in 20 hits a NaN, DESIGN.md section 5 'known open issue', and bench.py then repeats the measurement
-# on a fresh model -- a profile that contains such a discarded run is thrown away and taken again)
+# (should bench.py ever discard a diverged measurement -- DESIGN.md section 5 -- and repeat it on a fresh model, a profile
+# that contains the discarded run is thrown away and taken again)
 for attempt in 1 2 3; do
   rm -rf "$O/stats"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o t -- python "$R/bench.py" --cpu-baseline 0 > "$O/stats.log" 2>&1)
