@@ -271,3 +271,31 @@ def test_texture_atlas_and_obj_text_vs_reference_golden(oracle_built):
     if S.have_backend("ref"):
         b, _ = S.create_texture_image(g["textures"], 16, backend="ref")
         assert np.array_equal(img, b)
+
+
+def test_reference_algorithm_is_immune_to_collapsed_edges(oracle_built):
+    """An edge seen end-on: `den` of soft_rasterize_cuda_kernel.cu:86 is exactly 0 (fp32 cancellation in :82-84), the edge
+    parameter inf / NaN.  The reference's inside branch never selects such an edge (`dis < dis_min` is false for NaN / inf),
+    its outside branch clamps: the restatement -- and the reference kernels themselves where they were built -- render the
+    crafted faces of tests/test_gpu_zz_collapsed_edges.py without a single non-finite value.  (The GPU test holds the
+    product kernels to the same.)"""
+    import os
+    from oracle import softras
+    from test_gpu_zz_collapsed_edges import collapsed_edge_faces, _den_collapsed
+    fv, _ = collapsed_edge_faces(64, 64)
+    assert all(_den_collapsed(f[0, :2], f[1, :2], f[2, :2]) == 0 for f in fv)
+    tex = np.random.default_rng(1).random((1, 64, 4, 3), dtype=np.float32)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(np.log(1. / 1e-10 - 1.)), gamma_val=1e-4,
+               func_id_rgb=1, double_side=True)
+    backends = ["port"] + (["ref"] if os.path.exists(os.path.join(os.path.dirname(softras.__file__), "_ref", "libsoftras_ref.so")) else [])
+    outs = []
+    for be in backends:
+        o = softras.raster_forward(fv.reshape(1, 64, 9), tex, 64, background=(0.1, 0.2, 0.3), backend=be, **cfg)
+        assert np.isfinite(o["soft_colors"]).all() and np.isfinite(o["aggrs_info"]).all(), be
+        gsc = np.ones((1, 4, 64, 64), np.float32)
+        gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"], gsc, 64,
+                                         backend=be, **cfg)
+        outs.append(o["soft_colors"])
+        assert np.isfinite(gt).all(), be      # (grad_faces may legitimately be huge for needles; texel gradients are weights)
+    if len(outs) == 2:
+        assert np.array_equal(outs[0], outs[1])
