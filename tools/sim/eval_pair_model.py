@@ -45,7 +45,7 @@ def face_setup(fv):
     return dict(x=x, y=y, inv=inv, K=K, edges=edges, obt=obt, ox=ox.astype(f32), oy=oy.astype(f32))
 
 
-def eval_pair(rec, xp, yp, thr, threshold, nis, fallback=True):
+def eval_pair(rec, xp, yp, thr, threshold, nis, fallback=True, exact3_below=0.0):
     """rec: face_setup of n faces; xp, yp [P] pixel centres -> (live [n,P] bool, frag [n,P] f32, nonfinite_tv [n,P] bool)"""
     n = len(rec["x"]); X = xp[None, :].astype(f32); Y = yp[None, :].astype(f32)
     x, y, inv, K = rec["x"], rec["y"], rec["inv"], rec["K"]
@@ -96,6 +96,26 @@ def eval_pair(rec, xp, yp, thr, threshold, nis, fallback=True):
             k = np.where(bad & oka, ka, np.where(bad & ~oka & okb, kb, k))
             tv = np.where(bad & oka, ta, np.where(bad & ~oka & okb, tb_, np.where(bad, f32(0), tv))).astype(f32)
             no_edge = bad & ~oka & ~okb
+        if exact3_below > 0:
+            # faces with an ill-conditioned edge (|den| below the bound): the reference's own inside evaluation -- all three
+            # edge lines, smallest computed distance with `<` in the order k = 0, 1, 2 (:78-107)
+            flagged = (np.abs(E[:, :, 4]).min(1) < exact3_below)[:, None] & inside
+            if flagged.any():
+                dmin = np.full(tv.shape, f32(1e8)); kbest = np.full(tv.shape, -1); tbest = np.zeros(tv.shape, f32)
+                for kk in range(3):
+                    tk = edge_param(np.full(tv.shape, kk))
+                    bk = [np.where(kk == 0, tk, np.where(kk == 1, f32(0), f32(1) - tk)), np.where(kk == 0, f32(1) - tk, np.where(kk == 1, tk, f32(0))),
+                          np.where(kk == 0, f32(0), np.where(kk == 1, f32(1) - tk, tk))]
+                    tt = [(bk[i].astype(f32) - w[i]).astype(f32) for i in range(3)]
+                    ddx = (((tt[0] * x[:, 0, None]).astype(f32) + (tt[1] * x[:, 1, None]).astype(f32)).astype(f32) + (tt[2] * x[:, 2, None]).astype(f32)).astype(f32)
+                    ddy = (((tt[0] * y[:, 0, None]).astype(f32) + (tt[1] * y[:, 1, None]).astype(f32)).astype(f32) + (tt[2] * y[:, 2, None]).astype(f32)).astype(f32)
+                    dk = ((ddx * ddx).astype(f32) + (ddy * ddy).astype(f32)).astype(f32)
+                    better = dk < dmin
+                    dmin = np.where(better, dk, dmin); kbest = np.where(better, kk, kbest); tbest = np.where(better, tk, tbest)
+                k = np.where(flagged & (kbest >= 0), kbest, k)
+                tv = np.where(flagged & (kbest >= 0), tbest, tv).astype(f32)
+                no_edge = np.where(flagged, kbest < 0, no_edge)
+                tv = np.where(no_edge, f32(0), tv).astype(f32)
         tb = (f32(1) - tv).astype(f32)
         ba = np.where(inside, tv, np.minimum(np.fmax(tv, f32(0)), f32(1)))
         bb = np.where(inside, tb, np.minimum(np.fmax(tb, f32(0)), f32(1)))
