@@ -164,6 +164,10 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         float *eb = r + R_EDGE + 8 * e;
         eb[0] = a[0]; eb[1] = a[1]; eb[2] = a[2]; eb[3] = a[e1];
         eb[4] = den; eb[5] = 1.f / den; eb[6] = 0.f; eb[7] = 0.f;
+        // bit 4: some edge is shorter than ~3e-3 screen units (0.8 px at IS = 512): its `den` -- a squared length obtained
+        // by cancellation of O(1) terms -- is rounding noise, possibly exactly 0.  eval_pair then evaluates the inside
+        // branch the reference's way (all three edge lines, smallest computed distance).  NaN den: flagged as well.
+        if (!(fabsf(den) >= 1e-5f)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
     }
 #pragma unroll
     for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
@@ -211,6 +215,7 @@ struct Face {  // wave-uniform: 32 SGPRs + the record's address
     __device__ __forceinline__ bool front() const { return g<R_FRONT>() != 0.f; }
     __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
     __device__ __forceinline__ bool depth_in_range() const { return (__float_as_int(g<R_FLAGS>()) & 8) != 0; }
+    __device__ __forceinline__ bool ill_conditioned() const { return (__float_as_int(g<R_FLAGS>()) & 16) != 0; }
 };
 
 struct FaceV : Face {   // + 15 VGPRs per lane, filled once per face by the face-major backward (a wave owns one face)
@@ -300,32 +305,43 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
     // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
     // D ~ exp(-d^2/sigma) ~ 1e-9, amplifying rounding noise in d^2 ~20x: parity there needs the reference's
     // own noise, i.e. its own arithmetic, not just the same formula.
-    auto edge_param = [&](int kk) {   // {a0,a1,a2,a[v1]}, {den, 1/den, -, -} of edge kk -> t[v0]
+    auto edge_param = [&](int kk) {   // {a0,a1,a2,a[v1]}, {den, 1/den, -, -} of edge kk -> t[v0] = num / den (:86,:137)
         const unsigned ko = (unsigned)kk * 32u;
         const float4 ea = ld_u4(fc.edges, ko), eb = ld_u4(fc.edges, ko + 16u);
-        return div_r(((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w, eb.x, eb.y);
+        const float num = ((w0 * ea.x + w1 * ea.y) + w2 * ea.z) - ea.w;
+        // den = 0 (see below): the IEEE quotient is +-inf (NaN for 0 / 0); Markstein's correction would turn inf into NaN
+        return fabsf(eb.y) <= 3.0e38f ? div_r(num, eb.x, eb.y) : num * eb.y;
     };
     int k = max(ksel, 0);
     float tv = edge_param(k);
     // An edge whose screen-space length is below ~3e-4 (an edge seen end-on) loses its squared length in the cancellation of
-    // :82-84 -- den comes out as exactly 0 about every second time -- and t[v0] is then inf or NaN.  Outside the triangle the
-    // clamp below absorbs that, as in the reference.  INSIDE, the reference evaluates all three edge lines and keeps the
-    // smallest distance with `dis < dis_min` (:99), which is false for NaN and inf: a collapsed edge is simply never the
-    // winner.  Here the edge was picked beforehand (by its line distance m), so it has to be skipped explicitly -- next
-    // edge by line distance; with no usable edge the reference ends with dis_x = dis_y = 0 (:72-73,:105-106).
+    // :82-84 -- den comes out as exactly 0 about every second time, as noise otherwise -- and t[v0] is inf, NaN or garbage.
+    // Outside the triangle the clamp below absorbs that exactly as in the reference.  INSIDE, the reference evaluates all
+    // three edge lines and keeps the smallest COMPUTED distance with `dis < dis_min` (:78-107) -- false for NaN and inf, so a
+    // collapsed edge is never the winner, and among garbage distances the smallest garbage wins.  Picking the edge
+    // beforehand by its true line distance (above) is equivalent only while the three `den` are well conditioned; faces
+    // flagged by k_face_setup (wave-uniform) take the reference's own route here.  With no usable edge the reference ends
+    // with dis_x = dis_y = 0 (:72-73,:105-106).
     bool no_edge = false;
-    if (__any(inside & !(fabsf(tv) <= 3.0e38f))) {   // rare: not on the visit's critical path
-        if (inside & !(fabsf(tv) <= 3.0e38f)) {
-            const float mk[3] = {m0, m1, m2};
-            int ka = k == 0 ? 1 : 0, kb = k == 2 ? 1 : 2;
-            if (mk[kb] < mk[ka]) { const int s_ = ka; ka = kb; kb = s_; }
-            float ta = edge_param(ka);
-            if (fabsf(ta) <= 3.0e38f) { k = ka; tv = ta; }
-            else {
-                ta = edge_param(kb);
-                if (fabsf(ta) <= 3.0e38f) { k = kb; tv = ta; }
-                else { no_edge = true; tv = 0.f; }
+    if (fc.ill_conditioned()) {
+        if (inside) {
+            float dmin = 100000000.f;
+            int kb = -1;
+            float tbest = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const float tk = edge_param(kk), uk = 1.f - tk;
+                const float c0 = kk == 0 ? tk : (kk == 1 ? 0.f : uk), c1 = kk == 0 ? uk : (kk == 1 ? tk : 0.f),
+                            c2 = kk == 0 ? 0.f : (kk == 1 ? uk : tk);
+                const float s0 = c0 - w0, s1 = c1 - w1, s2 = c2 - w2;
+                const float ex = (s0 * fc.template xy<0>() + s1 * fc.template xy<2>()) + s2 * fc.template xy<4>();
+                const float ey = (s0 * fc.template xy<1>() + s1 * fc.template xy<3>()) + s2 * fc.template xy<5>();
+                const float dk = ex * ex + ey * ey;
+                if (dk < dmin) { dmin = dk; kb = kk; tbest = tk; }
             }
+            no_edge = kb < 0;
+            k = no_edge ? 0 : kb;
+            tv = no_edge ? 0.f : tbest;
         }
     }
     const bool k0 = k == 0, k1 = k == 1;

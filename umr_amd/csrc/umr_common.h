@@ -1,6 +1,8 @@
 // umr_common.h -- shared device helpers for libumr_hip.so (gfx950 / CDNA4 only, wave64).
 #pragma once
+#ifndef UMR_HOST_SHIM          // tests/host_kernel/device_shim.h compiles this source for the host (test infrastructure)
 #include <hip/hip_runtime.h>
+#endif
 #include <stddef.h>
 #include "../../include/umr_hip.h"
 
@@ -55,6 +57,7 @@ __device__ __forceinline__ float block_sum(float v, float *smem /* >= 16 floats 
 static __global__ void umr_k_zero(unsigned *__restrict__ p, size_t words) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
+#ifndef UMR_HOST_SHIM
 static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {   // bytes: multiple of 4, p 4-byte aligned
     const size_t words = bytes / 4;
     if (!words) return true;
@@ -62,6 +65,7 @@ static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {   // 
     umr_k_zero<<<blocks, 256, 0, st>>>((unsigned *)p, words);
     return hipGetLastError() == hipSuccess;
 }
+#endif
 
 // ---- non-finite tripwire (debug builds only: -DUMR_TRAP=1, tools/debug/bench_trap.py) -----------------------------------
 // Kernels report the FIRST non-finite value they read or write without adding a launch or a host synchronisation: one
