@@ -2,7 +2,9 @@
 umr_amd/csrc/raster_core.h -- fuzzed on the CPU against the oracle (the reference's algorithm): one face per mesh, so a
 mesh's alpha plane is that face's soft fragment D per pixel (0 where the pair is rejected).  Finds classes of faces on which
 the product's pick-the-edge-first formulation and the reference's evaluate-all-three formulation disagree, or where the
-former is not finite -- without a GPU.  (Test infrastructure; the product never imports it.)
+former is not finite -- without a GPU.  (Test infrastructure; the product never imports it.  It was the design sketch for the
+ill-conditioned-face rule now in eval_pair -- `exact3_below=1e-5` is the shipped behaviour; since then the kernel source
+itself is fuzzed on the host, tests/test_kernel_source_on_host.py.)
 
 usage: python tools/sim/eval_pair_model.py [meshes_per_case]
 """
