@@ -33,4 +33,28 @@ int host_pairs(const float *faces, int n, const float *xp, const float *yp, int 
     return 0;
 }
 
+// the conservative tile-vs-dilated-triangle test both raster directions cull with: 1 = "some pixel of the tile may survive"
+// tiles: [ntiles,4] = (cx, cy, hx, hy) centre and half extent of the tile's pixel-centre rectangle
+int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles, float thr, unsigned char *out) {
+    float *rec = new float[(size_t)n * REC];
+    float4 *bbox = new float4[n];
+    blockDim.x = 1;
+    for (int i = 0; i < n; ++i) {
+        blockIdx.x = (unsigned)i; threadIdx.x = 0;
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+    }
+    for (int i = 0; i < n; ++i) {
+        const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_INV);
+        const float4 bb = bbox[i];
+        for (int t = 0; t < ntiles; ++t) {
+            const float cx = tiles[4 * t], cy = tiles[4 * t + 1], hx = tiles[4 * t + 2], hy = tiles[4 * t + 3];
+            bool hit = !(cx - hx > bb.y || cx + hx < bb.x || cy - hy > bb.w || cy + hy < bb.z);   // the kernels' bbox test first
+            if (hit) hit = tile_may_hit(q[0], q[1], q[2], cx, cy, hx, hy, thr);
+            out[(size_t)i * ntiles + t] = hit ? 1 : 0;
+        }
+    }
+    delete[] rec; delete[] bbox;
+    return 0;
+}
+
 }

@@ -32,6 +32,8 @@ def host_lib():
     P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     h.host_pairs.argtypes = [P, I, P, P, I, F, F, F, F, F, P, P, P, P]
     h.host_pairs.restype = I
+    h.host_tile_may_hit.argtypes = [P, I, P, I, F, P]
+    h.host_tile_may_hit.restype = I
     return h
 
 
@@ -82,3 +84,34 @@ def test_kernel_pair_geometry_on_host_vs_oracle(host_lib, oracle_built):
         report[name] = (int((err > 1e-4).sum()), int((ra > 0).sum()))
     for name, (bad, live) in report.items():   # every class, needles and sub-pixel faces included: the reference's render up to
         assert bad <= 2, (name, bad, live)     # a tie or two between two nearest edges
+
+
+def test_tile_culling_of_the_kernel_source_is_conservative(host_lib):
+    """The bbox + tile_may_hit test that forward and backward cull with (raster_core.h) must not drop a tile in which some
+    pixel contributes: for 12 classes of faces, every 8x8 and 4x4 tile of a 48^2 image that holds a pixel with a soft fragment
+    above 1e-6 must pass the test -- checked with the kernel's own source on the host.  (Below 1e-6: on needles the
+    reference's COMPUTED distance can be ~30 % short of the geometric one -- its arithmetic is ill conditioned there -- so a
+    pixel 1.2 thresholds away from the needle still gets D ~ 1e-7 from the reference while the geometric cull, rightly,
+    drops its tile; parity is unaffected at the 1e-4 the renders are held to.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    from eval_pair_model import fuzz_cases
+    IS, n = 48, 120
+    sigma, del_ = 1e-5, float(np.log(1. / 1e-10 - 1.))
+    thr = float(np.sqrt(f32(f32(del_) * f32(sigma))))
+    cases, px = fuzz_cases(n, IS, np.random.default_rng(11))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for T in (8, 4):
+        nt = IS // T
+        lo = px[np.arange(nt) * T]; hi = px[np.arange(nt) * T + T - 1]
+        cxs, hxs = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        # tile (ty, tx): image rows ty*T.. -> y index IS-1-row: centres px[IS-1-row]
+        ylo = px[IS - 1 - (np.arange(nt) * T + T - 1)]; yhi = px[IS - 1 - np.arange(nt) * T]
+        cys, hys = 0.5 * (ylo + yhi), 0.5 * (yhi - ylo)
+        tiles = np.ascontiguousarray(np.stack([np.tile(cxs, nt), np.repeat(cys, nt), np.tile(hxs, nt), np.repeat(hys, nt)], 1), f32)
+        for name, fv in cases.items():
+            alpha, _ = _alpha_from_kernel_source(host_lib, fv, IS, sigma, del_)
+            live = (alpha > 1e-6).reshape(n, nt, T, nt, T).any(axis=(2, 4)).reshape(n, nt * nt)     # [n, ty*nt+tx]
+            out = np.zeros((n, nt * nt), np.uint8)
+            assert host_lib.host_tile_may_hit(p(np.ascontiguousarray(fv.reshape(n, 9), f32)), n, p(tiles), nt * nt, thr, p(out)) == 0
+            dropped = live & (out == 0)
+            assert not dropped.any(), "%s, %dx%d tiles: %d needed tiles culled" % (name, T, T, int(dropped.sum()))

@@ -405,7 +405,12 @@ __device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, c
     const float w2 = fmaf(i1.z, cx, fmaf(i1.w, cy, i2.x)) + (hx * fabsf(i1.z) + hy * fabsf(i1.w));
     const bool out = w0 < -(thr * __frsqrt_rn(i2.y)) - 1e-3f || w1 < -(thr * __frsqrt_rn(i2.z)) - 1e-3f ||
                      w2 < -(thr * __frsqrt_rn(i2.w)) - 1e-3f;
-    return !out;
+    // A face one of whose heights is below ~3e-5 screen units (a sliver, a needle, a face seen edge-on) is not culled beyond
+    // its bounding box: its barycentrics carry rounding noise of the size of this very test, and what the reference's
+    // arithmetic makes of such a face (soft fragments up to 0.5 along its line) follows that noise, not the geometry.
+    // (Found by fuzzing this source on the host, tests/test_kernel_source_on_host.py.)
+    const bool sliver = !(fminf(fminf(i2.y, i2.z), i2.w) >= 1e-9f);
+    return sliver | !out;
 }
 
 // XCD-aware work mapping: hardware places workgroup b on XCD b % 8; give each XCD a contiguous
