@@ -409,7 +409,7 @@ __device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, c
     // its bounding box: its barycentrics carry rounding noise of the size of this very test, and what the reference's
     // arithmetic makes of such a face (soft fragments up to 0.5 along its line) follows that noise, not the geometry.
     // (Found by fuzzing this source on the host, tests/test_kernel_source_on_host.py.)
-    const bool sliver = !(fminf(fminf(i2.y, i2.z), i2.w) >= 1e-9f);
+    const bool sliver = !((i2.y >= 1e-9f) & (i2.z >= 1e-9f) & (i2.w >= 1e-9f));
     return sliver | !out;
 }
 
