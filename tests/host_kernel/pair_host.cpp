@@ -2,6 +2,7 @@
 // compiled for the host through device_shim.h and exported for ctypes.  One lane at a time.
 #include "device_shim.h"
 #include "../../umr_amd/csrc/raster_core.h"
+#include "../../umr_amd/csrc/raster_general.h"
 
 extern "C" {
 
@@ -27,6 +28,63 @@ int host_pairs(const float *faces, int n, const float *xp, const float *yp, int 
             dxy[2 * o] = pr.dx; dxy[2 * o + 1] = pr.dy;
             float q0, q1, q2;
             zp_out[o] = ok ? clip_depth(q0, q1, q2, pr, fc) : 0.f;
+        }
+    }
+    delete[] rec; delete[] bbox;
+    return 0;
+}
+
+// texel of the surface texture a covered pixel samples (clip_depth + texel_index, :54-59, :180-189), -1 where the pair is
+// rejected or the pixel is not inside [0,1]^3 (the hard z-buffer's condition, :409)
+int host_texels(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,
+                int R, int *tix_out) {
+    float *rec = new float[(size_t)n * REC];
+    float4 *bbox = new float4[n];
+    blockDim.x = 1;
+    for (int i = 0; i < n; ++i) {
+        blockIdx.x = (unsigned)i; threadIdx.x = 0;
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+    }
+    for (int i = 0; i < n; ++i) {
+        Face fc;
+        load_face(fc, rec + (size_t)i * REC);
+        for (int p = 0; p < npix; ++p) {
+            Pair pr;
+            const bool ok = eval_pair(pr, fc, xp[p], yp[p], threshold, nis);
+            int t = -1;
+            if (ok) {
+                float q0, q1, q2;
+                const float zp = clip_depth(q0, q1, q2, pr, fc);
+                const bool incl = pr.w0 <= 1 && pr.w0 >= 0 && pr.w1 <= 1 && pr.w1 >= 0 && pr.w2 <= 1 && pr.w2 >= 0;
+                if (incl && !(zp < 1.f || zp > 100.f)) t = texel_index(q0, q1, R);
+            }
+            tix_out[(size_t)i * npix + p] = t;
+        }
+    }
+    delete[] rec; delete[] bbox;
+    return 0;
+}
+
+// soft fragment of the general-mode kernels (raster_general.h gen_fragment) for dist_mode 0 (hard) / 1 (barycentric) / 2
+int host_general_frag(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,
+                      int dist_mode, unsigned char *live, float *frag) {
+    float *rec = new float[(size_t)n * REC];
+    float4 *bbox = new float4[n];
+    blockDim.x = 1;
+    for (int i = 0; i < n; ++i) {
+        blockIdx.x = (unsigned)i; threadIdx.x = 0;
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+    }
+    RasterArgs A = {};
+    A.threshold = threshold; A.nis = nis; A.thr = thr; A.dist_mode = dist_mode;
+    for (int i = 0; i < n; ++i) {
+        Face fc;
+        load_face(fc, rec + (size_t)i * REC);
+        for (int p = 0; p < npix; ++p) {
+            GenFrag g;
+            gen_fragment(g, fc, A, xp[p], yp[p], true);
+            live[(size_t)i * npix + p] = g.live ? 1 : 0;
+            frag[(size_t)i * npix + p] = g.frag;
         }
     }
     delete[] rec; delete[] bbox;

@@ -24,7 +24,8 @@ def host_lib():
         pytest.skip("clang++ of the ROCm toolchain not present")
     so = os.path.join(HK, "libpair_host.so")
     srcs = [os.path.join(HK, "pair_host.cpp"), os.path.join(HK, "device_shim.h"),
-            os.path.join(ROOT, "umr_amd", "csrc", "raster_core.h"), os.path.join(ROOT, "umr_amd", "csrc", "umr_common.h")]
+            os.path.join(ROOT, "umr_amd", "csrc", "raster_core.h"), os.path.join(ROOT, "umr_amd", "csrc", "umr_common.h"),
+            os.path.join(ROOT, "umr_amd", "csrc", "raster_general.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-function",
                                "-Wno-unknown-attributes", srcs[0], "-o", so])
@@ -34,7 +35,17 @@ def host_lib():
     h.host_pairs.restype = I
     h.host_tile_may_hit.argtypes = [P, I, P, I, F, P]
     h.host_tile_may_hit.restype = I
+    h.host_texels.argtypes = [P, I, P, P, I, F, F, F, I, P]
+    h.host_texels.restype = I
+    h.host_general_frag.argtypes = [P, I, P, P, I, F, F, F, I, P, P]
+    h.host_general_frag.restype = I
     return h
+
+
+def _pixels(IS):
+    px = ((2 * np.arange(IS) + 1 - IS) / IS).astype(f32)
+    xi, ri = np.meshgrid(np.arange(IS), np.arange(IS))
+    return np.ascontiguousarray(px[xi.ravel()]), np.ascontiguousarray(px[(IS - 1 - ri).ravel()])
 
 
 def _alpha_from_kernel_source(h, fv, IS, sigma, dist_eps_log):
@@ -115,3 +126,60 @@ def test_tile_culling_of_the_kernel_source_is_conservative(host_lib):
             assert host_lib.host_tile_may_hit(p(np.ascontiguousarray(fv.reshape(n, 9), f32)), n, p(tiles), nt * nt, thr, p(out)) == 0
             dropped = live & (out == 0)
             assert not dropped.any(), "%s, %dx%d tiles: %d needed tiles culled" % (name, T, T, int(dropped.sum()))
+
+
+def test_texel_lookup_of_the_kernel_source_vs_oracle(host_lib, oracle_built):
+    """clip_depth + texel_index of the kernel source: with a 'hard' render of ONE face whose 36 texels carry their own index
+    as colour, the oracle's image names the texel every covered pixel samples (soft_rasterize_cuda_kernel.cu:54-59,
+    :180-189, :408-414) -- the host-compiled kernel source must name the same one."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    from eval_pair_model import fuzz_cases
+    from oracle import softras
+    IS, n, R = 48, 200, 6
+    sigma, del_ = 1e-5, float(np.log(1. / 1e-10 - 1.))
+    threshold = f32(f32(del_) * f32(sigma)); thr, nis = float(np.sqrt(threshold)), float(f32(-1.0 / f32(sigma)))
+    cases, _ = fuzz_cases(n, IS, np.random.default_rng(21))
+    xp, yp = _pixels(IS)
+    tex = np.zeros((n, 1, R * R, 3), f32)
+    tex[:, 0, :, 0] = np.arange(R * R, dtype=f32)[None] + 1            # channel 0 = texel index + 1 (background stays 0)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=sigma, dist_eps_log=del_, gamma_val=1e-4, func_id_rgb=0, double_side=True)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for name in ("random", "small", "vertex_on_pixel", "obtuse", "sliver", "collapsed_edge_1e-4"):
+        fv = cases[name].copy()
+        fv[:, :, 2] = 7.7 + np.random.default_rng(1).uniform(-1, 1, (n, 3)).astype(f32)        # perspective-correct weights matter
+        ref = softras.raster_forward(fv.reshape(n, 1, 9), tex, IS, background=(0, 0, 0), backend="port", n_threads=8, **cfg)
+        ref_tix = np.rint(ref["soft_colors"][:, 0].reshape(n, -1)).astype(np.int64) - 1          # -1 = not covered
+        got = np.zeros((n, IS * IS), np.int32)
+        assert host_lib.host_texels(p(np.ascontiguousarray(fv.reshape(n, 9), f32)), n, p(xp), p(yp), IS * IS, thr, float(threshold), nis, R,
+                                    p(got)) == 0
+        diff = int((got != ref_tix).sum())
+        assert diff <= 2, (name, diff, int((ref_tix >= 0).sum()))        # (a tie on a texel boundary at most)
+
+
+@pytest.mark.parametrize("dist_mode", [0, 1])
+def test_general_mode_fragments_of_the_kernel_source_vs_oracle(host_lib, oracle_built, dist_mode):
+    """gen_fragment of raster_general.h (hard / barycentric distance, :154-157, :365-372) on the host against the oracle's
+    alpha plane of one-face meshes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    from eval_pair_model import fuzz_cases
+    from oracle import softras
+    IS, n = 48, 200
+    sigma, del_ = (1e-5 if dist_mode == 0 else 1e-4), float(np.log(1. / 1e-10 - 1.))
+    threshold = f32(f32(del_) * f32(sigma)); thr, nis = float(np.sqrt(threshold)), float(f32(-1.0 / f32(sigma)))
+    cases, _ = fuzz_cases(n, IS, np.random.default_rng(31))
+    xp, yp = _pixels(IS)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=sigma, dist_eps_log=del_, gamma_val=1e-4, func_id_rgb=1, double_side=True,
+               func_id_dist=dist_mode, func_id_alpha=2, texture_sample_type=0)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for name in ("random", "small", "vertex_on_pixel", "obtuse", "two_equal", "collinear"):
+        fv = cases[name]
+        ref = softras.raster_forward(fv.reshape(n, 1, 9), np.ones((n, 1, 1, 3), f32), IS, background=(0, 0, 0), backend="port",
+                                     n_threads=8, **cfg)
+        ra = ref["soft_colors"][:, 3].reshape(n, -1)
+        live = np.zeros((n, IS * IS), np.uint8); frag = np.zeros((n, IS * IS), f32)
+        assert host_lib.host_general_frag(p(np.ascontiguousarray(fv.reshape(n, 9), f32)), n, p(xp), p(yp), IS * IS, thr, float(threshold),
+                                          nis, dist_mode, p(live), p(frag)) == 0
+        alpha = np.where(live != 0, frag, f32(0))
+        assert np.isfinite(alpha).all(), name
+        bad = int((np.abs(alpha.astype(np.float64) - ra) > 1e-4).sum())
+        assert bad <= 2, (name, bad, int((ra > 0).sum()))
