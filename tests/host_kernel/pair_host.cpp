@@ -91,6 +91,24 @@ int host_general_frag(const float *faces, int n, const float *xp, const float *y
     return 0;
 }
 
+// pixel-centre coordinate both ways: the fp64 expression of the reference (:325-326) and the fp32 shortcut for power-of-two
+// images; also tile_setup's per-thread pixel coordinates for one (block, thread) of a launch
+int host_ndc(int IS, float *ref_out, float *fast_out) {
+    const bool pow2 = (IS & (IS - 1)) == 0;
+    const float inv_is = 1.f / (float)IS;
+    for (int i = 0; i < IS; ++i) { ref_out[i] = ndc_coord(i, IS); fast_out[i] = ndc_coord_fast(i, IS, inv_is, pow2); }
+    return 0;
+}
+int host_tile_setup(int N, int IS, int no_xcd_remap, unsigned block, unsigned thread, int *out5) {
+    RasterArgs A = {};
+    A.N = N; A.IS = IS; A.tiles_x = (IS + BLK_W - 1) / BLK_W; A.tiles_y = (IS + BLK_H - 1) / BLK_H; A.no_xcd_remap = no_xcd_remap;
+    blockIdx.x = block; threadIdx.x = thread; blockDim.x = BLK_THREADS;
+    Tile t;
+    tile_setup(t, A);
+    out5[0] = t.n; out5[1] = t.xi; out5[2] = t.row; out5[3] = t.valid ? 1 : 0; out5[4] = t.wave_on ? 1 : 0;
+    return 0;
+}
+
 // the conservative tile-vs-dilated-triangle test both raster directions cull with: 1 = "some pixel of the tile may survive"
 // tiles: [ntiles,4] = (cx, cy, hx, hy) centre and half extent of the tile's pixel-centre rectangle
 int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles, float thr, unsigned char *out) {

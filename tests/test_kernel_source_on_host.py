@@ -39,6 +39,10 @@ def host_lib():
     h.host_texels.restype = I
     h.host_general_frag.argtypes = [P, I, P, P, I, F, F, F, I, P, P]
     h.host_general_frag.restype = I
+    h.host_ndc.argtypes = [I, P, P]
+    h.host_ndc.restype = I
+    h.host_tile_setup.argtypes = [I, I, I, ctypes.c_uint, ctypes.c_uint, P]
+    h.host_tile_setup.restype = I
     return h
 
 
@@ -183,3 +187,27 @@ def test_general_mode_fragments_of_the_kernel_source_vs_oracle(host_lib, oracle_
         assert np.isfinite(alpha).all(), name
         bad = int((np.abs(alpha.astype(np.float64) - ra) > 1e-4).sum())
         assert bad <= 2, (name, bad, int((ra > 0).sum()))
+
+
+def test_pixel_coordinates_and_work_mapping_of_the_kernel_source(host_lib):
+    """(a) the fp32 pixel-centre shortcut equals the reference's fp64 expression (:325-326) to the bit, for power-of-two and
+    other image sizes; (b) every work mapping of the pixel-major kernels (plain, contiguous per XCD, row-interleaved per XCD)
+    sends the launch's workgroups x threads onto every (mesh, pixel) exactly once -- tile_setup of the kernel source, run
+    for all blocks and threads of a launch."""
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for IS in (16, 64, 512, 1024, 24, 136, 200):
+        a, b = np.zeros(IS, f32), np.zeros(IS, f32)
+        host_lib.host_ndc(IS, p(a), p(b))
+        expect = ((2.0 * np.arange(IS) + 1.0 - IS) / IS).astype(f32)
+        assert np.array_equal(a, expect) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), IS
+    out = np.zeros(5, np.int32)
+    for (N, IS) in ((3, 128), (2, 136), (8, 64), (1, 24)):
+        tiles = ((IS + 15) // 16) ** 2
+        for mode in (0, 1, 2):
+            seen = np.zeros((N, IS, IS), np.int32)
+            for block in range(N * tiles):
+                for thread in range(256):
+                    host_lib.host_tile_setup(N, IS, mode, block, thread, p(out))
+                    if out[3]:
+                        seen[out[0], out[2], out[1]] += 1
+            assert (seen == 1).all(), (N, IS, mode, int((seen != 1).sum()))
