@@ -109,6 +109,8 @@ int host_tile_setup(int N, int IS, int no_xcd_remap, unsigned block, unsigned th
     return 0;
 }
 
+int host_fm_owned_face(int xcd, int j, int per, int split) { return fm_owned_face(xcd, j, per, split); }
+
 // the conservative tile-vs-dilated-triangle test both raster directions cull with: 1 = "some pixel of the tile may survive"
 // tiles: [ntiles,4] = (cx, cy, hx, hy) centre and half extent of the tile's pixel-centre rectangle
 int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles, float thr, unsigned char *out) {

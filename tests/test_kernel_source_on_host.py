@@ -43,6 +43,8 @@ def host_lib():
     h.host_ndc.restype = I
     h.host_tile_setup.argtypes = [I, I, I, ctypes.c_uint, ctypes.c_uint, P]
     h.host_tile_setup.restype = I
+    h.host_fm_owned_face.argtypes = [I, I, I, I]
+    h.host_fm_owned_face.restype = I
     return h
 
 
@@ -211,3 +213,11 @@ def test_pixel_coordinates_and_work_mapping_of_the_kernel_source(host_lib):
                     if out[3]:
                         seen[out[0], out[2], out[1]] += 1
             assert (seen == 1).all(), (N, IS, mode, int((seen != 1).sum()))
+    # (c) face ownership of the face-major backward: for every split the 8 XCDs' runs partition the mesh's faces
+    for F in (1280, 5120, 320, 64):
+        per = F // 8
+        for split in (1, 2, 4):
+            if per % split:
+                continue
+            owned = sorted(host_lib.host_fm_owned_face(x, j, per, split) for x in range(8) for j in range(per))
+            assert owned == list(range(F)), (F, split)

@@ -140,19 +140,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // drains on cheap ones.  Work estimate: 4x4 sub-tiles under the dilated bbox; / 8 for faces the state cull will remove --
 // mode 1 (texel gradients only): back faces; mode 2 (silhouette): faces whose corners and centroid all sit on alpha == 1.
 // The order changes no result (every face is still reduced by one wave in its own fixed order).
-// Face ownership of the face-major backward: XCD `xcd` owns, of every mesh, `split` contiguous runs of per / split faces
-// (run q of XCD x = chunk q * 8 + x of the mesh's 8 * split chunks); j = 0 .. per-1 enumerates them.  Contiguous index runs
-// are spatial patches of a subdivided mesh, so the saved state an XCD's waves re-read stays in its L2; but with one run
-// per XCD whole patches are front- or back-facing and the XCDs' loads differ 0.3x .. 1.8x per mesh.  Measured (N = 16,
-// split 1 -> 4): texel gradients only 122.9 -> 119.0 us, silhouette 77.7 -> 74.1 us, vertex + texel gradients 204 -> 228 us
-// (28 B of state per pixel: locality wins); no gain at N = 128.  raster.hip picks 4 for the two light variants at N <= 16.
-__device__ __forceinline__ int fm_owned_face(int xcd, int j, int per, int split) {
-    if (split > 1) {
-        const int c = per / split, q = j / c;
-        return (q * 8 + xcd) * c + (j - q * c);
-    }
-    return xcd * per + j;
-}
 #define ORDER_KEYS 1024
 #define ORDER_MAX_ENTRIES 16384
 #define ORDER_THREADS 1024
