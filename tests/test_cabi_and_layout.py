@@ -234,3 +234,33 @@ def test_soft_rasterize_refuses_cpu_tensors_and_bad_vertex_textures():
     with pytest.raises(RuntimeError):      # texture_type 'vertex' needs [N,F,3,3] (the reference reads w[j], j < texture_size)
         UF.SoftRasterizeFunction.apply(fv, torch.zeros(1, 4, 4, 3), 8, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-4, 1e-4,
                                        'softmax', 'prod', 'vertex')
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/umr_hip.h has a ctypes signature in umr_amd/_lib.py with the same number of parameters and
+    compatible kinds (pointer / integer / float): a drifted argtypes list is undefined behaviour at the first call."""
+    import ctypes
+    import re
+    from umr_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "umr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|long|const char \*)\s*(umr_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 40
+    checked = 0
+    for name, args in protos:
+        params = [a.strip() for a in args.replace("\n", " ").split(",")] if args.strip() not in ("", "void") else []
+        if name not in _lib.SIGNATURES:
+            assert name in ("umr_version", "umr_build_id"), name + " has no ctypes signature"
+            continue
+        argtypes, _ = _lib.SIGNATURES[name]
+        assert len(argtypes) == len(params), (name, len(argtypes), len(params))
+        for a, p in zip(argtypes, params):
+            is_ptr = "*" in p
+            if is_ptr:
+                assert a in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(a, "_type_") and not isinstance(a._type_, str), (name, p, a)
+            elif re.search(r"\b(float|double)\b", p):
+                assert a in (ctypes.c_float, ctypes.c_double), (name, p, a)
+            else:
+                assert a in (ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_uint), (name, p, a)
+        checked += 1
+    assert checked >= 40
