@@ -221,3 +221,28 @@ def test_pixel_coordinates_and_work_mapping_of_the_kernel_source(host_lib):
                 continue
             owned = sorted(host_lib.host_fm_owned_face(x, j, per, split) for x in range(8) for j in range(per))
             assert owned == list(range(F)), (F, split)
+
+
+def test_depth_in_range_flag_of_the_kernel_source_is_sound(host_lib):
+    """k_face_setup's flag "every vertex depth strictly inside (near, far)" lets the silhouette backward skip the
+    perspective-correct depth and its range test (:592).  Sound only if the interpolated depth of such a face can never
+    leave [near, far]: for faces the flag covers (vertex depths inside (near * 1.0001, far * 0.9999)), every live pixel's
+    clip_depth of the kernel source must lie in range -- needles and slivers included."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    from eval_pair_model import fuzz_cases
+    IS, n = 48, 150
+    sigma, del_ = 1e-5, float(np.log(1. / 1e-10 - 1.))
+    near, far = 1.0, 100.0
+    rng = np.random.default_rng(41)
+    cases, _ = fuzz_cases(n, IS, rng)
+    for name, fv in cases.items():
+        fv = fv.copy()
+        fv[:, :, 2] = np.exp(rng.uniform(np.log(near * 1.001), np.log(far * 0.999), (n, 3))).astype(f32)   # flag set for all
+        alpha, zp = _alpha_from_kernel_source(host_lib, fv, IS, sigma, del_)
+        lv = alpha > 0
+        assert lv.any() or name == "tiny"
+        z = zp[lv]
+        assert np.isfinite(z).all() and (z >= near).all() and (z <= far).all(), (name, float(z.min()), float(z.max()))
+        zmin, zmax = fv[:, :, 2].min(1), fv[:, :, 2].max(1)
+        inside = (zp >= zmin[:, None] * (1 - 1e-5)) & (zp <= zmax[:, None] * (1 + 1e-5))     # a convex combination of the 1/z_k
+        assert inside[lv].all(), name
