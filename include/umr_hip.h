@@ -207,10 +207,12 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
  * backward: grad_predict (same striding, ADDED into) = grad_loss[n] * d loss[n] / d p.
  * sums [N, umr_neg_iou_sums_stride(P)]: forward scratch (per-block partial sums, added in a fixed order: no float
  * atomics, bit-reproducible) whose first two floats per row, (intersect, union + 1e-6), backward reads.
+ * sums_bytes: size of the caller's scratch, checked against N * umr_neg_iou_sums_stride(P) * 4 (the row grew from 2 floats
+ * in version 0.1: a caller built against the old contract is refused instead of being written past).
  * -------------------------------------------------------------------------------------------*/
 long umr_neg_iou_sums_stride(long P);
 int umr_neg_iou_forward(const float *predict, long predict_stride, const float *target, float *loss,
-                        float *sums, int N, long P, void *stream);
+                        float *sums, size_t sums_bytes, int N, long P, void *stream);
 int umr_neg_iou_backward(const float *predict, long predict_stride, const float *target, const float *sums,
                          const float *grad_loss, float *grad_predict, long grad_stride, int N, long P,
                          void *stream);

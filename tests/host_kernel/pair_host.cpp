@@ -135,4 +135,42 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
     return 0;
 }
 
+
+// lean geometry of the face-major backward (raster_core.h lean_setup / lean_segments, faces flagged lean_ok by k_face_setup):
+// per (face, pixel) the lean flag of the face, live (inside | d2 < threshold), soft fragment, P - Q and the parameter of
+// the closest point on its edge, and the edge index -- what raster_backward.h's lean visit derives its gradients from
+int host_lean_pairs(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,
+                    unsigned char *lean_flag, unsigned char *live, float *frag, float *qxy, float *tpar, int *edge) {
+    float *rec = new float[(size_t)n * REC];
+    float4 *bbox = new float4[n];
+    blockDim.x = 1;
+    for (int i = 0; i < n; ++i) {
+        blockIdx.x = (unsigned)i; threadIdx.x = 0;
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+    }
+    for (int i = 0; i < n; ++i) {
+        Face fc;
+        load_face(fc, rec + (size_t)i * REC);
+        lean_flag[i] = fc.lean_ok() ? 1 : 0;
+        LeanFace L;
+        lean_setup(L, fc);
+        for (int p = 0; p < npix; ++p) {
+            LeanSeg sg;
+            const bool inside = lean_segments<true>(sg, L, xp[p], yp[p]) > 0.f;
+            const float dmin = fminf(fminf(sg.d2[0], sg.d2[1]), sg.d2[2]);
+            const bool m0 = sg.d2[0] <= fminf(sg.d2[1], sg.d2[2]);
+            const bool m1 = !m0 && sg.d2[1] <= sg.d2[2];
+            const int e = m0 ? 0 : (m1 ? 1 : 2);
+            const size_t o = (size_t)i * npix + p;
+            live[o] = (inside || dmin < threshold) ? 1 : 0;
+            frag[o] = 1.0f / (1.f + expf((inside ? dmin : -dmin) * nis));
+            qxy[2 * o] = sg.qx[e]; qxy[2 * o + 1] = sg.qy[e];
+            tpar[o] = sg.t[e];
+            edge[o] = inside ? e + 4 : e;
+        }
+    }
+    delete[] rec; delete[] bbox;
+    return 0;
+}
+
 }

@@ -33,6 +33,9 @@ if os.environ.get("UMR_FO") == "0":
 if os.environ.get("UMR_XCD"):
     _lib.debug_set("xcd_remap", int(os.environ["UMR_XCD"]))
     tag += " [xcd_remap %s]" % os.environ["UMR_XCD"]
+if os.environ.get("UMR_LEAN") == "0":
+    _lib.debug_set("bwd_lean", 0)
+    tag += " [reference-order backward]"
 if os.environ.get("UMR_FOG"):
     _lib.debug_set("face_order_group", int(os.environ["UMR_FOG"]))
     tag += " [order group %s]" % os.environ["UMR_FOG"]
@@ -43,6 +46,10 @@ out["n16_ts1"] = timed(bench, 16, 3, 512, 1, iters=20)
 out["n128_ts36_texonly_pooled"] = timed(bench, 128, 3, 512, 36, pool=True, need_p2f=False, need_gf=False)
 out["n128_ts36"] = timed(bench, 128, 3, 512, 36)
 out["n128_ts1"] = timed(bench, 128, 3, 512, 1)
+if os.environ.get("UMR_CFG4", "1") != "0":      # BASELINE config 4's raster shape: 5120 faces at IS = 1024
+    out["n32_f5120_is1024_ts36"] = timed(bench, 32, 4, 1024, 36, iters=5)
+    out["n32_f5120_is1024_ts36_texonly_pooled"] = timed(bench, 32, 4, 1024, 36, pool=True, need_p2f=False, need_gf=False, iters=5)
+    out["alpha_n32_f5120_is1024"] = timed(bench_alpha, 32, 4, 1024, ids=(2, 3), iters=5)
 out["alpha_n16"] = timed(bench_alpha, 16, 3, 512, ids=(2, 3))
 out["alpha_n128"] = timed(bench_alpha, 128, 3, 512, ids=(2, 3))
 print(json.dumps(out), flush=True)

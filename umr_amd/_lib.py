@@ -35,7 +35,7 @@ SIGNATURES = {
     "umr_project_points_forward": ([_P] * 3 + [_I, _I, _I, _F, _P], _I),
     "umr_project_points_backward": ([_P] * 5 + [_I, _I, _I, _P], _I),
     "umr_neg_iou_sums_stride": ([_L], _L),
-    "umr_neg_iou_forward": ([_P, _L, _P, _P, _P, _I, _L, _P], _I),
+    "umr_neg_iou_forward": ([_P, _L, _P, _P, _P, _Z, _I, _L, _P], _I),
     "umr_neg_iou_backward": ([_P, _L, _P, _P, _P, _P, _L, _I, _L, _P], _I),
     "umr_chamfer_forward": ([_P] * 6 + [_I, _I, _I, _I, _P], _I),
     "umr_chamfer_backward": ([_P] * 8 + [_I, _I, _I, _I, _P], _I),

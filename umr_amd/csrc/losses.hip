@@ -359,8 +359,9 @@ extern "C" {
 long umr_neg_iou_sums_stride(long P) { return P > 0 ? iou_stride(P) : 0; }
 
 int umr_neg_iou_forward(const float *predict, long predict_stride, const float *target, float *loss,
-                        float *sums, int N, long P, void *stream) {
+                        float *sums, size_t sums_bytes, int N, long P, void *stream) {
     if (!predict || !target || !loss || !sums || N <= 0 || P <= 0 || predict_stride < P) return UMR_ERR_ARG;
+    if (sums_bytes < (size_t)N * (size_t)iou_stride(P) * sizeof(float)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)iou_blocks(P), (unsigned)N);
     k_iou_partial<<<grid, 256, 0, st>>>(predict, predict_stride, target, sums, P);

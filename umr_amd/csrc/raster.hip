@@ -36,7 +36,8 @@ namespace {
 size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 255) & ~(size_t)255; }
 size_t ws_rec_bytes(int N, int F) { return (size_t)N * F * REC * sizeof(float); }
 size_t ws_sbcount_bytes(int N) { return (((size_t)N * SB_SLOTS * sizeof(int)) + 255) & ~(size_t)255; }
-size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * F * sizeof(int); }
+int sb_cap_for(int F) { return F < SB_CAP ? F : SB_CAP; }
+size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * sb_cap_for(F) * sizeof(int); }
 size_t ws_order_bytes(int N, int F) {   // start order in whole groups of <= 16 meshes + the per-face work estimates
     return (size_t)(N + 15) * F * sizeof(int) + (((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255);
 }
@@ -47,11 +48,16 @@ int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping 
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
 int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts its waves in index order,
                                  // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
+int g_bwd_lean = 1;              // umr_debug_set("bwd_lean", 0): every face of the face-major backward takes the reference-order geometry
 bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
 
-// super-block edge: an eighth of the image, rounded up to whole 16-pixel workgroup blocks (<= 8 x 8 super-blocks)
+// super-block edge: 64 pixels, or a sixteenth of the image rounded up to whole 16-pixel workgroup blocks when that is larger
+// (<= 16 x 16 super-blocks).  64^2 keeps a workgroup's candidate list at ~100 faces for the BASELINE meshes at IS = 512 and
+// at IS = 1024 alike (a fixed 8 x 8 grid made them 128^2 and the lists 3x as long there: 80.9 us per mesh forward at
+// N = 32, F = 5120, IS = 1024 in round 2).
 void superblock_geometry(int IS, int *size, int *nx) {
-    *size = (((IS + 7) / 8) + 15) & ~15;
+    const int sixteenth = (((IS + 15) / 16) + 15) & ~15;
+    *size = sixteenth > 64 ? sixteenth : 64;
     *nx = (IS + *size - 1) / *size;
 }
 
@@ -62,7 +68,8 @@ void setup_bins(RasterArgs &A, void *workspace, int N, int F, int IS, hipStream_
     char *p = (char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F);
     int *cnt = (int *)p, *lst = (int *)(p + ws_sbcount_bytes(N));
     superblock_geometry(IS, &A.sb_size, &A.sb_nx);
-    k_superblock_bin<<<dim3(SB_SLOTS, N), 256, 0, st>>>(A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx);
+    A.sb_cap = sb_cap_for(F);
+    k_superblock_bin<<<dim3(A.sb_nx * A.sb_nx, N), 256, 0, st>>>(A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx, A.sb_cap);
     A.sb_count = cnt; A.sb_list = lst;
 }
 
@@ -117,6 +124,7 @@ int umr_debug_set(const char *key, int value) {
     if (!key) return UMR_ERR_ARG;
     if (std::string(key) == "bwd_pixel_major") { g_bwd_pixel_major = value != 0; return UMR_OK; }
     if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
+    if (std::string(key) == "bwd_lean") { g_bwd_lean = value != 0; return UMR_OK; }
     if (std::string(key) == "xcd_remap") { g_xcd_remap = value; return UMR_OK; }   // 0 off, 1 contiguous runs, 2 row-interleaved
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
@@ -286,7 +294,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.gamma = gamma_val; A.double_side = double_side;
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
-    A.tex_group = tex_group;
+    A.tex_group = tex_group; A.bwd_lean = g_bwd_lean;
     A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;

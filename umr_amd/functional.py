@@ -240,7 +240,7 @@ class NegIoUFunction(Function):
         N, P = p.shape
         loss = torch.empty(N, device=p.device, dtype=torch.float32)
         sums = torch.empty(N, L.umr_neg_iou_sums_stride(P), device=p.device, dtype=torch.float32)
-        _lib.check(L.umr_neg_iou_forward(ptr(p), P, ptr(t), ptr(loss), ptr(sums), N, P, _lib.stream_ptr(p.device)),
+        _lib.check(L.umr_neg_iou_forward(ptr(p), P, ptr(t), ptr(loss), ptr(sums), sums.numel() * 4, N, P, _lib.stream_ptr(p.device)),
                    "umr_neg_iou_forward")
         ctx.save_for_backward(p, t, sums)
         ctx.shape = predict.shape
@@ -415,6 +415,9 @@ class PerceptualPrologueFunction(Function):
         L = _lib.lib()
         x, m = _f32c(img), _f32c(mask)
         B, C, H, W = x.shape
+        if C > 3 or tuple(m.shape) not in ((B, H, W), (B, 1, H, W)):   # the kernel reads mask[b * H * W + p]: no broadcasting
+            raise ValueError("perceptual prologue: img %s needs C <= 3 and a mask of shape [B,H,W], got %s"
+                             % (tuple(x.shape), tuple(m.shape)))
         out = torch.empty_like(x)
         sh, sc = (ctypes.c_float * 3)(*[float(v) for v in shift]), (ctypes.c_float * 3)(*[float(v) for v in scale])
         _lib.check(L.umr_perceptual_prologue_forward(ptr(x), ptr(m), ptr(out), B, C, H * W, sh, sc, _lib.stream_ptr(x.device)),

@@ -57,11 +57,13 @@ def weighted_total(module, terms, weights):
     multiply and an add per term in each direction: the step's wall time equals its host enqueue time, so every
     elementwise launch on scalars costs ~10 us of it.  `weights`: list of (name, python float); the weight vector is
     uploaded once per device and cached on `module`."""
+    weights = [(k, v) for k, v in weights if float(v) != 0.0]   # a term with weight 0 is OMITTED, as the reference omits the
+    # epoch-gated regularisers (train_s1.py:250-255): 0 * inf would poison the total, and its zero gradient costs kernels
     vals = torch.stack([terms[k].reshape(()) for k, _ in weights])
     cache = module.__dict__.setdefault("_wvec_cache", {})
-    key = (vals.device, tuple(float(v) for _, v in weights))
+    key = (vals.device, tuple((k, float(v)) for k, v in weights))
     if key not in cache:
-        cache[key] = torch.tensor(key[1], dtype=vals.dtype, device=vals.device)
+        cache[key] = torch.tensor([v for _, v in key[1]], dtype=vals.dtype, device=vals.device)
     return (vals * cache[key]).sum()
 
 
@@ -149,7 +151,9 @@ class RenderCompareS1(nn.Module):
         else:  # keep the render + its backward in the step even without a discriminator network
             terms["gan"] = mask_pred_unseen.mean()
         # train_s1.py:247-265; the symmetry term only while epoch < stop_ori_epoch (:250), the deformation term only once
-        # epoch > update_template_freq (:253) -- weight 0 keeps the term in `terms` for logging, as the reference does
+        # epoch > update_template_freq (:253) -- a gated-off term stays in `terms` for logging, as in the reference, and is
+        # left out of the sum (weighted_total).  A HIP graph captured from this module bakes in the epoch's gating:
+        # re-capture after set_epoch crosses stop_ori_epoch / update_template_freq (bench.py --graph runs one epoch).
         ori_wt = w.ori_reg_wt if self.epoch < w.stop_ori_epoch else 0.0
         deform_wt = w.deform_reg_wt if self.epoch > w.update_template_freq else 0.0
         total = weighted_total(self, terms, [
