@@ -4,6 +4,77 @@
 #include "../../umr_amd/csrc/raster_core.h"
 #include "../../umr_amd/csrc/raster_general.h"
 
+namespace {
+// ---- a well-conditioned closest-point evaluation (TEST INSTRUMENT, not product code) -------------------------------------
+// Round 3 built this as a 'lean' geometry for the face-major backward and measured it on the MI355X: rejected,
+// because what it differs by from eval_pair -- the reference formulation's own rounding noise -- decides which rim pixels
+// contribute.  It stays here to MEASURE that noise on the kernel source (test_reference_order_geometry_carries_rounding_noise).
+// The reference obtains the closest boundary point through barycentrics of O(1) homogeneous products (:63-152): region
+// tables, one edge parameter from differences of `face_sym`, the offset as sum_k (t_k - w_k) p_k.  Mathematically that IS
+// the Euclidean closest point of the triangle's boundary (the obtuse-corner override exists to make it so), so for a
+// well-conditioned face the same point follows from the three clamped edge projections directly: per edge e = (A, A + E)
+//   t = clamp(<P - A, E> / |E|^2, 0, 1),  q = (P - A) - t E = P - Q_e,  d2_e = |q|^2,
+// 9 full-rate VALU each on operands relative to the face's own vertices (no cancellation of O(1) terms), and the nearest
+// of the three is the reference's point; inside the triangle the clamp never acts (the foot on the nearest edge's line
+// lies on the edge), so one formula serves both branches.  The FORWARD keeps the reference's operation order -- outside
+// the silhouette colours are ratios of weights ~1e-9 and have to carry the reference's own rounding noise to agree within
+// 1e-4 -- but gradients are sums of such terms and are held to a relative tolerance; what differs is the reference's
+// rounding noise in d^2 (~1e-7 absolute in the offset: up to ~1e-3 relative in D at the rim of the 3.9 px band, ~1e-5
+// near the edge where the weight is).
+struct LeanFace {   // per lane (VGPRs; the face is wave-uniform, the copies make every operand a full-rate VGPR source)
+    float ax[3], ay[3];   // edge e starts at vertex e ...
+    float ex[3], ey[3];   // ... and runs to vertex e + 1
+    float rl[3];          // 1 / |E_e|^2
+    float orient;         // +1 | -1: sign that makes the edge functions positive inside
+};
+
+template <class FaceT>
+__device__ __forceinline__ void lean_setup(LeanFace &L, const FaceT &fc) {
+    float x[3], y[3];
+#ifdef UMR_HOST_SHIM
+    x[0] = fc.template g<R_X0>(); y[0] = fc.template g<R_Y0>(); x[1] = fc.template g<R_X1>(); y[1] = fc.template g<R_Y1>();
+    x[2] = fc.template g<R_X2>(); y[2] = fc.template g<R_Y2>();
+#else
+#define UMR_VMOV(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
+    UMR_VMOV(x[0], fc.template g<R_X0>()); UMR_VMOV(y[0], fc.template g<R_Y0>()); UMR_VMOV(x[1], fc.template g<R_X1>());
+    UMR_VMOV(y[1], fc.template g<R_Y1>()); UMR_VMOV(x[2], fc.template g<R_X2>()); UMR_VMOV(y[2], fc.template g<R_Y2>());
+#undef UMR_VMOV
+#endif
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int b = (e + 1) % 3;
+        L.ax[e] = x[e]; L.ay[e] = y[e];
+        L.ex[e] = x[b] - x[e]; L.ey[e] = y[b] - y[e];
+        L.rl[e] = 1.f / (L.ex[e] * L.ex[e] + L.ey[e] * L.ey[e]);   // >= 1e-4 for flagged faces
+    }
+    // edge function of edge 0 at vertex 2 = twice the signed area
+    L.orient = (L.ex[0] * (y[2] - y[0]) - L.ey[0] * (x[2] - x[0])) > 0.f ? 1.f : -1.f;
+}
+
+struct LeanSeg { float qx[3], qy[3], t[3], d2[3]; };   // per edge: P - Q_e, parameter of Q_e, squared distance
+
+template <bool EDGE_FN>
+__device__ __forceinline__ float lean_segments(LeanSeg &s, const LeanFace &L, float xp, float yp) {
+    // returns (EDGE_FN) the smallest oriented edge function: > 0 <=> the pixel centre is strictly inside
+    float cmin = 0.f;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const float px = xp - L.ax[e], py = yp - L.ay[e];
+        const float u = fmaf(px, L.ex[e], py * L.ey[e]);
+        const float t = fminf(fmaxf(u * L.rl[e], 0.f), 1.f);
+        const float qx = fmaf(-t, L.ex[e], px), qy = fmaf(-t, L.ey[e], py);
+        s.qx[e] = qx; s.qy[e] = qy; s.t[e] = t;
+        s.d2[e] = fmaf(qx, qx, qy * qy);
+        if (EDGE_FN) {
+            const float c = fmaf(L.ex[e], py, -(L.ey[e] * px)) * L.orient;
+            cmin = e == 0 ? c : fminf(cmin, c);
+        }
+    }
+    return cmin;
+}
+
+}  // namespace
+
 extern "C" {
 
 // faces [n,9] -> per (face, pixel): live flag, soft fragment D, unclipped barycentrics, dx, dy, clipped depth zp
@@ -135,12 +206,10 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
     return 0;
 }
 
-
-// lean geometry of the face-major backward (raster_core.h lean_setup / lean_segments, faces flagged lean_ok by k_face_setup):
-// per (face, pixel) the lean flag of the face, live (inside | d2 < threshold), soft fragment, P - Q and the parameter of
-// the closest point on its edge, and the edge index -- what raster_backward.h's lean visit derives its gradients from
-int host_lean_pairs(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,
-                    unsigned char *lean_flag, unsigned char *live, float *frag, float *qxy, float *tpar, int *edge) {
+// per (face, pixel): the closest boundary point by three clamped edge projections on operands relative to the face's own
+// vertices (agrees with a float64 evaluation to ~1e-9): live (inside | d2 < threshold), soft fragment, P - Q
+int host_accurate_pairs(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,
+                        unsigned char *live, float *frag, float *qxy) {
     float *rec = new float[(size_t)n * REC];
     float4 *bbox = new float4[n];
     blockDim.x = 1;
@@ -151,22 +220,17 @@ int host_lean_pairs(const float *faces, int n, const float *xp, const float *yp,
     for (int i = 0; i < n; ++i) {
         Face fc;
         load_face(fc, rec + (size_t)i * REC);
-        lean_flag[i] = fc.lean_ok() ? 1 : 0;
         LeanFace L;
         lean_setup(L, fc);
         for (int p = 0; p < npix; ++p) {
             LeanSeg sg;
             const bool inside = lean_segments<true>(sg, L, xp[p], yp[p]) > 0.f;
             const float dmin = fminf(fminf(sg.d2[0], sg.d2[1]), sg.d2[2]);
-            const bool m0 = sg.d2[0] <= fminf(sg.d2[1], sg.d2[2]);
-            const bool m1 = !m0 && sg.d2[1] <= sg.d2[2];
-            const int e = m0 ? 0 : (m1 ? 1 : 2);
+            const int e = sg.d2[0] <= fminf(sg.d2[1], sg.d2[2]) ? 0 : (sg.d2[1] <= sg.d2[2] ? 1 : 2);
             const size_t o = (size_t)i * npix + p;
             live[o] = (inside || dmin < threshold) ? 1 : 0;
             frag[o] = 1.0f / (1.f + expf((inside ? dmin : -dmin) * nis));
             qxy[2 * o] = sg.qx[e]; qxy[2 * o + 1] = sg.qy[e];
-            tpar[o] = sg.t[e];
-            edge[o] = inside ? e + 4 : e;
         }
     }
     delete[] rec; delete[] bbox;

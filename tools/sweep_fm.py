@@ -33,9 +33,6 @@ if os.environ.get("UMR_FO") == "0":
 if os.environ.get("UMR_XCD"):
     _lib.debug_set("xcd_remap", int(os.environ["UMR_XCD"]))
     tag += " [xcd_remap %s]" % os.environ["UMR_XCD"]
-if os.environ.get("UMR_LEAN") == "0":
-    _lib.debug_set("bwd_lean", 0)
-    tag += " [reference-order backward]"
 if os.environ.get("UMR_FOG"):
     _lib.debug_set("face_order_group", int(os.environ["UMR_FOG"]))
     tag += " [order group %s]" % os.environ["UMR_FOG"]

@@ -48,7 +48,6 @@ int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping 
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
 int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts its waves in index order,
                                  // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
-int g_bwd_lean = 1;              // umr_debug_set("bwd_lean", 0): every face of the face-major backward takes the reference-order geometry
 bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
 
 // super-block edge: 64 pixels, or a sixteenth of the image rounded up to whole 16-pixel workgroup blocks when that is larger
@@ -124,7 +123,6 @@ int umr_debug_set(const char *key, int value) {
     if (!key) return UMR_ERR_ARG;
     if (std::string(key) == "bwd_pixel_major") { g_bwd_pixel_major = value != 0; return UMR_OK; }
     if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
-    if (std::string(key) == "bwd_lean") { g_bwd_lean = value != 0; return UMR_OK; }
     if (std::string(key) == "xcd_remap") { g_xcd_remap = value; return UMR_OK; }   // 0 off, 1 contiguous runs, 2 row-interleaved
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
@@ -294,7 +292,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.gamma = gamma_val; A.double_side = double_side;
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
-    A.tex_group = tex_group; A.bwd_lean = g_bwd_lean;
+    A.tex_group = tex_group;
     A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;

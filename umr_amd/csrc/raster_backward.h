@@ -240,9 +240,6 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
 #else
 #define FM_ACC(acc, a, b) acc += (a) * (b)
 #endif
-#ifndef FM_LEAN
-#define FM_LEAN 1         // 1: faces flagged well-conditioned take the lean geometry (raster_core.h lean_segments); the
-#endif                    // run-time switch umr_debug_set("bwd_lean", 0) sends every face down the reference-order path
 #ifndef FM_STATE_CULL
 #define FM_STATE_CULL 1   // sub-tile skips from the saved forward state inside the culling pass (A/B: -DFM_STATE_CULL=0)
 #endif
@@ -297,28 +294,50 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
         atomicAdd(&my_tex[tix * 3 + 2], c);
     }
 }
-// ---- one face of the face-major backward, walked by one wavefront ------------------------------------------------------
-// RGB 2 = silhouette only (soft_colors / grads are alpha planes).  COMMON = the production case (gradient arrives 2x2-pooled,
-// power-of-two image, double-sided faces) as compile-time facts: the wave-uniform flags otherwise live as 64-bit lane masks
-// in SGPRs that spill (v_readlane per visit).  LEAN = the lean geometry of raster_core.h (faces flagged lean_ok) instead of
-// the reference-order eval_pair; the two are separate instantiations so that each gets its own register allocation.
+template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
+// COMMON = the production case (gradient arrives 2x2-pooled, power-of-two image, double-sided faces) as compile-time
+// facts: the wave-uniform flags otherwise live as 64-bit lane masks in SGPRs that spill (v_readlane per visit)
+#ifndef BWD_WPE
+#define BWD_WPE 7
+#endif
+#define BWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BWD_WPE, BWD_WPE)))
+__global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_fm(const RasterArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
+    const int F = A.F, IS = A.IS, TS = A.TS;
+    const bool pooled = COMMON ? true : (A.grad_pooled != 0);
+    const bool two_sided = COMMON ? true : (A.double_side != 0);
+    // Wave-uniform float constants of the visit body, held in VGPRs on purpose: with the 32-float face record in SGPRs
+    // the scalar file is full, and every constant the allocator spills comes back as a v_readlane (VALU) per visit.
+    // As VALU operands they are as cheap from a VGPR.  (#define FM_VCONST 0 keeps them scalar for A/B.)
 #if FM_VCONST
 #define FM_V(x) ({ float v_; asm volatile("v_mov_b32 %0, %1" : "=v"(v_) : "s"(x)); v_; })
 #else
 #define FM_V(x) (x)
 #endif
-template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON, bool LEAN>
-__device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const int f, const int lane, float *wave_tex) {
-    const int F = A.F, IS = A.IS, TS = A.TS;
-    const bool pooled = COMMON ? true : (A.grad_pooled != 0);
-    const bool two_sided = COMMON ? true : (A.double_side != 0);
-    constexpr bool live = true;
-    constexpr bool lean = LEAN;
-    // Wave-uniform float constants of the visit body, held in VGPRs on purpose: with the 32-float face record in SGPRs
-    // the scalar file is full, and every constant the allocator spills comes back as a v_readlane (VALU) per visit.
-    // As VALU operands they are as cheap from a VGPR.  (#define FM_VCONST 0 keeps them scalar for A/B.)
     const float c_near = FM_V(A.near_), c_far = FM_V(A.far_), c_rr = FM_V(A.r_range), c_ig = FM_V(A.inv_gamma);
     const float c_thr2 = FM_V(A.threshold), c_nis = FM_V(A.nis);
+    // XCD-aware: hardware XCD = blockIdx % 8.  Each XCD owns a fixed contiguous EIGHTH of every mesh's faces
+    // (index-neighbouring faces of a subdivided mesh are spatial neighbours), so the per-pixel state its waves
+    // re-read (~6x) covers 1/8 of the screen and stays in that XCD's 4 MB L2, and all 8 XCDs share every mesh
+    // (balance at small N).  Measured fabric reads: 47 MB/mesh round-robin -> ~20 MB/mesh (11.8 MB algorithmic).
+    const int fblocks = (F + FM_WAVES - 1) / FM_WAVES;   // blocks per mesh (grid = N * fblocks)
+    int nb = blockIdx.x / fblocks, fb = blockIdx.x % fblocks;
+    if (fblocks % 8 == 0 && (A.N * fblocks) % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = fblocks >> 3;
+        nb = slot / per;
+        fb = __builtin_amdgcn_readfirstlane(fm_owned_face(xcd, slot % per, per, A.fm_split));   // (uniform; the division hides it)
+    }
+    int fidx = fb * FM_WAVES + wave;
+    if (FM_WAVES == 1 && A.order) {   // cost-ordered start (k_face_order): same XCD ownership, heavy faces first
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gsz = A.order_group * (F >> 3);
+        const int g = slot / gsz;
+        const int e = A.order[((size_t)g * 8 + xcd) * gsz + slot % gsz];
+        nb = g * A.order_group + (e >> 16);
+        fidx = e & 0xffff;
+    }
+    const bool live = fidx < F;
+    const int n = nb, f = live ? fidx : 0;
     const size_t npix = (size_t)IS * IS;
     // wave-uniform bases of this mesh's per-pixel planes; every per-pixel load below is base + 32-bit byte offset
     const int H2 = IS >> 1;
@@ -328,42 +347,21 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
     const char *sc_n = (const char *)(A.soft_colors + (size_t)n * cplanes * npix);
     const char *ag_n = (const char *)(A.aggrs + (size_t)n * 2 * npix);
     const char *gc_n = (const char *)(A.grad_colors + (size_t)n * cplanes * (pooled ? (size_t)H2 * H2 : npix));
+    float *wave_tex = s_tex + (size_t)wave * FM_TEXCOPY * FM_TEX_STRIDE(TS);
     // this lane's copy: horizontally and vertically adjacent pixels of a 4x4 / 8x8 tile get different copies
     float *my_tex = wave_tex + ((lane ^ (lane >> 2) ^ (lane >> 4)) & (FM_TEXCOPY - 1)) * FM_TEX_STRIDE(TS);
     if (NEED_GT && TS > 1)
         for (int j = lane; j < FM_TEXCOPY * FM_TEX_STRIDE(TS); j += 64) wave_tex[j] = 0.f;
-    // Vertex-gradient accumulators.  Exact path: gv[0..8] = d/d(x0,y0,z0,x1,...).  Lean path (LeanFace): per edge e the
-    // sums S_e = sum c (Q - P) in gv[4e], gv[4e+1] and T_e = sum c t (Q - P) in gv[4e+2], gv[4e+3] of the pixels whose
-    // closest point lies on edge e -- vertex e receives S_e - T_e, vertex e+1 receives T_e (folded after the walk) -- and
-    // the depth gradients in gz[].
-    float gv[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gz[3] = {0.f, 0.f, 0.f};
+    float gv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f;  // TS == 1 texel gradient
     bool visited = false;                   // wave-uniform: some sub-tile survived the culling pass
     if (live) {
         // VGPR-resident operands where the register budget of 7 waves / SIMD has room for them (silhouette and
-        // texel-gradient-only variants: 56-60 VGPRs with them; the full variant would spill).  Variants that carry the
-        // lean path keep the exact path on the SGPR record: only the rare ill-conditioned faces take it.
-        static_assert(!LEAN || RGB != 0, "the hard-colour variants have no lean path");
-        constexpr bool LEAN_T = LEAN;
-        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF) && !LEAN;
+        // texel-gradient-only variants: 56-60 VGPRs with them; the full variant would spill)
+        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF);
         typename std::conditional<VREC, FaceV, Face>::type fc;
         load_face(fc, A.rec + ((size_t)n * F + f) * REC);
         if constexpr (VREC) fc.fill();
-        LeanFace L;
-        float vinv[9];
-        if constexpr (LEAN_T) {
-            lean_setup(L, fc);
-            if (RGB == 1) {
-#define UMR_VMOV(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
-                UMR_VMOV(vinv[0], fc.template g<R_INV + 0>()); UMR_VMOV(vinv[1], fc.template g<R_INV + 1>());
-                UMR_VMOV(vinv[2], fc.template g<R_INV + 2>()); UMR_VMOV(vinv[3], fc.template g<R_INV + 3>());
-                UMR_VMOV(vinv[4], fc.template g<R_INV + 4>()); UMR_VMOV(vinv[5], fc.template g<R_INV + 5>());
-                UMR_VMOV(vinv[6], fc.template g<R_INV + 6>()); UMR_VMOV(vinv[7], fc.template g<R_INV + 7>());
-                UMR_VMOV(vinv[8], fc.template g<R_INV + 8>());
-#undef UMR_VMOV
-            }
-        }
         const float *__restrict__ tex_f = A.textures + ((size_t)(n / A.tex_group) * F + f) * TS * 3;
         // pixel-index window of the dilated bbox, widened by one pixel; the exact per-pixel reject of the
         // reference (:536) still runs inside eval_pair, so the window only has to be conservative.
@@ -388,7 +386,11 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
             const float4 i1 = make_float4(fc.template g<R_INV + 4>(), fc.template g<R_INV + 5>(), fc.template g<R_INV + 6>(), fc.template g<R_INV + 7>());
             const float4 i2 = make_float4(fc.template g<R_INV + 8>(), fc.template g<R_K0>(), fc.template g<R_K1>(), fc.template g<R_K2>());
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
+#ifdef FM_NO_CULL            // time-split experiment (tools/r3/split.sh): per-face set-up and reductions only
+            for (int tb = ntiles; tb < ntiles; tb += 64) {
+#else
             for (int tb = 0; tb < ntiles; tb += 64) {
+#endif
                 // one lane per sub-tile: drop those no pixel of which can survive (conservative), then walk the rest
                 const int ti = tb + lane;
                 bool want = false;
@@ -439,6 +441,9 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
                 }
                 unsigned long long tm = __ballot(want);
                 visited |= tm != 0;
+#ifdef FM_NO_VISIT          // time-split experiment (tools/r3/split.sh): per-face set-up + culling pass only
+                tm = 0;
+#endif
                 while (tm) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
                     int mine = -1;
@@ -451,7 +456,7 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
                             if (sub == qq) mine = e;
                         }
                     }
-                    if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2 && !lean) {
+                    if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2) {
                         // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
                         // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop.  Only for the variants that
                         // also carry the 9 vertex-gradient accumulators and the colour path (measured 4-6 % faster with
@@ -486,94 +491,6 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
                             }
                         }
                         if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;
-                    }
-                    if constexpr (LEAN_T) {
-                        if (lean) {
-                            // ---- lean geometry: the same closest boundary point from three clamped edge projections ----
-                            LeanSeg sg;
-                            bool inside;
-                            float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-                            if (RGB == 2) {
-                                inside = lean_segments<true>(sg, L, xp, yp) > 0.f;
-                            } else {
-                                lean_segments<false>(sg, L, xp, yp);
-                                // barycentrics in the reference's operation order: they pick the texel and feed the depth
-                                w0 = (vinv[0] * xp + vinv[1] * yp) + vinv[2];
-                                w1 = (vinv[3] * xp + vinv[4] * yp) + vinv[5];
-                                w2 = (vinv[6] * xp + vinv[7] * yp) + vinv[8];
-                                inside = fminf(fminf(w0, w1), w2) > 0.f && fmaxf(fmaxf(w0, w1), w2) < 1.f;
-                            }
-                            const float dmin = fminf(fminf(sg.d2[0], sg.d2[1]), sg.d2[2]);
-                            if (!(inside || dmin < c_thr2)) continue;                 // :382 (the bbox reject :355 is implied)
-                            const float frag = __builtin_amdgcn_rcpf(1.f + __expf((inside ? dmin : -dmin) * c_nis));   // :383
-                            // nearest edge, first minimum; its weight for the per-edge accumulators
-                            const bool m0 = sg.d2[0] <= fminf(sg.d2[1], sg.d2[2]);
-                            const bool m1 = !m0 && sg.d2[1] <= sg.d2[2];
-                            float c_xy = 0.f;
-                            if (RGB == 2) {
-                                if (!fc.depth_in_range()) {
-                                    Pair pw;
-                                    pw.w0 = (fc.template g<R_INV + 0>() * xp + fc.template g<R_INV + 1>() * yp) + fc.template g<R_INV + 2>();
-                                    pw.w1 = (fc.template g<R_INV + 3>() * xp + fc.template g<R_INV + 4>() * yp) + fc.template g<R_INV + 5>();
-                                    pw.w2 = (fc.template g<R_INV + 6>() * xp + fc.template g<R_INV + 7>() * yp) + fc.template g<R_INV + 8>();
-                                    float u0, u1, u2;
-                                    const float zq = clip_depth(u0, u1, u2, pw, fc);
-                                    if (zq < c_near || zq > c_far) continue;  // :592
-                                }
-                                const float ga = (pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
-                                UMR_TRAP_IF(umr_bad(ga), 3);
-                                const float oa = ld_u(sc_n, pn4);
-                                c_xy = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - frag, 1e-6f)));   // :584
-                            } else {
-                                const float gscale = pooled ? 0.25f : 1.f;
-                                const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
-                                            g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
-                                const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
-                                UMR_TRAP_IF(umr_bad(g0) | umr_bad(g1) | umr_bad(g2) | umr_bad(g3), 3);
-                                const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
-                                if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - frag, 1e-6f)));  // :584
-                                Pair pw; pw.w0 = w0; pw.w1 = w1; pw.w2 = w2;
-                                float q0, q1, q2;
-                                const float zp = clip_depth(q0, q1, q2, pw, fc);
-                                if (zp < c_near || zp > c_far) continue;  // :592
-                                if (two_sided || fc.front()) {
-                                    const float zn = div_r(c_far - zp, c_far - c_near, c_rr);
-                                    const float ps = frag * __expf((zn - smax) * c_ig) * __builtin_amdgcn_rcpf(ssum);  // :608
-                                    const int tix = texel_index(q0, q1, A.R);
-                                    if (NEED_GT) {
-                                        if (TS == 1) { FM_ACC(gt0, ps, g0); FM_ACC(gt1, ps, g1); FM_ACC(gt2, ps, g2); }
-                                        else texel_accumulate(my_tex, tix, ps * g0, ps * g1, ps * g2, lane);
-                                    }
-                                    if (NEED_GF) {
-                                        const char *tx = (const char *)tex_f;
-                                        const unsigned t12 = (unsigned)tix * 12u;
-                                        float c_rgb = g0 * (ld_u(tx, t12) - ld_u(sc_n, pn4));
-                                        c_rgb += g1 * (ld_u(tx, t12 + 4) - ld_u(sc_n, pn4 + pst));
-                                        c_rgb += g2 * (ld_u(tx, t12 + 8) - ld_u(sc_n, pn4 + 2 * pst));
-                                        c_rgb *= ps;
-                                        c_xy += c_rgb * __builtin_amdgcn_rcpf(frag);
-                                        const float c_z = -(c_rgb * c_ig * c_rr) * zp * zp;  // :624
-                                        gz[0] += c_z * q0 * fc.template g<R_RZ0>() * fc.template g<R_RZ0>();
-                                        gz[1] += c_z * q1 * fc.template g<R_RZ1>() * fc.template g<R_RZ1>();
-                                        gz[2] += c_z * q2 * fc.template g<R_RZ2>() * fc.template g<R_RZ2>();
-                                    }
-                                }
-                            }
-                            if (NEED_GF) {
-                                c_xy *= frag * (1.f - frag) * (-c_nis);                 // :632
-                                const float k2 = inside ? -2.f * c_xy : 2.f * c_xy;      // :640 with Q - P = -q
-                                // grad vertex k += 2 sign c b_k (Q - P) with b = (1 - t, t) on the nearest edge's end points
-#pragma unroll
-                                for (int e = 0; e < 3; ++e) {
-                                    const float ce = (e == 0 ? m0 : (e == 1 ? m1 : !(m0 || m1))) ? k2 : 0.f;
-                                    const float wx = ce * sg.qx[e], wy = ce * sg.qy[e];
-                                    gv[4 * e] += wx; gv[4 * e + 1] += wy;
-                                    gv[4 * e + 2] = fmaf(sg.t[e], wx, gv[4 * e + 2]);
-                                    gv[4 * e + 3] = fmaf(sg.t[e], wy, gv[4 * e + 3]);
-                                }
-                            }
-                            continue;
-                        }
                     }
                     Pair p;
                     if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis)) continue;
@@ -650,26 +567,12 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
 #ifndef FM_SKIP_EMPTY
 #define FM_SKIP_EMPTY 1   // a face none of whose sub-tiles survived the culling pass (half the mesh under a texel-gradient
 #endif                    // launch) adds exact zeros: skip its lane reductions, LDS read-out and read-modify-write stores
-    if (FM_SKIP_EMPTY && !visited) return;
+    if (FM_SKIP_EMPTY && FM_WAVES == 1 && !visited) return;
     if (NEED_GF) {
-        float out[9];
-        if (lean) {   // fold the per-edge sums: vertex v = start of edge v (S - T) + end of edge v - 1 (T)
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int pe = (v + 2) % 3;
-                out[3 * v] = (gv[4 * v] - gv[4 * v + 2]) + gv[4 * pe + 2];
-                out[3 * v + 1] = (gv[4 * v + 1] - gv[4 * v + 3]) + gv[4 * pe + 3];
-                out[3 * v + 2] = gz[v];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) out[k] = gv[k];
-        }
         float mine = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            if (RGB == 2 && k % 3 == 2) continue;          // no depth gradient from the silhouette
-            const float sv = wave_sum_full(out[k]);
+            const float sv = wave_sum_full(gv[k]);
             if (lane == k) mine = sv;
         }
         UMR_TRAP_IF(umr_bad(mine), 4);
@@ -680,7 +583,7 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
             const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
             if (live && lane < 3) A.grad_textures[((size_t)n * F + f) * 3 + lane] += lane == 0 ? s0 : (lane == 1 ? s1 : s2);
         } else {
-            __syncthreads();  // one wave per workgroup: orders this wave's LDS atomics before its read-out
+            __syncthreads();  // every wave arrives exactly once; orders the LDS atomics before the read-out
             if (live) {
                 float *dst = A.grad_textures + ((size_t)n * F + f) * TS * 3;
                 for (int j = lane; j < TS * 3; j += 64) {
@@ -695,100 +598,14 @@ __device__ __forceinline__ void fm_face(const RasterArgs &A, const int n, const 
     }
 }
 
-// wave-uniform: does face (n, f) take the lean path?  (flag word of its record through the scalar cache)
-template <int RGB>
-__device__ __forceinline__ bool fm_face_is_lean(const RasterArgs &A, int n, int f) {
-    if (!(FM_LEAN != 0 && RGB != 0) || !A.bwd_lean) return false;
-    typedef const __attribute__((address_space(4))) int cint_t;
-    const int flags = *(cint_t *)(A.rec + ((size_t)n * A.F + f) * REC + R_FLAGS);
-    return (flags & 32) != 0;
-}
-
-#ifndef BWD_WPE
-#define BWD_WPE 7
-#endif
-// occupancy per variant: the lean path keeps 16-25 per-lane face constants next to the accumulators (12 per-edge sums for
-// the vertex gradients), so the lean colour variants with vertex gradients take 5 waves (96 VGPRs), texel-only 6 (80)
-#define BWD_WPE_V ((LEAN && RGB == 1) ? (NEED_GF ? BWD_WPE - 2 : BWD_WPE - 1) : BWD_WPE)
-#define BWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BWD_WPE_V, BWD_WPE_V)))
-// Main kernel: one workgroup = one wavefront = one face.  With LEAN it walks the faces flagged lean_ok and leaves the
-// others to k_raster_backward_fm_exc; without (hard colour, or umr_debug_set("bwd_lean", 0)) it walks every face.
-template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON, bool LEAN>
-__global__ __launch_bounds__(64) BWD_WPE_ATTR void k_raster_backward_fm(const RasterArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_TEXCOPY][FM_TEX_STRIDE(TS)]
-    const int lane = threadIdx.x & 63;
-    const int F = A.F;
-    // XCD-aware: hardware XCD = blockIdx % 8.  Each XCD owns a fixed contiguous EIGHTH of every mesh's faces
-    // (index-neighbouring faces of a subdivided mesh are spatial neighbours), so the per-pixel state its waves
-    // re-read (~6x) covers 1/8 of the screen and stays in that XCD's 4 MB L2, and all 8 XCDs share every mesh
-    // (balance at small N).  Measured fabric reads: 47 MB/mesh round-robin -> ~20 MB/mesh (11.8 MB algorithmic).
-    const int fblocks = F;   // blocks per mesh (grid = N * F)
-    int nb = blockIdx.x / fblocks, fb = blockIdx.x % fblocks;
-    if (fblocks % 8 == 0 && (A.N * fblocks) % 8 == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = fblocks >> 3;
-        nb = slot / per;
-        fb = __builtin_amdgcn_readfirstlane(fm_owned_face(xcd, slot % per, per, A.fm_split));   // (uniform; the division hides it)
-    }
-    int fidx = fb;
-    if (A.order) {   // cost-ordered start (k_face_order): same XCD ownership, heavy faces first
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gsz = A.order_group * (F >> 3);
-        const int g = slot / gsz;
-        const int e = A.order[((size_t)g * 8 + xcd) * gsz + slot % gsz];
-        nb = g * A.order_group + (e >> 16);
-        fidx = e & 0xffff;
-    }
-    if (fidx >= F) return;
-    const int n = nb, f = fidx;
-    if (fm_face_is_lean<RGB>(A, n, f) != LEAN) return;
-    fm_face<RGB, NEED_GF, NEED_GT, COMMON, LEAN>(A, n, f, lane, s_tex);
-}
-
-// Exception pass behind a LEAN main kernel: the faces NOT flagged lean_ok (needles, slivers, sub-pixel faces, off-screen
-// giants), normally none or a few per mesh.  Each wavefront looks at FM_EXC_CHUNK consecutive faces' flag words and walks
-// the unflagged ones with the reference-order geometry; with none the launch is a flag read per face.
-#define FM_EXC_CHUNK 8
-template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BWD_WPE, BWD_WPE))) void k_raster_backward_fm_exc(const RasterArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float s_tex[];
-    const int lane = threadIdx.x & 63;
-    const long total = (long)A.N * A.F, base = (long)blockIdx.x * FM_EXC_CHUNK;
-    bool exc = false;
-    if (lane < FM_EXC_CHUNK && base + lane < total)
-        exc = (__float_as_int(A.rec[(size_t)(base + lane) * REC + R_FLAGS]) & 32) == 0;
-    unsigned long long m = __ballot(exc);
-    while (m) {
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        const long i = base + b;
-        fm_face<RGB, NEED_GF, NEED_GT, COMMON, false>(A, (int)(i / A.F), (int)(i % A.F), lane, s_tex);
-    }
-}
-
-template <int RGB, bool COMMON, bool LEAN>
-void launch_backward_fm3(const RasterArgs &A, hipStream_t st) {
-    const int blocks = A.N * A.F;
-    const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
-    const int eblocks = (int)(((long)A.N * A.F + FM_EXC_CHUNK - 1) / FM_EXC_CHUNK);
-    if (RGB == 2) {
-        k_raster_backward_fm<2, true, false, COMMON, LEAN><<<blocks, 64, 0, st>>>(A);
-        if (LEAN) k_raster_backward_fm_exc<2, true, false, COMMON><<<eblocks, 64, 0, st>>>(A);
-    } else if (A.need_gf && A.need_gt) {
-        k_raster_backward_fm<RGB, true, true, COMMON, LEAN><<<blocks, 64, lds, st>>>(A);
-        if (LEAN) k_raster_backward_fm_exc<RGB, true, true, COMMON><<<eblocks, 64, lds, st>>>(A);
-    } else if (A.need_gf) {
-        k_raster_backward_fm<RGB, true, false, COMMON, LEAN><<<blocks, 64, lds, st>>>(A);
-        if (LEAN) k_raster_backward_fm_exc<RGB, true, false, COMMON><<<eblocks, 64, lds, st>>>(A);
-    } else {
-        k_raster_backward_fm<RGB, false, true, COMMON, LEAN><<<blocks, 64, lds, st>>>(A);
-        if (LEAN) k_raster_backward_fm_exc<RGB, false, true, COMMON><<<eblocks, 64, lds, st>>>(A);
-    }
-}
 template <int RGB, bool COMMON>
 void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
-    if constexpr (FM_LEAN != 0 && RGB != 0) {
-        if (A.bwd_lean) { launch_backward_fm3<RGB, COMMON, true>(A, st); return; }
-    }
-    launch_backward_fm3<RGB, COMMON, false>(A, st);
+    const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
+    const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
+    if (RGB == 2) k_raster_backward_fm<2, true, false, COMMON><<<blocks, FM_WAVES * 64, 0, st>>>(A);
+    else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else if (A.need_gf) k_raster_backward_fm<RGB, true, false, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    else k_raster_backward_fm<RGB, false, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
 }
 template <int RGB>
 void launch_backward_fm(const RasterArgs &A, hipStream_t st) {

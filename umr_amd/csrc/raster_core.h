@@ -67,7 +67,6 @@ struct RasterArgs {
     float *vis;         // k_raster_forward<1, .., VIS>: hard z-buffer planes [N,2,IS,IS] = (nearest depth, its face id | -1),
                         // written next to the soft-max render of the same faces (umr_raster_forward_vis)
     int no_xcd_remap;   // A/B switch (umr_debug_set("xcd_remap", 0)): pixel-major work items in plain blockIdx order
-    int bwd_lean;     // face-major backward: faces flagged lean_ok take the lean geometry (umr_debug_set("bwd_lean", 0 | 1))
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
 };
@@ -172,24 +171,6 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         // branch the reference's way (all three edge lines, smallest computed distance).  NaN den: flagged as well.
         if (!(fabsf(den) >= 1e-5f)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
     }
-    // bit 5: well conditioned for the lean geometry of the face-major backward (lean_segments below): finite on-screen-sized
-    // coordinates, every edge longer than 0.01 (2.6 px at IS = 512) and no height below 1/16 of the longest edge.  Outside
-    // this class the reference's own arithmetic is ill conditioned (its distances follow rounding noise: needles, slivers,
-    // sub-pixel faces) and the backward reproduces it operation by operation (eval_pair) instead.
-    {
-        float lmin = 3.0e38f, lmax = 0.f, kmin = 3.0e38f;
-        bool fin = true;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int a = (c + 1) % 3;
-            const float ex = px[a] - px[c], ey = py[a] - py[c], l2 = ex * ex + ey * ey;
-            lmin = fminf(lmin, l2); lmax = fmaxf(lmax, l2);
-            kmin = fminf(kmin, r[R_K0 + c]);
-            fin = fin && fabsf(px[c]) <= 8.f && fabsf(py[c]) <= 8.f;     // false for NaN
-        }
-        const bool lean = fin && lmin >= 1e-4f && kmin * 256.f >= lmax && !(__float_as_int(r[R_FLAGS]) & 16);
-        if (lean) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 32);
-    }
 #pragma unroll
     for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
 }
@@ -237,7 +218,6 @@ struct Face {  // wave-uniform: 32 SGPRs + the record's address
     __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
     __device__ __forceinline__ bool depth_in_range() const { return (__float_as_int(g<R_FLAGS>()) & 8) != 0; }
     __device__ __forceinline__ bool ill_conditioned() const { return (__float_as_int(g<R_FLAGS>()) & 16) != 0; }
-    __device__ __forceinline__ bool lean_ok() const { return (__float_as_int(g<R_FLAGS>()) & 32) != 0; }
 };
 
 struct FaceV : Face {   // + 15 VGPRs per lane, filled once per face by the face-major backward (a wave owns one face)
@@ -410,71 +390,6 @@ __device__ __forceinline__ int texel_index(float c0, float c1, int R) {  // :180
     const int wx = (int)(c0 * R), wy = (int)(c1 * R);
     if ((c0 + c1) * R - wx - wy <= 1) return wy * R + wx;
     return (R - 1 - wy) * R + (R - 1 - wx);
-}
-
-// ---- lean geometry (face-major backward, faces flagged lean_ok by k_face_setup) --------------------------------------
-// The reference obtains the closest boundary point through barycentrics of O(1) homogeneous products (:63-152): region
-// tables, one edge parameter from differences of `face_sym`, the offset as sum_k (t_k - w_k) p_k.  Mathematically that IS
-// the Euclidean closest point of the triangle's boundary (the obtuse-corner override exists to make it so), so for a
-// well-conditioned face the same point follows from the three clamped edge projections directly: per edge e = (A, A + E)
-//   t = clamp(<P - A, E> / |E|^2, 0, 1),  q = (P - A) - t E = P - Q_e,  d2_e = |q|^2,
-// 9 full-rate VALU each on operands relative to the face's own vertices (no cancellation of O(1) terms), and the nearest
-// of the three is the reference's point; inside the triangle the clamp never acts (the foot on the nearest edge's line
-// lies on the edge), so one formula serves both branches.  The FORWARD keeps the reference's operation order -- outside
-// the silhouette colours are ratios of weights ~1e-9 and have to carry the reference's own rounding noise to agree within
-// 1e-4 -- but gradients are sums of such terms and are held to a relative tolerance; what differs is the reference's
-// rounding noise in d^2 (~1e-7 absolute in the offset: up to ~1e-3 relative in D at the rim of the 3.9 px band, ~1e-5
-// near the edge where the weight is).
-struct LeanFace {   // per lane (VGPRs; the face is wave-uniform, the copies make every operand a full-rate VGPR source)
-    float ax[3], ay[3];   // edge e starts at vertex e ...
-    float ex[3], ey[3];   // ... and runs to vertex e + 1
-    float rl[3];          // 1 / |E_e|^2
-    float orient;         // +1 | -1: sign that makes the edge functions positive inside
-};
-
-template <class FaceT>
-__device__ __forceinline__ void lean_setup(LeanFace &L, const FaceT &fc) {
-    float x[3], y[3];
-#ifdef UMR_HOST_SHIM
-    x[0] = fc.template g<R_X0>(); y[0] = fc.template g<R_Y0>(); x[1] = fc.template g<R_X1>(); y[1] = fc.template g<R_Y1>();
-    x[2] = fc.template g<R_X2>(); y[2] = fc.template g<R_Y2>();
-#else
-#define UMR_VMOV(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
-    UMR_VMOV(x[0], fc.template g<R_X0>()); UMR_VMOV(y[0], fc.template g<R_Y0>()); UMR_VMOV(x[1], fc.template g<R_X1>());
-    UMR_VMOV(y[1], fc.template g<R_Y1>()); UMR_VMOV(x[2], fc.template g<R_X2>()); UMR_VMOV(y[2], fc.template g<R_Y2>());
-#undef UMR_VMOV
-#endif
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        const int b = (e + 1) % 3;
-        L.ax[e] = x[e]; L.ay[e] = y[e];
-        L.ex[e] = x[b] - x[e]; L.ey[e] = y[b] - y[e];
-        L.rl[e] = 1.f / (L.ex[e] * L.ex[e] + L.ey[e] * L.ey[e]);   // >= 1e-4 for flagged faces
-    }
-    // edge function of edge 0 at vertex 2 = twice the signed area
-    L.orient = (L.ex[0] * (y[2] - y[0]) - L.ey[0] * (x[2] - x[0])) > 0.f ? 1.f : -1.f;
-}
-
-struct LeanSeg { float qx[3], qy[3], t[3], d2[3]; };   // per edge: P - Q_e, parameter of Q_e, squared distance
-
-template <bool EDGE_FN>
-__device__ __forceinline__ float lean_segments(LeanSeg &s, const LeanFace &L, float xp, float yp) {
-    // returns (EDGE_FN) the smallest oriented edge function: > 0 <=> the pixel centre is strictly inside
-    float cmin = 0.f;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        const float px = xp - L.ax[e], py = yp - L.ay[e];
-        const float u = fmaf(px, L.ex[e], py * L.ey[e]);
-        const float t = fminf(fmaxf(u * L.rl[e], 0.f), 1.f);
-        const float qx = fmaf(-t, L.ex[e], px), qy = fmaf(-t, L.ey[e], py);
-        s.qx[e] = qx; s.qy[e] = qy; s.t[e] = t;
-        s.d2[e] = fmaf(qx, qx, qy * qy);
-        if (EDGE_FN) {
-            const float c = fmaf(L.ex[e], py, -(L.ey[e] * px)) * L.orient;
-            cmin = e == 0 ? c : fminf(cmin, c);
-        }
-    }
-    return cmin;
 }
 
 // Conservative "can any pixel centre of this tile survive the reference's rejects?" test.  A pixel whose

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                 }
             }
             unsigned long long m = __ballot(hit);
+#ifdef FWD_NO_VISIT         // time-split experiment (tools/r3): binning and tile filter only
+            m = 0;
+#endif
             while (m) {
                 const int b = __builtin_ctzll(m);
                 m &= m - 1;
