@@ -189,6 +189,9 @@ int umr_project_faces_lit_backward(const float *grad_face_out, const float *grad
  * host in the reference; call sites experiments/train_s1.py:233, train_s2.py:257).  cam, out [B,7]; forward only
  * (both call sites detach the camera).  out = [s, tx, ty, q'] with q' = q_y(angle) (x) q, unit norm, q'_w >= 0. */
 int umr_rotate_cam_y(const float *cam, const float *angle_deg, float *out, int B, void *stream);
+/* ... and about any axis (HOST pointer to 3 floats; the reference's cv2.Rodrigues(rad_angle * axis) rotates by |rad_angle * axis|
+ * about axis / |axis|, so a non-unit axis scales the angle). */
+int umr_rotate_cam_axis(const float *cam, const float *angle_deg, const float *axis3, float *out, int B, void *stream);
 
 /* vertices only, no flip, no look_at:
  *   out_dim 2: SoftRenderer.project_points / orthographic_proj (nnutils/smr.py:76-78, geom_utils.py:60-72)
@@ -357,6 +360,54 @@ int umr_upsample2x_bilinear_backward(const float *grad_out, float *grad_in, long
 int umr_texture_atlas_shape(int F, int res_out, int *height, int *width);
 int umr_texture_atlas(const float *textures, float *image, unsigned char *image_u8, float *uv, int F, int res_in,
                       int res_out, float eps, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small regularisers and the masked L1 image term (csrc/regs.hip).  Replace the torch op chains of
+ *   deform_l2reg        nnutils/loss_utils.py:118-123   out[0] = mean over rows of ||x_row||_2,  x [rows, width]
+ *   sym_reg             nnutils/loss_utils.py:125-126   out[0] = mean |x[row, column]|           (verts [B*V,3], column 1)
+ *   texture_loss_masks  nnutils/loss_utils.py:103-116   per_sample[b] = mean_{c,p} |img_pred mask_pred - img_gt mask_gt|
+ *                       (img [B,C,HW], masks [B,HW]); the avg=True form is the mean of per_sample
+ * Two-stage sums in a fixed order (no float atomics): `scratch` holds the per-block partials,
+ * umr_reg_scratch_floats(elements, batch) floats (elements = rows, or C*HW with batch = B).
+ * backward: grad_x / grad_img_pred / grad_mask_pred are OVERWRITTEN (either masked-L1 gradient may be NULL); the norm's
+ * gradient at a zero row and sign(0) are 0, as in torch.
+ * -------------------------------------------------------------------------------------------*/
+long umr_reg_scratch_floats(long elements, int batch);
+int umr_row_norm_mean_forward(const float *x, float *out, float *scratch, size_t scratch_bytes, long rows, int width, void *stream);
+int umr_row_norm_mean_backward(const float *x, const float *grad_out, float *grad_x, long rows, int width, void *stream);
+int umr_abs_mean_forward(const float *x, float *out, float *scratch, size_t scratch_bytes, long rows, int width, int column,
+                         void *stream);
+int umr_abs_mean_backward(const float *x, const float *grad_out, float *grad_x, long rows, int width, int column, void *stream);
+int umr_masked_l1_forward(const float *img_pred, const float *img_gt, const float *mask_gt, const float *mask_pred,
+                          float *per_sample, float *scratch, size_t scratch_bytes, int B, int C, long HW, void *stream);
+int umr_masked_l1_backward(const float *img_pred, const float *img_gt, const float *mask_gt, const float *mask_pred,
+                           const float *grad_per_sample, float *grad_img_pred, float *grad_mask_pred, int B, int C, long HW,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Keypoint-transfer evaluation (csrc/eval.hip).  Replaces the per-pair host loops of experiments/test_kp.py:
+ *   flow mode  :125-158  keypoint -> face (arg-max over faces of the keypoint heat map, utils/kp_utils.py:42-69, sampled at
+ *                        the source texture flow) -> image point (mean of the coordinate grid sampled at the target flow)
+ *   cam mode   :160-193  keypoint -> nearest projected template vertex (source camera) -> nearest foreground pixel of the
+ *                        target mask to that vertex (target camera)
+ *   PCK        :253-258, :317-323  integer counters [3,K] = (visible, err < thr_a, err < thr_b) per keypoint, ADDED into
+ * One call maps `pairs` independent (source, target) entries (a test pair is two entries, one per direction).
+ *   kp_src [pairs,K,kp_stride>=2] in [-1,1]; flow_* [pairs,F,TT,2]; patch [(6 sigma+1)^2] = the Gaussian of draw_labelmap
+ *   (caller computes it in float64 as the reference does); face_idx / vert_idx [pairs,K] int32; k2k [pairs,K,2];
+ *   kp_gt [pairs,K,gt_stride] + vis [pairs,K] + counters, all three or none; verts_src / verts_tgt [pairs,V,2] = template
+ *   vertices projected with the two cameras (umr_project_points_forward); mask_tgt [pairs,S,S] (non-zero = foreground);
+ *   pixel_of_vertex [pairs,V] int32 scratch/out (raster index of each vertex's foreground pixel, -1 for an empty mask).
+ * Ties go to the first index, as torch.max / torch.min do.
+ * -------------------------------------------------------------------------------------------*/
+size_t umr_kp_flow_workspace_bytes(int pairs, int K, int F);
+int umr_kp_flow_transfer(const float *kp_src, int kp_stride, const float *flow_src, const float *flow_tgt, const float *patch,
+                         int *face_idx, float *k2k, const float *kp_gt, int gt_stride, const float *vis, int *counters, int pairs,
+                         int K, int F, int TT, int image_size, int sigma, float padding_frac, float thr_a, float thr_b,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int umr_kp_cam_transfer(const float *kp_src, int kp_stride, const float *verts_src, const float *verts_tgt, const float *mask_tgt,
+                        int *vert_idx, int *pixel_of_vertex, float *k2k, const float *kp_gt, int gt_stride, const float *vis,
+                        int *counters, int pairs, int K, int V, int image_size, float padding_frac, float thr_a, float thr_b,
+                        void *stream);
 
 #ifdef __cplusplus
 }

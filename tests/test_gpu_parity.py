@@ -482,7 +482,9 @@ def test_cfg4_size_vs_oracle(oracle_built):
 
 
 def test_eval_metrics_vs_reference_restatement(oracle_built):
-    """BASELINE config 5: mask IoU and keypoint transfer (flow and cam modes) + PCK on synthetic pairs."""
+    """BASELINE config 5 at the model's size (1280 faces, 642 vertices): mask IoU, and the device keypoint-transfer kernels
+    (csrc/eval.hip) against the torch-CPU restatement of test_kp.py:125-193 on synthetic pairs -- the exact-index goldens
+    from the imported reference are in test_gpu_round3.py::test_keypoint_transfer_vs_reference_golden."""
     from oracle import torch_ref
     from umr_amd import eval_utils as EU
     from umr_amd.smr import SoftRenderer
@@ -497,36 +499,22 @@ def test_eval_metrics_vs_reference_restatement(oracle_built):
     inter = masks_gt * ref_pred
     iou_ref = inter.reshape(2, -1).sum(1) / (masks_gt + ref_pred - inter).reshape(2, -1).sum(1)
     np.testing.assert_allclose(t2n(iou), iou_ref.numpy(), atol=1e-5)
-    # --- flow mode (test_kp.py:125-158)
+    # --- flow mode (test_kp.py:125-158): smooth flows (a face's 36 texels land near each other, as a network's do)
     K = 15
-    kps = torch.rand(2, K, 3, generator=g) * 2 - 1
+    kps = torch.rand(2, K, 3, generator=g) * 1.8 - 0.9
     kps[0, 0, :2] = torch.tensor([-0.99, 0.98])      # patch clipped by the image border
-    flows = torch.rand(2, 1280, 6, 6, 2, generator=g) * 2 - 1
+    flows = (torch.rand(2, 1280, 1, 1, 2, generator=g) * 1.6 - 0.8 + 0.08 * (torch.rand(2, 1280, 6, 6, 2, generator=g) - 0.5)).clamp(-1, 1)
     for a, b in ((0, 1), (1, 0)):
         got = EU.map_kp_flow(kps[a].to(DEV), flows[a].to(DEV), flows[b].to(DEV))
         ref = torch_ref.map_kp_flow(kps[a], flows[a], flows[b])
         assert got.shape == (K, 2)
-        same = (t2n(got) - ref.numpy())
-        assert (np.abs(same).max(1) < 1e-5).mean() >= 0.9      # arg-max ties on a random flow may pick another face
-    hm = EU.draw_labelmaps(((kps[0, :, :2] + 1) / 2 * 256).to(DEV), 256, 3)
-    for c in range(K):
-        ref_hm = torch_ref.draw_labelmap(np.zeros((256, 256)), (float((kps[0, c, 0] + 1) / 2 * 256), float((kps[0, c, 1] + 1) / 2 * 256)), 3)
-        np.testing.assert_allclose(t2n(hm[c]), ref_hm, atol=1e-6)
+        np.testing.assert_allclose(t2n(got), ref.numpy(), atol=1e-6)
     # --- cam mode (test_kp.py:160-193): ~30k foreground pixels x 642 projected vertices
     mean_shape = verts[0] * 0.9
     mask = (pred[1] > 0.5).float().cpu()
     got = EU.map_kp_cam(kps[0].to(DEV), cams[0].to(DEV), cams[1].to(DEV), mask.to(DEV), mean_shape.to(DEV))
     ref = torch_ref.map_kp_cam(kps[0], cams[0], cams[1], mask, mean_shape)
-    assert (np.abs(t2n(got) - ref.numpy()).max(1) < 1e-5).mean() >= 0.9
-    # --- PCK (test_kp.py:253-258, 317-323)
-    pred_k = torch.rand(6, K, 2, generator=g) * 0.3
-    gt_k = torch.rand(6, K, 2, generator=g) * 0.3
-    vis = (torch.rand(6, K, generator=g) > 0.2).float()
-    p1, p15 = EU.pck(pred_k.to(DEV), gt_k.to(DEV), vis.to(DEV))
-    err = np.sqrt(((pred_k - gt_k).numpy() ** 2).sum(2)) * (1 + 2 * 0.05) / 2.0
-    nv = vis.numpy().sum(0)
-    assert abs(p1 - (((err < 0.1) * vis.numpy()).sum(0) / nv).mean()) < 1e-6
-    assert abs(p15 - (((err < 0.15) * vis.numpy()).sum(0) / nv).mean()) < 1e-6
+    np.testing.assert_allclose(t2n(got), ref.numpy(), atol=1e-6)
 
 
 @pytest.mark.parametrize("rgb", ["softmax", "hard"])

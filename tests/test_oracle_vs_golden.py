@@ -299,3 +299,23 @@ def test_reference_algorithm_is_immune_to_collapsed_edges(oracle_built):
         assert np.isfinite(gt).all(), be      # (grad_faces may legitimately be huge for needles; texel gradients are weights)
     if len(outs) == 2:
         assert np.array_equal(outs[0], outs[1])
+
+
+def test_eval_restatement_vs_reference_golden():
+    """oracle/torch_ref.map_kp_flow / map_kp_cam (restatements of experiments/test_kp.py:125-193) pinned on the golden written
+    by the reference's own kp_utils / chamfer_python / smr (oracle/gen_golden_r3.py): transferred keypoints of every pair in
+    both directions, flow and cam mode."""
+    from oracle import torch_ref
+    g = load_golden("eval_kp.npz")
+    kps = torch.from_numpy(g["kps"]); flows = torch.from_numpy(g["flows"].astype(np.float32))
+    cams = torch.from_numpy(g["cams"]); masks = torch.from_numpy(g["masks"].astype(np.float32)); ms = torch.from_numpy(g["mean_shape"])
+    S, sigma = int(g["image_size"]), int(g["sigma"])
+    for p in range(kps.shape[0]):
+        a = torch_ref.map_kp_flow(kps[p, 0], flows[p, 0], flows[p, 1], S, sigma)
+        b = torch_ref.map_kp_flow(kps[p, 1], flows[p, 1], flows[p, 0], S, sigma)
+        np.testing.assert_allclose(a.numpy(), g["flow_k1_to_k2"][p], atol=1e-6)
+        np.testing.assert_allclose(b.numpy(), g["flow_k2_to_k1"][p], atol=1e-6)
+        c = torch_ref.map_kp_cam(kps[p, 0], cams[p, 0], cams[p, 1], masks[p, 1], ms, S)
+        d = torch_ref.map_kp_cam(kps[p, 1], cams[p, 1], cams[p, 0], masks[p, 0], ms, S)
+        np.testing.assert_allclose(c.numpy(), g["cam_k1_to_k2"][p], atol=1e-6)
+        np.testing.assert_allclose(d.numpy(), g["cam_k2_to_k1"][p], atol=1e-6)

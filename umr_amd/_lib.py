@@ -32,6 +32,7 @@ SIGNATURES = {
     "umr_project_workspace_bytes": ([_I, _I], _Z),
     "umr_project_faces_backward": ([_P] * 7 + [_I, _I, _I, _I, _P, _Z, _P], _I),
     "umr_rotate_cam_y": ([_P, _P, _P, _I, _P], _I),
+    "umr_rotate_cam_axis": ([_P, _P, ctypes.POINTER(_F), _P, _I, _P], _I),
     "umr_project_points_forward": ([_P] * 3 + [_I, _I, _I, _F, _P], _I),
     "umr_project_points_backward": ([_P] * 5 + [_I, _I, _I, _P], _I),
     "umr_neg_iou_sums_stride": ([_L], _L),
@@ -62,6 +63,16 @@ SIGNATURES = {
     "umr_dt_barrier": ([_P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P], _I),
     "umr_texture_atlas_shape": ([_I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)], _I),
     "umr_texture_atlas": ([_P, _P, _P, _P, _I, _I, _I, _F, _P], _I),
+    "umr_kp_flow_workspace_bytes": ([_I, _I, _I], _Z),
+    "umr_kp_flow_transfer": ([_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _Z, _P], _I),
+    "umr_kp_cam_transfer": ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P], _I),
+    "umr_reg_scratch_floats": ([_L, _I], _L),
+    "umr_row_norm_mean_forward": ([_P, _P, _P, _Z, _L, _I, _P], _I),
+    "umr_row_norm_mean_backward": ([_P, _P, _P, _L, _I, _P], _I),
+    "umr_abs_mean_forward": ([_P, _P, _P, _Z, _L, _I, _I, _P], _I),
+    "umr_abs_mean_backward": ([_P, _P, _P, _L, _I, _I, _P], _I),
+    "umr_masked_l1_forward": ([_P, _P, _P, _P, _P, _P, _Z, _I, _I, _L, _P], _I),
+    "umr_masked_l1_backward": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P], _I),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libumr_hip.so")
-SOURCES = ["raster.hip", "geometry.hip", "losses.hip", "perceptual.hip", "edt.hip", "atlas.hip"]
+SOURCES = ["raster.hip", "geometry.hip", "losses.hip", "perceptual.hip", "edt.hip", "atlas.hip", "regs.hip", "eval.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
          "-munsafe-fp-atomics",   # native global_atomic_add_f32 instead of CAS loops

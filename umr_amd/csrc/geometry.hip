@@ -156,6 +156,30 @@ __global__ void k_rotate_cam_y(const float *__restrict__ cam, const float *__res
     o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = nw; o[4] = nx; o[5] = ny; o[6] = nz;
 }
 
+// The general form (any axis; the reference's rotate_by = cv2.Rodrigues(rad_angle * axis): rotation by |rad_angle * axis| about
+// axis / |axis|): new_q = q_axis (x) q, same normalisation and sign convention.
+__global__ void k_rotate_cam_axis(const float *__restrict__ cam, const float *__restrict__ angle_deg, float ax, float ay, float az,
+                                  float *__restrict__ out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const float *c = cam + (size_t)i * 7;
+    const float len = sqrtf(ax * ax + ay * ay + az * az);
+    const float half = angle_deg[i] * 0.008726646259971648f * len;   // pi / 360 * |axis|
+    const float inv = len > 0.f ? 1.f / len : 0.f;
+    const float rw = cosf(half), s = sinf(half), rx = s * ax * inv, ry = s * ay * inv, rz = s * az * inv;
+    const float qw = c[3], qx = c[4], qy = c[5], qz = c[6];
+    // Hamilton product r (x) q
+    float nw = rw * qw - rx * qx - ry * qy - rz * qz;
+    float nx = rw * qx + rx * qw + ry * qz - rz * qy;
+    float ny = rw * qy - rx * qz + ry * qw + rz * qx;
+    float nz = rw * qz + rx * qy - ry * qx + rz * qw;
+    const float nrm = fmaxf(sqrtf(nw * nw + nx * nx + ny * ny + nz * nz), 1e-12f);
+    nw /= nrm; nx /= nrm; ny /= nrm; nz /= nrm;
+    if (nw < 0.f) { nw = -nw; nx = -nx; ny = -ny; nz = -nz; }
+    float *o = out + (size_t)i * 7;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = nw; o[4] = nx; o[5] = ny; o[6] = nz;
+}
+
 // One block per mesh.  With M(q) = (w^2-|u|^2) I + 2 u u^T + 2 w [u]x  and  P = s M X + t:
 //   dL/dX = s M^T g,  dL/ds = sum g.(M X),  dL/dt = sum g_xy,
 //   dL/dw = 2 s sum [ w (g.X) + g.(u x X) ],
@@ -305,6 +329,12 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
         k_project_backward<2><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V, 1);
     else
         return UMR_ERR_ARG;
+    return umr_launch_status();
+}
+
+int umr_rotate_cam_axis(const float *cam, const float *angle_deg, const float *axis3, float *out, int B, void *stream) {
+    if (!cam || !angle_deg || !axis3 || !out || B <= 0) return UMR_ERR_ARG;
+    k_rotate_cam_axis<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(cam, angle_deg, axis3[0], axis3[1], axis3[2], out, B);
     return umr_launch_status();
 }
 

@@ -1,11 +1,11 @@
 """Evaluation metrics of BASELINE config 5 on the GPU path: mask IoU (experiments/test_iou.py:101-110) and
 keypoint transfer / PCK (experiments/test_kp.py:125-193, 253-324).  Rendering, texture-flow sampling, camera
-projection and nearest-neighbour search are the HIP kernels of the training path; the per-keypoint python/numpy
-loops of the reference (heat-map drawing, CPU round trips) are vectorised on the device."""
+projection and nearest-neighbour search are the HIP kernels of the training path; the per-keypoint python/numpy loops of the
+reference (heat-map drawing, host round trips, numpy PCK accumulation) are the kernels of csrc/eval.hip: a batch of pairs
+is two (flow mode) or four (cam mode) launches, PCK counters stay on the device."""
 import torch
 
 from . import functional as UF
-from .chamfer_python import distChamfer
 
 
 def mask_iou(mask_gt, mask_pred):
@@ -21,58 +21,98 @@ def create_grid(image_size, device):
     return UF.standard_grid(image_size, torch.device(device))
 
 
-def draw_labelmaps(kp_xy_pix, image_size, sigma):
-    """utils/kp_utils.py:42-69 (draw_labelmap) for K keypoints at once: an un-normalised (6 sigma + 1)^2 Gaussian
-    patch whose upper-left corner is int(pt - 3 sigma) (truncation toward zero, as python's int()).
-    kp_xy_pix [K,2] (x, y) in pixels -> [K,H,W]."""
-    dev = kp_xy_pix.device
-    size = 6 * sigma + 1
-    c0 = size // 2
-    ul = torch.trunc(kp_xy_pix - 3 * sigma)                     # [K,2]
-    br = torch.trunc(kp_xy_pix + 3 * sigma + 1)
-    ys, xs = torch.meshgrid(torch.arange(image_size, device=dev, dtype=torch.float32),
-                            torch.arange(image_size, device=dev, dtype=torch.float32), indexing="ij")
-    gx = xs[None] - ul[:, 0, None, None]
-    gy = ys[None] - ul[:, 1, None, None]
-    inside = (gx >= 0) & (gx < size) & (gy >= 0) & (gy < size) & (xs[None] < br[:, 0, None, None]) & (ys[None] < br[:, 1, None, None])
-    g = torch.exp(-((gx - c0) ** 2 + (gy - c0) ** 2) / (2.0 * sigma ** 2))
-    return torch.where(inside, g, torch.zeros_like(g))
+_PATCH_CACHE = {}
+
+
+def gaussian_patch(sigma, device):
+    """The (6 sigma + 1)^2 un-normalised Gaussian of utils/kp_utils.py:53-59, computed in float64 with numpy exactly as
+    draw_labelmap does and rounded to float32 as its assignment into the float heat-map tensor does."""
+    key = (int(sigma), str(device))
+    if key not in _PATCH_CACHE:
+        import numpy as np
+        size = 6 * int(sigma) + 1
+        x = np.arange(0, size, 1, float)
+        y = x[:, np.newaxis]
+        x0 = y0 = size // 2
+        g = np.exp(- ((x - x0) ** 2 + (y - y0) ** 2) / (2 * int(sigma) ** 2))
+        _PATCH_CACHE[key] = torch.from_numpy(g.astype(np.float32)).to(device).contiguous()
+    return _PATCH_CACHE[key]
+
+
+class PCKCounters:
+    """Device-side accumulators of test_kp.py:253-258, 317-323: int32 [3,K] = (visible, err < 0.1, err < 0.15) per keypoint,
+    added into by every transfer call that is given a ground truth; .pck() -> (PCK.1, PCK.15)."""
+
+    def __init__(self, K, device, padding_frac=0.05, thresholds=(0.1, 0.15)):
+        self.counts = torch.zeros(3, K, dtype=torch.int32, device=device)
+        self.padding_frac, self.thresholds = float(padding_frac), thresholds
+
+    def pck(self):
+        c = self.counts.double()
+        return float((c[1] / c[0]).mean()), float((c[2] / c[0]).mean())
+
+
+def map_kp_flow_batch(kp_src, flow_src, flow_tgt, image_size=256, sigma=3, kp_gt=None, vis=None, counters=None):
+    """test_kp.py:125-158 for `pairs` (source, target) entries at once: kp_src [P,K,>=2] in [-1,1], flow_* [P,F,T,T,2] ->
+    (k2k [P,K,2], face index [P,K] int32).  Two launches (umr_kp_flow_transfer): per-face scores of every keypoint heat map
+    and the face's image point, then arg-max + gather (+ the PCK counters when kp_gt [P,K,>=2], vis [P,K] and a PCKCounters
+    are given)."""
+    from . import _lib
+    L = _lib.lib()
+    dev = flow_src.device
+    kp = kp_src.to(dev, torch.float32).contiguous()
+    fs, ft = flow_src.to(torch.float32).contiguous(), flow_tgt.to(torch.float32).contiguous()
+    P, K = kp.shape[0], kp.shape[1]
+    F = fs.shape[1]
+    TT = fs[0, 0].numel() // 2
+    face_idx = torch.empty(P, K, dtype=torch.int32, device=dev)
+    k2k = torch.empty(P, K, 2, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.umr_kp_flow_workspace_bytes(P, K, F), dtype=torch.uint8, device=dev)
+    gt = kp_gt.to(dev, torch.float32).contiguous() if kp_gt is not None else None
+    v = vis.to(dev, torch.float32).contiguous() if vis is not None else None
+    pf, ta, tb = (counters.padding_frac, counters.thresholds[0], counters.thresholds[1]) if counters is not None else (0.05, 0.1, 0.15)
+    _lib.check(L.umr_kp_flow_transfer(_lib.ptr(kp), kp.shape[2], _lib.ptr(fs), _lib.ptr(ft), _lib.ptr(gaussian_patch(sigma, dev)),
+                                      _lib.ptr(face_idx), _lib.ptr(k2k), _lib.ptr(gt), gt.shape[2] if gt is not None else 0, _lib.ptr(v),
+                                      _lib.ptr(counters.counts) if counters is not None else None, P, K, F, TT, int(image_size),
+                                      int(sigma), pf, ta, tb, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "umr_kp_flow_transfer")
+    return k2k, face_idx
 
 
 def map_kp_flow(kp_src, flow_src, flow_tgt, image_size=256, sigma=3):
-    """test_kp.py:125-158 (flow mode).  kp_src [K,>=2] in [-1,1]; flow_* [F,T,T,2] -> transferred keypoints [K,2]:
+    """test_kp.py:125-158 (flow mode), one pair.  kp_src [K,>=2] in [-1,1]; flow_* [F,T,T,2] -> transferred keypoints [K,2]:
     keypoint -> face (arg-max of the keypoint heat map sampled at the source flow) -> target pixel (mean of the
     coordinate grid sampled at the target flow)."""
-    nf = flow_tgt.size(0)
-    dev = flow_tgt.device
-    sgrid = create_grid(image_size, dev).permute(2, 0, 1).unsqueeze(0).contiguous()          # [1,2,H,W]
-    p2face = UF.GridSampleCLFunction.apply(sgrid, flow_tgt.reshape(1, -1, 2))                   # [1, F*TT, 2]
-    p2face = p2face.view(nf, -1, 2).mean(dim=1)                                                # [F,2]
-    kp_pix = (kp_src[:, 0:2] + 1) / 2.0 * 256                                                  # :146 (hard-coded 256)
-    hp = draw_labelmaps(kp_pix.to(dev), image_size, sigma).unsqueeze(0).contiguous()           # [1,K,H,W]
-    k2face = UF.GridSampleCLFunction.apply(hp, flow_src.reshape(1, -1, 2))                      # [1, F*TT, K]
-    k2face = k2face.view(nf, -1, hp.size(1)).mean(dim=1)                                       # [F,K]
-    k2face_idx = torch.max(k2face, dim=0)[1]                                                   # [K]
-    return p2face[k2face_idx]
+    return map_kp_flow_batch(kp_src[None], flow_src[None], flow_tgt[None], image_size, sigma)[0][0]
+
+
+def map_kp_cam_batch(kp_src, cam_src, cam_tgt, mask_tgt, mean_shape, image_size=256, kp_gt=None, vis=None, counters=None):
+    """test_kp.py:160-193 for `pairs` entries at once: kp_src [P,K,>=2], cam_* [P,7], mask_tgt [P,S,S], mean_shape [V,3] ->
+    (k2k [P,K,2], nearest-vertex index [P,K] int32).  Four launches: two projections, nearest foreground pixel of every
+    projected vertex, keypoint -> vertex -> pixel."""
+    from . import _lib
+    L = _lib.lib()
+    dev = mean_shape.device
+    P, K = kp_src.shape[0], kp_src.shape[1]
+    ms = mean_shape.view(1, -1, 3).expand(P, -1, -1).contiguous()
+    V = ms.shape[1]
+    v_tgt = UF.ProjectPointsFunction.apply(ms, cam_tgt.view(P, 7).contiguous(), 2, 0.0).contiguous()
+    v_src = UF.ProjectPointsFunction.apply(ms, cam_src.view(P, 7).contiguous(), 2, 0.0).contiguous()
+    kp = kp_src.to(dev, torch.float32).contiguous()
+    mask = mask_tgt.to(dev, torch.float32).contiguous()
+    vert_idx = torch.empty(P, K, dtype=torch.int32, device=dev)
+    pix = torch.empty(P, V, dtype=torch.int32, device=dev)
+    k2k = torch.empty(P, K, 2, dtype=torch.float32, device=dev)
+    gt = kp_gt.to(dev, torch.float32).contiguous() if kp_gt is not None else None
+    v = vis.to(dev, torch.float32).contiguous() if vis is not None else None
+    pf, ta, tb = (counters.padding_frac, counters.thresholds[0], counters.thresholds[1]) if counters is not None else (0.05, 0.1, 0.15)
+    _lib.check(L.umr_kp_cam_transfer(_lib.ptr(kp), kp.shape[2], _lib.ptr(v_src), _lib.ptr(v_tgt), _lib.ptr(mask), _lib.ptr(vert_idx),
+                                     _lib.ptr(pix), _lib.ptr(k2k), _lib.ptr(gt), gt.shape[2] if gt is not None else 0, _lib.ptr(v),
+                                     _lib.ptr(counters.counts) if counters is not None else None, P, K, V, int(image_size), pf, ta, tb,
+                                     _lib.stream_ptr(dev)), "umr_kp_cam_transfer")
+    return k2k, vert_idx
 
 
 def map_kp_cam(kp_src, cam_src, cam_tgt, mask_tgt, mean_shape, image_size=256):
-    """test_kp.py:160-193 (cam mode): keypoint -> nearest projected template vertex under the source camera ->
+    """test_kp.py:160-193 (cam mode), one pair: keypoint -> nearest projected template vertex under the source camera ->
     that vertex under the target camera -> nearest foreground pixel of the target mask."""
-    dev = mean_shape.device
-    ms = mean_shape.view(1, -1, 3).contiguous()
-    v_tgt = UF.ProjectPointsFunction.apply(ms, cam_tgt.view(1, 7).contiguous(), 2, 0.0)
-    sgrid = create_grid(image_size, dev).reshape(-1, 2)
-    fg_coords = sgrid[torch.nonzero(mask_tgt.reshape(-1)).squeeze(1), :]
-    _, _, _, proj2fg_idx = distChamfer(fg_coords.unsqueeze(0).contiguous(), v_tgt)
-    v_src = UF.ProjectPointsFunction.apply(ms, cam_src.view(1, 7).contiguous(), 2, 0.0)
-    _, _, kp2proj_idx, _ = distChamfer(kp_src[:, 0:2].to(dev).unsqueeze(0).contiguous(), v_src)
-    return fg_coords[proj2fg_idx.squeeze(0).long()[kp2proj_idx.squeeze(0).long()], :]
-
-
-def pck(kps_pred, kps_gt, kps_vis, padding_frac=0.05, thresholds=(0.1, 0.15)):
-    """test_kp.py:253-258, 317-323.  kps_pred/kps_gt [P,K,2], kps_vis [P,K] -> tuple of PCK@t (mean over keypoints
-    of correct/visible)."""
-    err = torch.sqrt(((kps_pred - kps_gt) ** 2).sum(-1)) * ((1 + 2 * padding_frac) / 2.0)
-    n_vis = kps_vis.sum(0)
-    return tuple(float((((err < t).float() * kps_vis).sum(0) / n_vis).mean()) for t in thresholds)
+    return map_kp_cam_batch(kp_src[None], cam_src.view(1, 7), cam_tgt.view(1, 7), mask_tgt[None], mean_shape, image_size)[0][0]

@@ -528,3 +528,90 @@ class PartMatchFunction(Function):
         _lib.check(L.umr_part_match_backward(ptr(a), ptr(b), ptr(q), B, H, W, w, bg, eps, ptr(ge), ptr(gl), ptr(ga), ptr(gb),
                                              ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "umr_part_match_backward")
         return ga, gb, None, None, None, None
+
+
+class RowNormMeanFunction(Function):
+    """mean over rows of ||x_row||_2 (deform_l2reg, nnutils/loss_utils.py:118-123): x [..., W] -> scalar."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        x2 = _f32c(x).view(-1, x.shape[-1])
+        rows, width = x2.shape
+        out = torch.empty((), device=x2.device, dtype=torch.float32)
+        scratch = torch.empty(L.umr_reg_scratch_floats(rows, 1), device=x2.device, dtype=torch.float32)
+        _lib.check(L.umr_row_norm_mean_forward(ptr(x2), ptr(out), ptr(scratch), scratch.numel() * 4, rows, width,
+                                               _lib.stream_ptr(x2.device)), "umr_row_norm_mean_forward")
+        ctx.save_for_backward(x2)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x2, = ctx.saved_tensors
+        gx = torch.empty_like(x2)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(L.umr_row_norm_mean_backward(ptr(x2), ptr(g), ptr(gx), x2.shape[0], x2.shape[1], _lib.stream_ptr(x2.device)),
+                   "umr_row_norm_mean_backward")
+        return gx.view(ctx.shape)
+
+
+class AbsColumnMeanFunction(Function):
+    """mean |x[..., column]| (sym_reg, nnutils/loss_utils.py:125-126: column 1 of verts [B,V,3]) -> scalar."""
+
+    @staticmethod
+    def forward(ctx, x, column):
+        L = _lib.lib()
+        x2 = _f32c(x).view(-1, x.shape[-1])
+        rows, width = x2.shape
+        out = torch.empty((), device=x2.device, dtype=torch.float32)
+        scratch = torch.empty(L.umr_reg_scratch_floats(rows, 1), device=x2.device, dtype=torch.float32)
+        _lib.check(L.umr_abs_mean_forward(ptr(x2), ptr(out), ptr(scratch), scratch.numel() * 4, rows, width, int(column),
+                                          _lib.stream_ptr(x2.device)), "umr_abs_mean_forward")
+        ctx.save_for_backward(x2)
+        ctx.shape, ctx.column = x.shape, int(column)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x2, = ctx.saved_tensors
+        gx = torch.empty_like(x2)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(L.umr_abs_mean_backward(ptr(x2), ptr(g), ptr(gx), x2.shape[0], x2.shape[1], ctx.column,
+                                           _lib.stream_ptr(x2.device)), "umr_abs_mean_backward")
+        return gx.view(ctx.shape), None
+
+
+class MaskedL1Function(Function):
+    """per_sample[b] = mean_{c,p} |img_pred mask_pred - img_gt mask_gt| (texture_loss_masks, nnutils/loss_utils.py:103-116).
+    img_* [B,C,H,W], mask_* [B,H,W]; gradients to img_pred and mask_pred."""
+
+    @staticmethod
+    def forward(ctx, img_pred, img_gt, mask_gt, mask_pred):
+        L = _lib.lib()
+        ip, ig, mg, mp = _f32c(img_pred), _f32c(img_gt), _f32c(mask_gt), _f32c(mask_pred)
+        B, C, H, W = ip.shape
+        if ig.shape != ip.shape or mg.numel() != B * H * W or mp.numel() != B * H * W:
+            raise ValueError("masked L1: img %s / %s need masks [B,H,W], got %s / %s"
+                             % (tuple(ip.shape), tuple(ig.shape), tuple(mg.shape), tuple(mp.shape)))
+        per = torch.empty(B, device=ip.device, dtype=torch.float32)
+        scratch = torch.empty(L.umr_reg_scratch_floats(C * H * W, B), device=ip.device, dtype=torch.float32)
+        _lib.check(L.umr_masked_l1_forward(ptr(ip), ptr(ig), ptr(mg), ptr(mp), ptr(per), ptr(scratch), scratch.numel() * 4, B, C,
+                                           H * W, _lib.stream_ptr(ip.device)), "umr_masked_l1_forward")
+        ctx.save_for_backward(ip, ig, mg, mp)
+        ctx.mp_shape = mask_pred.shape
+        return per
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        ip, ig, mg, mp = ctx.saved_tensors
+        B, C, H, W = ip.shape
+        g = g.to(torch.float32).contiguous()
+        gip = torch.empty_like(ip) if ctx.needs_input_grad[0] else None
+        gmp = torch.empty_like(mp) if ctx.needs_input_grad[3] else None
+        _lib.check(L.umr_masked_l1_backward(ptr(ip), ptr(ig), ptr(mg), ptr(mp), ptr(g), ptr(gip), ptr(gmp), B, C, H * W,
+                                            _lib.stream_ptr(ip.device)), "umr_masked_l1_backward")
+        return gip, None, None, (gmp.view(ctx.mp_shape) if gmp is not None else None)

@@ -25,24 +25,19 @@ def texture_dt_loss(texture_flow, dist_transf, vis_rend=None, cams=None, verts=N
 
 
 def texture_loss_masks(img_pred, img_gt, mask_gt, mask_pred, avg=True):
-    """nnutils/loss_utils.py:103-116."""
-    mask_gt = mask_gt.unsqueeze(1)
-    mask_pred = mask_pred.unsqueeze(1)
-    if avg:
-        return torch.nn.L1Loss()(img_pred * mask_pred, img_gt * mask_gt)
-    loss = torch.nn.L1Loss(reduction='none')(img_pred * mask_pred, img_gt * mask_gt)
-    return torch.sum(loss, dim=(1, 2, 3)) / (loss.size(1) * loss.size(2) * loss.size(3))
+    """nnutils/loss_utils.py:103-116: L1(img_pred * mask_pred, img_gt * mask_gt); one kernel pair (umr_masked_l1_*)."""
+    per = UF.MaskedL1Function.apply(img_pred, img_gt, mask_gt, mask_pred)     # [B]: mean over (C, H, W) per sample
+    return per.mean() if avg else per
 
 
 def deform_l2reg(V):
-    """nnutils/loss_utils.py:118-123."""
-    V = V.view(-1, V.size(2))
-    return torch.mean(torch.norm(V, p=2, dim=1))
+    """nnutils/loss_utils.py:118-123: mean row norm of V [B,N,3] (umr_row_norm_mean_*)."""
+    return UF.RowNormMeanFunction.apply(V)
 
 
 def sym_reg(verts):
-    """nnutils/loss_utils.py:125-126."""
-    return torch.mean(torch.abs(verts[:, :, 1]))
+    """nnutils/loss_utils.py:125-126: mean |y| of verts [B,V,3] (umr_abs_mean_*)."""
+    return UF.AbsColumnMeanFunction.apply(verts, 1)
 
 
 class TexCycle(nn.Module):
