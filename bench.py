@@ -51,7 +51,7 @@ def parse():
                     help="s1 = BASELINE configs[1] (headline); s2 = train_s2 sequence of configs[2]/[3] (8 camera hypotheses)")
     ap.add_argument("--epoch", type=int, default=0, help="train_s1 epoch (gates the symmetry / deformation terms)")
     ap.add_argument("--profile-steps", type=int, default=5, help="untimed steps with kernel events for `roofline`")
-    ap.add_argument("--master-port", type=int, default=29511)
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
     ap.add_argument("--graph", type=int, default=0,
                     help="--model 0 only: capture the hot-path step (every raster / loss kernel, forward and backward) in ONE HIP "
                          "graph and time graph replays instead of eager launches")
@@ -61,9 +61,15 @@ def parse():
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 outside torchrun: start one rank per GPU of this node under
     torch.distributed.run (RCCL rendezvous on 127.0.0.1) and pass its exit status on.  Rank 0 prints the JSON line."""
+    import socket
     import subprocess
+    port = args.master_port
+    if port <= 0:                       # default: a port that is free right now (two benches on one node must not collide)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -102,12 +108,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    if world > 1:
+        # N ranks start at once on a fresh node: each gets its own MIOpen user database / kernel cache, so the first-use solver
+        # searches of the ranks do not write the same sqlite files concurrently (set before MIOpen creates its first handle)
+        for var, sub_ in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+            d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "umr_miopen_%s_rank%d" % (sub_, local))
+            os.makedirs(d, exist_ok=True)
+            os.environ.setdefault(var, d)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        os.environ.setdefault("MASTER_PORT", str(args.master_port or 29511))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" = RCCL on ROCm
 
     from umr_amd import _lib
@@ -284,6 +297,30 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         grad_info = {"grad_abs_sum": float(cs.item()), "grad_abs_sum_spread_over_ranks": float((hi - lo).item())}
+    # the gradient exchange on its own: the model's gradient bytes all-reduced in DDP's bucket size, timed with HIP events
+    # on every rank (max over ranks).  With one rank (--force-ddp) this is RCCL's launch + local-copy floor of the path.
+    ar_info = {}
+    if world > 1 or args.force_ddp:
+        import torch.distributed as dist
+        from umr_amd.parallel import BUCKET_MB
+        nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad) if model is not None else 337 * 1024 * 1024
+        flat = torch.zeros(nbytes // 4, device=dev)
+        per = BUCKET_MB * 1024 * 1024 // 4
+        buckets = [flat[i:i + per] for i in range(0, flat.numel(), per)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(7):
+            if it == 2:
+                barrier(); e0.record()
+            for bk in buckets:
+                dist.all_reduce(bk)
+        e1.record(); torch.cuda.synchronize()
+        ar = torch.tensor([e0.elapsed_time(e1) / 5.0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        ar_info = {"allreduce_bytes": int(nbytes), "ddp_bucket_mb": BUCKET_MB, "ddp_buckets": len(buckets),
+                   "allreduce_ms_standalone": float(ar.item()),
+                   "allreduce_bus_GBs_per_rank": (2.0 * (world - 1) / max(world, 1)) * nbytes / 1e9 / (float(ar.item()) / 1e3) if world > 1 else 0.0}
+        del flat, buckets
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
@@ -294,17 +331,33 @@ def main():
     # HBM traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
     # this very command, tools/collect_traffic.sh); bench.py cannot run the profiler on itself, so the committed
     # per-launch figure is attached when it was measured for the same workload, else null.
-    traffic = None
+    traffic, valu, traffic_note = None, {}, "no profiles/traffic.json"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if args.workload == "s1" and tj.get("workload") == [args.batch, args.image_size, args.subdivide, bool(use_model)]:
+        same_wl = args.workload == "s1" and tj.get("workload") == [args.batch, args.image_size, args.subdivide, bool(use_model)]
+        if tj.get("build_id") != _lib.build_id():
+            traffic_note = "profiles/traffic.json was measured on another build of libumr_hip.so (%s): not attached" % tj.get("build_id")
+        elif not same_wl:
+            traffic_note = "profiles/traffic.json was measured for another workload: not attached"
+        else:
             traffic = tj.get("raster_backward_bytes_per_launch")
+            traffic_note = "PMC FETCH_SIZE (x%.2f calibrated) + WRITE_SIZE per launch, tools/collect_traffic.sh on build %s" % (
+                tj.get("calibration", {}).get("fetch_correction_factor", 2.0), tj.get("build_id"))
+            for kname, key in (("k_raster_backward_fm<1", "backward"), ("k_raster_forward<1", "forward_kernel"),
+                               ("k_raster_forward<2", "silhouette_forward"), ("k_raster_backward_fm<2", "silhouette_backward")):
+                for kn, e in tj.get("kernels", {}).items():
+                    if kname in kn and e.get("valu"):
+                        v = e["valu"]
+                        valu[key] = {"issued_wave_instr": v.get("issued_wave_instr"), "useful_lane_instr": v.get("useful_lane_instr"),
+                                     "lane_use": v.get("lane_use"), "frac_of_peak": v.get("frac_of_peak"),
+                                     "peak_wave_instr_per_s": v.get("peak_wave_instr_per_s"), "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch")}
     rccl = {}
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
         rccl = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
     rccl.update(grad_info)
+    rccl.update(ar_info)
     net_note = ("; MeshNet fwd/bwd + %sAdam" % ("RCCL gradient all-reduce over %d ranks + " % world if world > 1 else "")
                 if use_model else "; network excluded")
     if args.workload == "s1":
@@ -336,10 +389,15 @@ def main():
         # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
         # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the
         # variant touches, once) / its mean HIP-event duration over the profile pass.
+        # `valu`: the resource that actually binds these kernels -- issued wave64 VALU instructions per launch,
+        # the share of their lanes that was active, and the issue rate against the fp32 vector peak (1228.9 G wave-instr/s),
+        # from SQ PMC passes of this command on this build (profiles/traffic.json; absent when that file is stale).
         "roofline": dict({"bound": "hbm", "kernel": "k_raster_backward_fm (textured render)", "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "traffic": traffic}, **kernel_line(1),
-                         forward_kernel=kernel_line(0), silhouette_forward=kernel_line(2),
-                         silhouette_backward=kernel_line(3)),
+                          "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_note, "valu": valu.get("backward")},
+                         **kernel_line(1),
+                         forward_kernel=dict(kernel_line(0), valu=valu.get("forward_kernel")),
+                         silhouette_forward=dict(kernel_line(2), valu=valu.get("silhouette_forward")),
+                         silhouette_backward=dict(kernel_line(3), valu=valu.get("silhouette_backward"))),
     }
     want_cpu = (world == 1 and args.workload == "s1") if args.cpu_baseline < 0 else bool(args.cpu_baseline)
     if want_cpu:

@@ -173,7 +173,7 @@ def test_keypoint_transfer_vs_reference_golden():
     np.testing.assert_allclose(t2n(k2k[:P]), g["flow_k1_to_k2"], atol=1e-6)
     np.testing.assert_allclose(t2n(k2k[P:]), g["flow_k2_to_k1"], atol=1e-6)
     p1, p15 = cnt.pck()
-    assert abs(p1 - float(g["pck1"])) < 1e-9 and abs(p15 - float(g["pck15"])) < 1e-9, (p1, p15, float(g["pck1"]), float(g["pck15"]))
+    assert abs(p1 - float(g["pck1"])) < 1e-7 and abs(p15 - float(g["pck15"])) < 1e-7,     # (the fixture stores float32) (p1, p15, float(g["pck1"]), float(g["pck15"]))
     # cam mode
     k2c, vert = EU.map_kp_cam_batch(src, torch.cat([cams[:, 0], cams[:, 1]]), torch.cat([cams[:, 1], cams[:, 0]]),
                                     torch.cat([masks[:, 1], masks[:, 0]]), mean_shape, S)

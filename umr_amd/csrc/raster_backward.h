@@ -241,8 +241,11 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
 #define FM_ACC(acc, a, b) acc += (a) * (b)
 #endif
 #ifndef FM_SLOTS
-#define FM_SLOTS 1        // 1: sub-tile hand-out through LDS slots (A/B: -DFM_SLOTS=0 = v_readlane rounds, round 2's form)
-#endif
+#define FM_SLOTS 1        // 1: sub-tile hand-out through LDS slots for the silhouette variant (A/B: -DFM_SLOTS=0 = v_readlane
+#endif                    // rounds everywhere, round 2's form; 2 = slots for every variant).  Measured on MI355X, us per launch
+                          // N = 16 / 128, readlane -> slots: silhouette 82.6 -> 73.7 / 490 -> 451 (-8..11 %; -14 % at F = 5120,
+                          // IS = 1024); colour variants the other way -- texel-only 121 -> 125 / 812 -> 826, vertex + texel
+                          // 206 -> 241 / 1321 -> 1571: they sit at the 72-VGPR budget of 7 waves, the slot's 4 values spill
 #ifndef FM_STATE_CULL
 #define FM_STATE_CULL 1   // sub-tile skips from the saved forward state inside the culling pass (A/B: -DFM_STATE_CULL=0)
 #endif
@@ -306,13 +309,12 @@ template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>  // RGB 2 = silhouet
 #define BWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BWD_WPE, BWD_WPE)))
 __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_fm(const RasterArgs A) {
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
-#if FM_SLOTS
+    constexpr bool SLOTS = FM_SLOTS == 2 || (FM_SLOTS == 1 && RGB == 2);
     // sub-tile hand-out: the lane that owns a wanted candidate of the culling pass writes the sub-tile's origin (pixel-centre
     // coordinates and byte offsets into the full / pooled planes) into slot [its rank among the wanted]; visit v hands slot
     // 4 v + g to lane group g with one 16-byte LDS read (a broadcast within the group) -- it replaced four rounds of
     // s_ff1 / v_readlane / v_cndmask and ~20 half-rate instructions of per-lane coordinate arithmetic per visit
-    __shared__ float4 s_slot[FM_WAVES][64];
-#endif
+    __shared__ float4 s_slot[SLOTS ? FM_WAVES : 1][SLOTS ? 64 : 1];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
     const int F = A.F, IS = A.IS, TS = A.TS;
     const bool pooled = COMMON ? true : (A.grad_pooled != 0);
@@ -396,13 +398,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
             const float4 i1 = make_float4(fc.template g<R_INV + 4>(), fc.template g<R_INV + 5>(), fc.template g<R_INV + 6>(), fc.template g<R_INV + 7>());
             const float4 i2 = make_float4(fc.template g<R_INV + 8>(), fc.template g<R_K0>(), fc.template g<R_K1>(), fc.template g<R_K2>());
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
-#if FM_SLOTS
-            // this lane's place inside a sub-tile, as the increments the slot's origin takes (exact: see the visit)
+            // (slots) this lane's place inside a sub-tile, as the increments the slot's origin takes (exact: see the visit)
             const bool fastxy = pow2 && IS % FM_TW == 0 && IS % FM_TH == 0;   // exact incremental pixel centres, no ragged sub-tile
             const int lx = sl % FM_TW, ly = sl / FM_TW;
             const float lxf = (float)(2 * lx) * inv_is, lyf = (float)(2 * ly) * inv_is;
             const unsigned lo_pn = (unsigned)(ly * IS + lx) * 4u, lo_gp = pooled ? (unsigned)((ly >> 1) * H2 + (lx >> 1)) * 4u : lo_pn;
-#endif
 #ifdef FM_NO_CULL            // time-split experiment (tools/r3/split.sh): per-face set-up and reductions only
             for (int tb = ntiles; tb < ntiles; tb += 64) {
 #else
@@ -461,9 +461,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
 #ifdef FM_NO_VISIT          // time-split experiment (tools/r3/split.sh): per-face set-up + culling pass only
                 tm = 0;
 #endif
-#if FM_SLOTS
                 const int nv = __popcll(tm);
-                if (want) {
+                float4 sd_next = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (SLOTS) {
+                  if (want) {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tm, 0u));
                     const int px0 = (tpk & 0xffff) * FM_TW, pr0 = (tpk >> 16) * FM_TH;
                     const unsigned o_pn = (unsigned)(pr0 * IS + px0) * 4u;
@@ -473,29 +474,29 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                     s_slot[wave][rank] = make_float4(fastxy ? ndc_coord_fast(px0, IS, inv_is, true) : __int_as_float(tpk),
                                                      fastxy ? ndc_coord_fast(IS - 1 - pr0, IS, inv_is, true) : 0.f,
                                                      __int_as_float((int)o_pn), __int_as_float((int)o_gp));
+                  }
+                  // the slot of visit v + 1 is read at the top of visit v: LDS operations of a wave complete in order, so a read
+                  // issued behind a visit's texel atomics (ds_add_f32, ~12 cycles a lane) would stall the next visit on them
+                  sd_next = s_slot[wave][sub < nv ? sub : 0];
                 }
-                // the slot of visit v + 1 is read at the top of visit v: LDS operations of a wave complete in order, so a read
-                // issued behind this visit's texel atomics (ds_add_f32, ~12 cycles a lane) would stall the next visit on them
-                float4 sd_next = s_slot[wave][sub < nv ? sub : 0];
                 for (int v0 = 0; v0 < nv; v0 += FM_NQ) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
-                    const int mine = v0 + sub < nv ? v0 + sub : -1;
-                    const float4 sd = sd_next;
-                    sd_next = s_slot[wave][v0 + FM_NQ + sub < nv ? v0 + FM_NQ + sub : 0];
-#else
-                while (tm) {
-                    // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
                     int mine = -1;
+                    float4 sd = sd_next;
+                    if constexpr (SLOTS) {
+                        mine = v0 + sub < nv ? v0 + sub : -1;
+                        sd_next = s_slot[wave][v0 + FM_NQ + sub < nv ? v0 + FM_NQ + sub : 0];
+                    } else {
 #pragma unroll
-                    for (int qq = 0; qq < FM_NQ; ++qq) {
-                        if (tm) {
-                            const int tbit = __builtin_ctzll(tm);
-                            tm &= tm - 1;
-                            const int e = __builtin_amdgcn_readlane(tpk, tbit);
-                            if (sub == qq) mine = e;
+                        for (int qq = 0; qq < FM_NQ; ++qq) {
+                            if (tm) {
+                                const int tbit = __builtin_ctzll(tm);
+                                tm &= tm - 1;
+                                const int e = __builtin_amdgcn_readlane(tpk, tbit);
+                                if (sub == qq) mine = e;
+                            }
                         }
                     }
-#endif
                     if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2) {
                         // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
                         // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop.  Only for the variants that
@@ -506,29 +507,30 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void k_raster_backward_
                         load_face(fc, rp);
                     }
                     if (mine < 0) continue;
-#if FM_SLOTS
                     float xp, yp;
-                    if (fastxy) {
+                    unsigned pn4, gp4;                                                          // byte offsets in a full / pooled plane
+                    if constexpr (SLOTS) {
+                      if (fastxy) {
                         // (2 (x0 + lx) + 1 - IS) / IS = origin + 2 lx / IS: every term and the sum are small integers over a power
                         // of two -- exact in fp32, the same bits as ndc_coord_fast per pixel (IS % 4 == 0: no ragged sub-tile)
                         xp = sd.x + lxf; yp = sd.y - lyf;
-                    } else {
+                      } else {
                         const int tp = __float_as_int(sd.x);
                         const int row = (tp >> 16) * FM_TH + ly, xi = (tp & 0xffff) * FM_TW + lx;
                         if (xi >= IS || row >= IS) continue;
                         yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2); xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                      }
+                      pn4 = (unsigned)__float_as_int(sd.z) + lo_pn;
+                      gp4 = (unsigned)__float_as_int(sd.w) + lo_gp;
+                    } else {
+                        const int row = (mine >> 16) * FM_TH + sl / FM_TW;
+                        const int xi = (mine & 0xffff) * FM_TW + sl % FM_TW;
+                        if (xi >= IS || row >= IS) continue;
+                        yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
+                        xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                        pn4 = (unsigned)(row * IS + xi) * 4u;
+                        gp4 = pooled ? (unsigned)((row >> 1) * H2 + (xi >> 1)) * 4u : pn4;
                     }
-                    const unsigned pn4 = (unsigned)__float_as_int(sd.z) + lo_pn;               // byte offset in a full plane
-                    const unsigned gp4 = (unsigned)__float_as_int(sd.w) + lo_gp;
-#else
-                    const int row = (mine >> 16) * FM_TH + sl / FM_TW;
-                    const int xi = (mine & 0xffff) * FM_TW + sl % FM_TW;
-                    if (xi >= IS || row >= IS) continue;
-                    const float yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
-                    const float xp = ndc_coord_fast(xi, IS, inv_is, pow2);
-                    const unsigned pn4 = (unsigned)(row * IS + xi) * 4u;                       // byte offset in a full plane
-                    const unsigned gp4 = pooled ? (unsigned)((row >> 1) * H2 + (xi >> 1)) * 4u : pn4;
-#endif
                     // Exact tile skips from the saved forward state, before any geometry:
                     //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
                     //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
