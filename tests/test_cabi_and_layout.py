@@ -264,3 +264,31 @@ def test_ctypes_signatures_match_the_header_prototypes():
                 assert a in (ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_uint), (name, p, a)
         checked += 1
     assert checked >= 40
+
+
+def test_every_kernel_of_the_path_is_a_registered_operator_with_a_fake_kernel():
+    """north_star: "all exposed to PyTorch-ROCm as custom ops".  umr_amd/ops.py (rasterizer) and umr_amd/ops_losses.py (geometry
+    and losses) register torch.ops.umr.*; here, without a GPU: every operator and its backward exist with a schema, and the
+    fake (meta) kernels propagate shapes and dtypes under FakeTensorMode -- what torch.compile / export trace through."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from umr_amd import ops, ops_losses  # noqa: F401
+    names = ["soft_rasterize", "soft_rasterize_backward", "silhouette", "silhouette_backward"] + list(ops_losses.ALL_OPS) + \
+        [n + "_backward" for n in ops_losses.ALL_OPS if n != "dt_barrier"]
+    for n in names:
+        assert hasattr(torch.ops.umr, n), n
+        assert str(getattr(torch.ops.umr, n).default._schema).startswith("umr::" + n + "("), n
+    with FakeTensorMode():
+        f = lambda *s, dt=torch.float32: torch.empty(*s, device="cuda", dtype=dt)
+        v, c, fi = f(4, 10, 3), f(4, 7), f(4, 6, 3, dt=torch.int32)
+        assert torch.ops.umr.project_faces(v, c, fi, 5.0, -2.7).shape == (4, 6, 3, 3)
+        assert torch.ops.umr.project_points(v, c, 3, 0.0).shape == (4, 10, 3)
+        assert torch.ops.umr.grid_sample_cl(f(2, 3, 8, 8), f(2, 5, 2)).shape == (2, 5, 3)
+        assert torch.ops.umr.laplacian(v, f(11, dt=torch.int32), f(40, dt=torch.int32))[0].shape == (4,)
+        assert torch.ops.umr.flatten(v, f(9, 4, dt=torch.int32)).shape == (4,)
+        assert torch.ops.umr.dt_barrier(f(2, 16, 16), 50.0).shape == (2, 16, 16)
+        assert torch.ops.umr.row_norm_mean(v).shape == () and torch.ops.umr.abs_column_mean(v, 1).shape == ()
+        d1, d2, i1, i2 = torch.ops.umr.chamfer(f(2, 5, 2), f(2, 7, 2))
+        assert d1.shape == (2, 5) and i2.shape == (2, 7) and i1.dtype == torch.int32
+        gv, gc = torch.ops.umr.project_points_backward(f(4, 10, 3), v, c, 3, True)
+        assert gv.shape == v.shape and gc.shape == c.shape

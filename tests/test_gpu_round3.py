@@ -173,7 +173,8 @@ def test_keypoint_transfer_vs_reference_golden():
     np.testing.assert_allclose(t2n(k2k[:P]), g["flow_k1_to_k2"], atol=1e-6)
     np.testing.assert_allclose(t2n(k2k[P:]), g["flow_k2_to_k1"], atol=1e-6)
     p1, p15 = cnt.pck()
-    assert abs(p1 - float(g["pck1"])) < 1e-7 and abs(p15 - float(g["pck15"])) < 1e-7,     # (the fixture stores float32) (p1, p15, float(g["pck1"]), float(g["pck15"]))
+    # (the fixture stores float32)
+    assert abs(p1 - float(g["pck1"])) < 1e-7 and abs(p15 - float(g["pck15"])) < 1e-7, (p1, p15, float(g["pck1"]), float(g["pck15"]))
     # cam mode
     k2c, vert = EU.map_kp_cam_batch(src, torch.cat([cams[:, 0], cams[:, 1]]), torch.cat([cams[:, 1], cams[:, 0]]),
                                     torch.cat([masks[:, 1], masks[:, 0]]), mean_shape, S)
@@ -181,3 +182,66 @@ def test_keypoint_transfer_vs_reference_golden():
     np.testing.assert_array_equal(t2n(vert[P:]), g["cam_vert_21"])
     np.testing.assert_allclose(t2n(k2c[:P]), g["cam_k1_to_k2"], atol=1e-6)
     np.testing.assert_allclose(t2n(k2c[P:]), g["cam_k2_to_k1"], atol=1e-6)
+
+
+def test_loss_and_geometry_operators_opcheck_and_match_the_function_path():
+    """torch.ops.umr.* of umr_amd/ops_losses.py on the device: torch.library.opcheck (schema, fake kernel against the real one,
+    autograd registration) on real inputs, and values / gradients identical to the autograd.Function route the loss modules
+    use (same kernels, same stream: bit-equal)."""
+    from torch.library import opcheck
+    from umr_amd import functional as UF, ops_losses  # noqa: F401
+    from umr_amd.loss_utils import LaplacianLoss, FlattenLoss
+    g = torch.Generator().manual_seed(9)
+    utils = ("test_schema", "test_faketensor", "test_autograd_registration")
+    verts, faces, cams, _ = scene(2, 1, seed=6)
+    v = verts.to(DEV).requires_grad_(True); c = cams.to(DEV).requires_grad_(True); fi = faces.int().to(DEV)
+    opcheck(torch.ops.umr.project_faces.default, (v, c, fi, 5.0, -2.732), test_utils=utils)
+    opcheck(torch.ops.umr.project_points.default, (v, c, 2, 0.0), test_utils=utils)
+    fo = torch.ops.umr.project_faces(v, c, fi, 5.0, -2.732)
+    w = torch.rand(fo.shape, generator=g).to(DEV)
+    (fo * w).sum().backward()
+    gv, gc = v.grad.clone(), c.grad.clone(); v.grad = None; c.grad = None
+    _, fo2, _ = UF.ProjectFacesFunction.apply(v, c, fi, 5.0, -2.732, False)
+    (fo2 * w).sum().backward()
+    assert torch.equal(fo, fo2) and torch.equal(gc, c.grad)
+    assert float((gv - v.grad).abs().max()) <= 1e-5 * float(gv.abs().max())       # vertex scatter: float atomics
+    p, t = torch.rand(3, 32, 32, generator=g).to(DEV).requires_grad_(True), (torch.rand(3, 32, 32, generator=g) > 0.5).float().to(DEV)
+    opcheck(torch.ops.umr.neg_iou.default, (p, t), test_utils=utils)
+    l1 = torch.ops.umr.neg_iou(p, t)[0]; l1.sum().backward(); g1 = p.grad.clone(); p.grad = None
+    l2 = UF.NegIoUFunction.apply(p, t); l2.sum().backward()
+    assert torch.equal(l1, l2) and torch.equal(g1, p.grad)
+    a, b = torch.rand(2, 9, 2, generator=g).to(DEV).requires_grad_(True), torch.rand(2, 13, 2, generator=g).to(DEV).requires_grad_(True)
+    opcheck(torch.ops.umr.chamfer.default, (a, b), test_utils=utils)
+    d1, d2, i1, i2 = torch.ops.umr.chamfer(a, b); (d1.sum() + 2 * d2.sum()).backward(); ga = a.grad.clone(); a.grad = None; b.grad = None
+    e1, e2, j1, j2 = UF.ChamferFunction.apply(a, b); (e1.sum() + 2 * e2.sum()).backward()
+    assert torch.equal(d1, e1) and torch.equal(i2, j2) and float((ga - a.grad).abs().max()) <= 1e-6
+    img, grid = torch.rand(2, 3, 16, 16, generator=g).to(DEV).requires_grad_(True), (torch.rand(2, 20, 2, generator=g) * 2 - 1).to(DEV).requires_grad_(True)
+    opcheck(torch.ops.umr.grid_sample_cl.default, (img, grid), test_utils=utils)
+    assert torch.equal(torch.ops.umr.grid_sample_cl(img, grid), UF.GridSampleCLFunction.apply(img, grid))
+    lap, fl = LaplacianLoss(verts[0], faces[0].int()).to(DEV), FlattenLoss(faces[0].int()).to(DEV)
+    x = verts.to(DEV).requires_grad_(True)
+    opcheck(torch.ops.umr.flatten.default, (x, fl.quads), test_utils=utils)
+    assert torch.equal(torch.ops.umr.flatten(x, fl.quads), fl(x))
+    opcheck(torch.ops.umr.laplacian.default, (x, lap.nbr_off, lap.nbr_idx), test_utils=utils)
+    assert torch.equal(torch.ops.umr.laplacian(x, lap.nbr_off, lap.nbr_idx)[0], lap(x))
+    f0 = [torch.rand(2, 8, 6, 6, generator=g).to(DEV).requires_grad_(True), torch.rand(2, 4, 3, 3, generator=g).to(DEV).requires_grad_(True)]
+    f1 = [torch.rand(2, 8, 6, 6, generator=g).to(DEV), torch.rand(2, 4, 3, 3, generator=g).to(DEV)]
+    opcheck(torch.ops.umr.cos_sim.default, (f0, f1, 1e-10), test_utils=utils)
+    val = torch.ops.umr.cos_sim(f0, f1, 1e-10)[0]; val.sum().backward(); gc0 = f0[0].grad.clone(); f0[0].grad = None; f0[1].grad = None
+    val2 = UF.CosSimDistanceFunction.apply(1e-10, *f0, *f1); val2.sum().backward()
+    assert torch.equal(val, val2) and torch.equal(gc0, f0[0].grad)
+    ra, rb = torch.rand(2, 4, 16, 16, generator=g).to(DEV).requires_grad_(True), torch.rand(2, 4, 16, 16, generator=g).to(DEV).requires_grad_(True)
+    q = torch.randn(2, 5, 16, 16, generator=g).to(DEV)
+    opcheck(torch.ops.umr.part_match.default, (ra, rb, q, [0., 5., 0., 0., 5.], 0.1, 1e-3), test_utils=utils)
+    e, l, _ = torch.ops.umr.part_match(ra, rb, q, [0., 5., 0., 0., 5.], 0.1, 1e-3)
+    e2, l2 = UF.PartMatchFunction.apply(ra, rb, q, [0., 5., 0., 0., 5.], 0.1, 1e-3)
+    assert torch.equal(e, e2) and torch.equal(l, l2)
+    m = (torch.rand(2, 32, 32, generator=g) > 0.6).float().to(DEV)
+    opcheck(torch.ops.umr.dt_barrier.default, (m, 50.0), test_utils=("test_schema", "test_faketensor"))
+    xr = torch.randn(3, 7, 3, generator=g).to(DEV).requires_grad_(True)
+    opcheck(torch.ops.umr.row_norm_mean.default, (xr,), test_utils=utils)
+    opcheck(torch.ops.umr.abs_column_mean.default, (xr, 1), test_utils=utils)
+    ip, ig = torch.rand(2, 3, 8, 8, generator=g).to(DEV).requires_grad_(True), torch.rand(2, 3, 8, 8, generator=g).to(DEV)
+    mg, mp = (torch.rand(2, 8, 8, generator=g) > 0.5).float().to(DEV), torch.rand(2, 8, 8, generator=g).to(DEV).requires_grad_(True)
+    opcheck(torch.ops.umr.masked_l1.default, (ip, ig, mg, mp), test_utils=utils)
+    assert torch.equal(torch.ops.umr.masked_l1(ip, ig, mg, mp), UF.MaskedL1Function.apply(ip, ig, mg, mp))

@@ -5,7 +5,7 @@
 set -euo pipefail
 export TMPDIR=/tmp
 R="$(cd "$(dirname "$0")/.." && pwd)"
-OUT="$1"; shift
+OUT="$(realpath -m "$1")"; shift
 mkdir -p "$OUT"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -4,7 +4,7 @@
 set -euo pipefail
 export TMPDIR=/tmp
 R="$(cd "$(dirname "$0")/.." && pwd)"
-OUT="$1"; shift
+OUT="$(realpath -m "$1")"; shift
 mkdir -p "$OUT"
 cd /tmp
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS \

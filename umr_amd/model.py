@@ -274,7 +274,10 @@ class MultiCamPredictor(nn.Module):
         cams = torch.stack([c(f) for c in self.camera_predictor], dim=1)      # [B,K,8]
         probs = F.softmax(cams[:, :, 4], dim=1)
         cam = torch.cat([cams[:, :, 5:6], cams[:, :, 6:8], cams[:, :, 0:4], probs.unsqueeze(-1)], dim=2)
-        inds = torch.multinomial(probs.detach(), 1)                  # per-rank RNG stream (:358-359)
+        # per-rank RNG stream (:358-359).  torch.multinomial device-asserts on a non-finite probability and the assert takes the
+        # whole process down (HSA hardware exception) -- a diverged run must reach the caller's own finite-loss check instead, so
+        # non-finite rows are sampled uniformly (finite rows are untouched: nan_to_num is the identity on them)
+        inds = torch.multinomial(torch.nan_to_num(probs.detach(), nan=1.0, posinf=1.0, neginf=0.0).clamp_min(1e-30), 1)
         sampled = torch.gather(cam, 1, inds.unsqueeze(-1).expand(-1, 1, 8)).squeeze(1)[:, 0:7]
         return sampled, inds, cam[:, :, 7], cam[:, :, 0:7], cams[:, :, 0:4]
 
