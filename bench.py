@@ -21,6 +21,7 @@ rank 0, N=1 only).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -53,8 +54,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5, help="untimed steps with kernel events for `roofline`")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
     ap.add_argument("--graph", type=int, default=0,
-                    help="--model 0 only: capture the hot-path step (every raster / loss kernel, forward and backward) in ONE HIP "
-                         "graph and time graph replays instead of eager launches")
+                    help="capture the step in ONE HIP graph and time graph replays instead of eager launches: with --model 0 the "
+                         "render-and-compare step (every raster / loss kernel, forward and backward), otherwise (train_s1, 1 GPU) "
+                         "the whole training step incl. MeshNet, backward and Adam")
     return ap.parse_args()
 
 
@@ -209,6 +211,41 @@ def main():
                 hip_graph.replay()
                 return static_total
 
+    whole_graph = None
+    if args.graph and use_model and world == 1 and args.workload == "s1":
+        # The WHOLE training step -- distance transform, MeshNet forward, every raster / loss kernel, backward, fused Adam with its
+        # on-device learning-rate schedule -- captured once into one HIP graph and replayed: the eager step's host enqueue time
+        # (config.host_enqueue_ms_per_step of the eager line) leaves the timed region.  Same recipe as the hot-path capture
+        # above: first eager steps (MIOpen solver search, caches), warm-up and capture on ONE side stream; gradients dropped
+        # before the capture so that they become graph-private allocations.
+        eager_step = step_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(max(3, args.warmup)):
+                    eager_step()
+                torch.cuda.synchronize()
+                whole_graph = torch.cuda.CUDAGraph()
+                with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(whole_graph, stream=side):
+                    static_loss = eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            whole_graph.replay()
+            torch.cuda.synchronize()
+            if not math.isfinite(float(static_loss)):
+                raise RuntimeError("first replay of the captured step returned a non-finite loss")
+
+            def step_fn():
+                whole_graph.replay()
+                return static_loss
+            step_fn.model = eager_step.model
+        except Exception as ex:     # noqa: BLE001 -- report, fall back to the eager step (the line then says hip_graph: false)
+            sys.stderr.write("bench.py: whole-step HIP-graph capture failed (%s: %s); timing the eager step\n" % (type(ex).__name__, ex))
+            whole_graph = None
+            torch.cuda.synchronize()
+            step_fn = build_step()
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -243,11 +280,14 @@ def main():
             # graph owns are only ever read back with .item() -- an eager torch op on `loss` here, torch.isfinite, was
             # reproducibly followed by replays whose last reduction returned a stale value; check_replay guards that.)
             break
-        ok = torch.isfinite(loss.detach()).reshape(1).to(torch.float32)
+        if whole_graph is not None:     # graph-owned tensor: read it with .item() only (see check_replay above)
+            ok = torch.tensor([1.0 if math.isfinite(float(loss)) else 0.0], device=dev)
+        else:
+            ok = torch.isfinite(loss.detach()).reshape(1).to(torch.float32)
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if bool(ok.item()) or discarded >= 2 or not use_model:
+        if bool(ok.item()) or discarded >= 2 or not use_model or whole_graph is not None:
             break
         discarded += 1
         if rank == 0:     # what the discarded trajectory looked like (stderr: the JSON line on stdout stays alone)
@@ -270,8 +310,9 @@ def main():
     _lib.profile_enable(True)
     for k in range(4):
         _lib.profile_collect(k)
+    prof_step = eager_step if whole_graph is not None else step_fn     # graph replays do not pass through the C ABI's event scope
     for _ in range(max(1, args.profile_steps)):
-        step_fn()
+        prof_step()
     barrier()
     _lib.profile_enable(False)
     prof = {k: _lib.profile_collect(k) for k in range(4)}   # 0 fwd, 1 bwd, 2 silhouette/id fwd, 3 silhouette bwd
@@ -384,7 +425,9 @@ def main():
         "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                         "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
                         "final_loss": float(loss.detach()), "discarded_nonfinite_runs": discarded,
-                        "hip_graph": bool(args.graph and not use_model and world == 1),
+                        "hip_graph": bool((args.graph and not use_model and world == 1) or whole_graph is not None),
+                        "hip_graph_scope": ("whole training step (network + losses + Adam)" if whole_graph is not None else
+                                            ("render-and-compare step" if (args.graph and not use_model and world == 1) else None)),
                         "hot_path_loss_spread": loss_spread}, **rccl),
         # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
         # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the

@@ -65,19 +65,24 @@ def test_raster_cabi_vs_reference_golden(name):
     np.testing.assert_array_equal(t2n(o["faces_info"]), g["faces_info"])
     # 1e-4 = north_star render tolerance
     assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="soft_colors")   # measured on MI355X: max |err| 3.6e-7, every element within 1e-4
+    # Bounds below = ~10x what the MI355X measured (profiles/r03_parity_measured.jsonl), every element (frac = 1).
     if int(g["func_id_rgb"]) == 1:
-        assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=1e-3, frac=0.999, name="aggrs")
+        # soft-max sum / max planes: measured max relative error 2.7e-7 (sum ~ 2e4)
+        assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=3e-6, frac=1.0, name="aggrs")
         scale = np.abs(g["p2f_sum"]).max()
-        assert_close_frac(t2n(o["p2f_sum"]), g["p2f_sum"], atol=1e-4 * scale, rtol=1e-3, frac=0.995, name="p2f_sum")
-        assert_close_frac(t2n(o["p2f_info"]), g["p2f_info"], atol=1e-4 * scale, rtol=1e-3, frac=0.995, name="p2f_info")
+        # p2f accumulators are float-atomic sums (order not fixed): measured 4.6e-5 absolute on sums of ~145
+        assert_close_frac(t2n(o["p2f_sum"]), g["p2f_sum"], atol=4e-6 * scale, rtol=1e-5, frac=1.0, name="p2f_sum")
+        assert_close_frac(t2n(o["p2f_info"]), g["p2f_info"], atol=4e-6 * scale, rtol=1e-5, frac=1.0, name="p2f_info")
     else:
-        ids_ok = (t2n(o["aggrs_info"])[:, 1] == g["aggrs_info"][:, 1]).mean()
-        assert ids_ok >= 0.999, ids_ok   # face-id plane: integer work, bit exact up to isolated depth ties
-        assert_close_frac(t2n(o["aggrs_info"])[:, 0], g["aggrs_info"][:, 0], atol=0, rtol=1e-5, frac=0.999, name="depth")
+        # hard render: the z-buffer winner (integer work) and its depth -- bit exact.  Tie rule: among faces of equal depth at
+        # a pixel the FIRST in index order wins (strict `<` against the running minimum, :408-411), as in the reference.
+        np.testing.assert_array_equal(t2n(o["aggrs_info"])[:, 1], g["aggrs_info"][:, 1])
+        np.testing.assert_array_equal(t2n(o["aggrs_info"])[:, 0], g["aggrs_info"][:, 0])
     sf = np.abs(g["grad_faces"]).max()
-    assert_close_frac(t2n(o["grad_faces"]), g["grad_faces"], atol=1e-4 * sf, rtol=2e-3, frac=0.99, name="grad_faces")
+    # measured: grad_faces max 8.9e-4 absolute at scale 650 .. 1084 (1.4e-6 of scale); grad_textures 2e-7 of scale
+    assert_close_frac(t2n(o["grad_faces"]), g["grad_faces"], atol=1.5e-5 * sf, rtol=1e-4, frac=1.0, name="grad_faces")
     st = max(np.abs(g["grad_textures"]).max(), 1e-12)
-    assert_close_frac(t2n(o["grad_textures"]), g["grad_textures"], atol=1e-4 * st, rtol=2e-3, frac=0.99, name="grad_textures")
+    assert_close_frac(t2n(o["grad_textures"]), g["grad_textures"], atol=3e-6 * st, rtol=1e-4, frac=1.0, name="grad_textures")
 
 
 def test_raster_flags_and_fused_pool():
@@ -126,15 +131,15 @@ def test_smr_softrenderer_vs_reference_golden(name):
     imgs, p2f, aggr = r.forward(verts, faces, cams, tex)
     assert imgs.shape == g["imgs"].shape and aggr.shape == g["aggr"].shape
     assert_close_frac(t2n(imgs), g["imgs"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="imgs")   # 1e-4: north_star; measured max |err| 2.4e-7
-    assert_close_frac(t2n(p2f), g["p2f"], atol=2e-3, rtol=1e-3, frac=0.99, name="p2f")
+    assert_close_frac(t2n(p2f), g["p2f"], atol=5e-6, rtol=1e-5, frac=1.0, name="p2f")                # measured max 5.4e-7
     np.testing.assert_allclose(t2n(r.project_points(verts, cams)), g["proj_points"], atol=2e-6)
     imgs.backward(torch.from_numpy(g["grad_imgs"]).to(DEV))
     for got, key in ((verts.grad, "grad_verts"), (cams.grad, "grad_cams")):
         s = max(np.abs(g[key]).max(), 1e-12)
-        assert_close_frac(t2n(got), g[key], atol=2e-4 * s, rtol=5e-3, frac=0.98, name=key)
+        assert_close_frac(t2n(got), g[key], atol=5e-5 * s, rtol=1e-4, frac=1.0, name=key)   # measured <= 5e-6 of scale
     if tex is not None:
         s = np.abs(g["grad_textures"]).max()
-        assert_close_frac(t2n(tex.grad), g["grad_textures"], atol=1e-4 * s, rtol=2e-3, frac=0.99, name="grad_textures")
+        assert_close_frac(t2n(tex.grad), g["grad_textures"], atol=1e-5 * s, rtol=1e-4, frac=1.0, name="grad_textures")   # measured 1e-6 of scale
 
 
 @pytest.mark.parametrize("ts,rgb", [(36, "softmax"), (1, "softmax"), (1, "hard")])
@@ -164,13 +169,16 @@ def test_full_size_vs_oracle(oracle_built, ts, rgb):
     assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.9999, max_outlier=2e-3, name="soft_colors")
     if rgb == "softmax":
         p2f_ref = o["p2f_info"] / np.maximum(o["p2f_sum"], 1e-12)
-        assert_close_frac(t2n(p2f), p2f_ref, atol=2e-3, frac=0.99, name="p2f")
+        assert_close_frac(t2n(p2f), p2f_ref, atol=3e-5, frac=1.0, name="p2f")                      # measured max 2.7e-6
     else:
         assert (t2n(aggr)[:, 1] == o["aggrs_info"][:, 1]).mean() >= 0.9995
     sf = np.abs(gf).max()
-    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * sf, rtol=5e-3, frac=0.99, name="grad_faces")
+    # measured: 99.86-99.89 % of the 23 040 values within 1e-4 of scale + 5e-3 relative; the rest are rim pixels (distance band
+    # edge, weights ~1e-10 that the soft-max renormalises to O(1)) whose accept / reject flips on 1-ulp exp differences
+    # between the host's libm and v_exp_f32: up to 1.4 % of scale
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * sf, rtol=5e-3, frac=0.997, max_outlier=6e-2 * sf, name="grad_faces")
     st = max(np.abs(gt).max(), 1e-12)
-    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * st, rtol=5e-3, frac=0.99, name="grad_textures")
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * st, rtol=5e-3, frac=0.9999, name="grad_textures")   # measured: every element (max 0.3 of atol)
 
 
 def test_backward_is_linear_in_upstream_gradient():
@@ -207,11 +215,11 @@ def test_losses_vs_reference_goldens():
     loss, masks = mml.forward(verts, torch.from_numpy(g["faces"]).to(DEV), cams, probs,
                               torch.from_numpy(g["masks_gt"]).to(DEV))
     assert abs(loss.item() - float(g["loss"])) < 1e-5
-    assert_close_frac(t2n(masks), g["mask_all_hypo"], atol=1e-4, frac=0.999, name="masks")
+    assert_close_frac(t2n(masks), g["mask_all_hypo"], atol=1e-4, frac=1.0, max_outlier=2e-6, name="masks")   # measured max 1.2e-7
     loss.backward()
     for got, key in ((verts.grad, "grad_verts"), (cams.grad, "grad_cams"), (probs.grad, "grad_probs")):
         s = np.abs(g[key]).max()
-        assert_close_frac(t2n(got), g[key], atol=2e-4 * s, rtol=5e-3, frac=0.98, name=key)
+        assert_close_frac(t2n(got), g[key], atol=5e-6 * s, rtol=1e-4, frac=1.0, name=key)   # measured <= 4e-7 of scale
 
     g = load_golden("loss_neg_iou.npz")
     p = torch.from_numpy(g["predict"]).to(DEV).requires_grad_(True)
@@ -252,7 +260,9 @@ def test_losses_vs_reference_goldens():
         np.testing.assert_allclose(t2n(d1), g["d1_%d" % i], atol=2e-6)
         np.testing.assert_allclose(t2n(d2), g["d2_%d" % i], atol=2e-6)
         assert i1.dtype == torch.int32
-        assert (t2n(i1) == g["i1_%d" % i]).mean() > 0.995 and (t2n(i2) == g["i2_%d" % i]).mean() > 0.995
+        # arg-mins: index work, exact.  Tie rule: the first index of the minimum (strict `<` in index order), torch.min's rule
+        np.testing.assert_array_equal(t2n(i1), g["i1_%d" % i])
+        np.testing.assert_array_equal(t2n(i2), g["i2_%d" % i])
         (d1.sum() + 0.5 * d2.sum()).backward()
         np.testing.assert_allclose(t2n(a.grad), g["ga%d" % i], atol=2e-5)
         np.testing.assert_allclose(t2n(b.grad), g["gb%d" % i], atol=2e-5)
@@ -318,7 +328,7 @@ def test_train_s1_step_vs_oracle(oracle_built):
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
         s = np.abs(r).max()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=3e-4 * s, rtol=5e-3, frac=0.98, name="grad_" + k)
+        assert_close_frac(t2n(out_g[k].grad), r, atol=3e-4 * s, rtol=5e-3, frac=0.99, name="grad_" + k)
 
 
 @pytest.mark.parametrize("name", RASTER)
@@ -336,7 +346,7 @@ def test_backward_variants_agree(name):
         s = max(float(a[k].abs().max()), 1e-12)
         assert float((a[k] - b[k]).abs().max()) <= 1e-4 * s, k
     sf = np.abs(g["grad_faces"]).max()
-    assert_close_frac(t2n(a["grad_faces"]), g["grad_faces"], atol=1e-4 * sf, rtol=2e-3, frac=0.99, name="pm grad_faces")
+    assert_close_frac(t2n(a["grad_faces"]), g["grad_faces"], atol=1.5e-5 * sf, rtol=1e-4, frac=1.0, name="pm grad_faces")
 
 
 def test_face_major_backward_non_pow2_and_determinism():
@@ -361,9 +371,9 @@ def test_face_major_backward_non_pow2_and_determinism():
     o = softras.raster_forward(t2n(fv), t2n(tex), 100, n_threads=4, **cfg)
     gf, gt = softras.raster_backward(o["faces"], o["textures"], o["soft_colors"], o["faces_info"], o["aggrs_info"],
                                      t2n(g), 100, n_threads=4, **cfg)
-    assert_close_frac(t2n(a[0]), o["soft_colors"], atol=1e-4, frac=0.999, name="soft_colors")
-    assert_close_frac(t2n(a[1]).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
-    assert_close_frac(t2n(a[2]), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="gt")
+    assert_close_frac(t2n(a[0]), o["soft_colors"], atol=1e-4, frac=1.0, max_outlier=5e-6, name="soft_colors")
+    assert_close_frac(t2n(a[1]).reshape(gf.shape), gf, atol=1e-5 * np.abs(gf).max(), rtol=1e-4, frac=1.0, name="gf")
+    assert_close_frac(t2n(a[2]), gt, atol=2e-6 * np.abs(gt).max(), rtol=1e-4, frac=1.0, name="gt")
 
 
 def test_train_s2_step_vs_oracle(oracle_built):
@@ -386,7 +396,7 @@ def test_train_s2_step_vs_oracle(oracle_built):
     for k in ("delta_v", "cam_hypotheses", "cam_probs", "tex_flow"):
         r = out_c[k].grad.numpy()
         s = np.abs(r).max()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=5e-4 * s, rtol=1e-2, frac=0.97, name="grad_" + k)
+        assert_close_frac(t2n(out_g[k].grad), r, atol=5e-4 * s, rtol=1e-2, frac=0.999, name="grad_" + k)
 
 
 def test_silhouette_only_kernels_match_full_kernels():
@@ -477,8 +487,8 @@ def test_cfg4_size_vs_oracle(oracle_built):
     sc.backward(gsc.to(DEV))
     # measured (4.2 M values): 99.998 % within 1e-4, max |err| 9.7e-4
     assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=0.9999, max_outlier=5e-3, name="soft_colors")
-    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
-    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="gt")
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.993, max_outlier=0.1 * np.abs(gf).max(), name="gf")   # measured 0.9967: rim pixels (see test_full_size_vs_oracle)
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.9999, name="gt")
 
 
 def test_eval_metrics_vs_reference_restatement(oracle_built):
@@ -540,8 +550,8 @@ def test_front_face_culling_and_depth_range_vs_oracle(oracle_built, rgb):
                                       'euclidean', 1e-10, 1e-4, rgb, 'prod', 'surface')
     sc.backward(gsc.to(DEV))
     assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-4, name="soft_colors")   # measured max 2.6e-6
-    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="gf")
-    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * max(np.abs(gt).max(), 1e-12), rtol=5e-3, frac=0.99, name="gt")
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.998, name="gf")          # measured 0.9993-0.9995
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * max(np.abs(gt).max(), 1e-12), rtol=5e-3, frac=1.0, name="gt")
     # and the silhouette-only kernels under the same depth range (the per-face "always in range" shortcut must not fire)
     a = UF.SilhouetteFunction.apply(fv.to(DEV).requires_grad_(True), 128, cfg["near"], cfg["far"], False, 1e-3, 1e-5, 1e-10,
                                     1e-4, False)
@@ -566,7 +576,7 @@ def test_degenerate_faces_do_not_poison_the_image():
     got = t2n(sc)
     finite_ref = np.isfinite(o["soft_colors"])
     assert np.isfinite(got[finite_ref]).all()
-    assert_close_frac(got[finite_ref], o["soft_colors"][finite_ref], atol=1e-4, frac=0.995, name="soft_colors")
+    assert_close_frac(got[finite_ref], o["soft_colors"][finite_ref], atol=1e-4, frac=1.0, max_outlier=2e-6, name="soft_colors")    # measured max 1.8e-7
 
 
 def test_visibility_only_kernel_matches_hard_render():

@@ -74,13 +74,13 @@ def test_reference_device_code_on_gpu_reproduces_the_goldens(name):
     assert np.array_equal(t2n(o["faces_info"]).view(np.uint32), g["faces_info"].view(np.uint32))
     # images: same text, device libm (exp / sqrt / pow) instead of the host's: agreement to a few ulp
     assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=2e-6, frac=1.0, max_outlier=2e-6, name="refgpu_soft_colors")
-    assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=1e-5, frac=0.9999, name="refgpu_aggrs")
+    assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=1e-5, frac=1.0, name="refgpu_aggrs")
     if int(g["func_id_rgb"]) == 1:
         assert_close_frac(t2n(o["p2f_sum"]), g["p2f_sum"], atol=1e-6 * np.abs(g["p2f_sum"]).max(), rtol=1e-4, frac=1.0, name="refgpu_p2f_sum")
     gf, gt = g["grad_faces"], g["grad_textures"]
     # hardware float atomics: the summation order is not the host loop's
-    assert_close_frac(t2n(o["grad_faces"]).reshape(gf.shape), gf, atol=1e-5 * np.abs(gf).max(), rtol=1e-3, frac=0.999, name="refgpu_grad_faces")
-    assert_close_frac(t2n(o["grad_textures"]), gt, atol=1e-5 * max(np.abs(gt).max(), 1e-12), rtol=1e-3, frac=0.999, name="refgpu_grad_textures")
+    assert_close_frac(t2n(o["grad_faces"]).reshape(gf.shape), gf, atol=1e-5 * np.abs(gf).max(), rtol=1e-3, frac=1.0, name="refgpu_grad_faces")
+    assert_close_frac(t2n(o["grad_textures"]), gt, atol=1e-5 * max(np.abs(gt).max(), 1e-12), rtol=1e-3, frac=1.0, name="refgpu_grad_textures")
 
 
 @pytest.mark.parametrize("ts,rgb", [(36, "softmax"), (1, "hard")])
@@ -103,10 +103,10 @@ def test_product_vs_reference_device_code_full_size(ts, rgb):
     sc.backward(gsc.to(DEV))
     assert_close_frac(t2n(sc), t2n(ref["soft_colors"]), atol=1e-4, frac=0.9999, max_outlier=2e-3, name="vs_refgpu_soft_colors")
     rp = ref["p2f_info"] / ref["p2f_sum"].clamp_min(1e-12)          # functional/soft_rasterize.py:73
-    assert_close_frac(t2n(p2f), t2n(rp), atol=2e-3, frac=0.99, name="vs_refgpu_p2f")
+    assert_close_frac(t2n(p2f), t2n(rp), atol=3e-5, frac=1.0, name="vs_refgpu_p2f")
     gf, gt = t2n(ref["grad_faces"]), t2n(ref["grad_textures"])
-    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.99, name="vs_refgpu_grad_faces")
-    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.99, name="vs_refgpu_grad_textures")
+    assert_close_frac(t2n(fvd.grad).reshape(gf.shape), gf, atol=1e-4 * np.abs(gf).max(), rtol=5e-3, frac=0.996, max_outlier=6e-2 * np.abs(gf).max(), name="vs_refgpu_grad_faces")
+    assert_close_frac(t2n(texd.grad), gt, atol=1e-4 * np.abs(gt).max(), rtol=5e-3, frac=0.9999, name="vs_refgpu_grad_textures")
 
 
 def test_fma_contraction_sensitivity_of_the_reference_text():
@@ -118,6 +118,31 @@ def test_fma_contraction_sensitivity_of_the_reference_text():
     faces, tex = torch.from_numpy(g["faces"]).to(DEV), torch.from_numpy(g["textures"]).to(DEV)
     o = _run_ref(h, faces, tex, int(g["image_size"]), g, torch.from_numpy(g["grad_soft_colors"]).to(DEV), g["background"])
     assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=0.995, name="refgpu_fma_soft_colors")
+
+
+def test_product_vs_fma_contracted_reference_at_full_size():
+    """nvcc's default contracts a*b+c into FMA and which products it fuses is the compiler's private choice; the reference's
+    CUDA render is only defined up to that.  The product (no contraction, like the goldens) against the SAME reference device
+    text built with contraction ON (libsoftras_ref_gfx950_fma.so), 2 x 1280 faces x 512^2, TS = 36: the fraction of values
+    within the north_star's 1e-4 for alpha, for alpha-weighted rgb (what every consumer composites) and for raw rgb -- whose
+    outliers are pixels OUTSIDE the silhouette, where the colour is a ratio of weights ~1e-9 and follows rounding noise.
+    Figures are recorded (profiles/r03_parity_measured.jsonl); alpha and composited colour are held to 1e-4."""
+    from oracle import torch_ref
+    from umr_amd import functional as UF
+    h = _lib("libsoftras_ref_gfx950_fma.so")
+    verts, faces, cams, gen = scene(2, 3, seed=5)
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).contiguous()
+    F = faces.shape[1]
+    tex = torch.rand(2, F, 36, 3, generator=gen)
+    gsc = torch.randn(2, 4, 512, 512, generator=gen)
+    cfg = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4, func_id_rgb=1,
+               double_side=True)
+    ref = t2n(_run_ref(h, fv.view(2, F, 9).to(DEV), tex.to(DEV), 512, cfg, gsc.to(DEV))["soft_colors"])
+    sc = t2n(UF.soft_rasterize(fv.to(DEV), tex.to(DEV), 512, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax')[0])
+    assert_close_frac(sc[:, 3], ref[:, 3], atol=1e-4, frac=0.9999, max_outlier=2e-3, name="vs_fma_alpha")
+    assert_close_frac(sc[:, :3] * sc[:, 3:4], ref[:, :3] * ref[:, 3:4], atol=1e-4, frac=0.9999, max_outlier=2e-3, name="vs_fma_alpha_weighted_rgb")
+    assert_close_frac(sc[:, :3], ref[:, :3], atol=1e-4, frac=0.98, name="vs_fma_raw_rgb")
 
 
 _DIST = {0: "hard", 1: "barycentric", 2: "euclidean"}
@@ -159,12 +184,12 @@ def test_other_modes_vs_reference_golden(case):
         assert np.array_equal(t2n(aggr[:, 1]), g[case + "/aggrs_info"][:, 1])
         np.testing.assert_allclose(t2n(aggr[:, 0]), g[case + "/aggrs_info"][:, 0], rtol=1e-6)
     else:
-        assert_close_frac(t2n(aggr), g[case + "/aggrs_info"], atol=0, rtol=1e-5, frac=0.9999, name="modes_%s_aggrs" % case)
+        assert_close_frac(t2n(aggr), g[case + "/aggrs_info"], atol=0, rtol=1e-5, frac=1.0, name="modes_%s_aggrs" % case)
         ref_p2f = g[case + "/p2f_info"] / np.maximum(g[case + "/p2f_sum"], 1e-12)
         assert_close_frac(t2n(p2f), ref_p2f, atol=1e-5, rtol=1e-4, frac=1.0, name="modes_%s_p2f" % case)
     rgf, rgt = g[case + "/grad_faces"], g[case + "/grad_textures"]
-    assert_close_frac(t2n(gf), rgf, atol=1e-5 * max(np.abs(rgf).max(), 1e-30), rtol=2e-4, frac=0.999, name="modes_%s_grad_faces" % case)
-    assert_close_frac(t2n(gt), rgt, atol=1e-5 * np.abs(rgt).max(), rtol=2e-4, frac=0.999, name="modes_%s_grad_textures" % case)
+    assert_close_frac(t2n(gf), rgf, atol=1e-5 * max(np.abs(rgf).max(), 1e-30), rtol=2e-4, frac=1.0, name="modes_%s_grad_faces" % case)
+    assert_close_frac(t2n(gt), rgt, atol=1e-5 * np.abs(rgt).max(), rtol=2e-4, frac=1.0, name="modes_%s_grad_textures" % case)
     if modes[0] == 0:
         assert float(gf[:, :, [0, 1, 3, 4, 6, 7]].abs().max()) == 0.0       # 'hard' distance has no x / y gradient (:634-642)
 
@@ -192,5 +217,5 @@ def test_other_modes_vs_reference_device_code_full_size(modes, ts, sigma):
         same = (aggr[:, 1] == o["aggrs_info"][:, 1]).float().mean().item()
         assert same >= 0.9999, same
     rgf, rgt = t2n(o["grad_faces"]), t2n(o["grad_textures"])
-    assert_close_frac(t2n(gf), rgf, atol=3e-4 * max(np.abs(rgf).max(), 1e-30), rtol=5e-3, frac=0.995, name=tag + "_grad_faces")
-    assert_close_frac(t2n(gt), rgt, atol=3e-4 * np.abs(rgt).max(), rtol=5e-3, frac=0.995, name=tag + "_grad_textures")
+    assert_close_frac(t2n(gf), rgf, atol=3e-4 * max(np.abs(rgf).max(), 1e-30), rtol=5e-3, frac=0.9999, name=tag + "_grad_faces")
+    assert_close_frac(t2n(gt), rgt, atol=3e-4 * np.abs(rgt).max(), rtol=5e-3, frac=1.0, name=tag + "_grad_textures")

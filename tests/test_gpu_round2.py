@@ -111,7 +111,7 @@ def test_directional_light_folded_into_projection_vs_oracle(oracle_built):
     assert_close_frac(t2n(img), ri.detach().numpy(), atol=1e-4, frac=0.999, max_outlier=0.05, name="lit_image")
     for name, a, b in (("verts", vg, vc), ("cams", cg, cc), ("tex", tg, tc)):
         ref_g = b.grad.numpy()
-        assert_close_frac(t2n(a.grad), ref_g, atol=3e-4 * np.abs(ref_g).max(), rtol=5e-3, frac=0.98, name="lit_grad_" + name)
+        assert_close_frac(t2n(a.grad), ref_g, atol=3e-5 * np.abs(ref_g).max(), rtol=1e-3, frac=1.0, name="lit_grad_" + name)
     # the light term really is in the vertex gradient: with the directional part off the gradient differs
     v2 = verts.to(DEV).requires_grad_(True)
     r2 = SoftRenderer(64, "softmax")
@@ -142,7 +142,7 @@ def test_perceptual_texture_loss_vs_oracle():
     np.testing.assert_allclose(t2n(v), rv.detach().numpy(), atol=1e-4, rtol=1e-4)     # fp32 convolutions, different
     for name, a, b in (("img", pg, pc), ("mask", mg, mc)):                           # summation order (MIOpen vs CPU)
         rg = b.grad.numpy()
-        assert_close_frac(t2n(a.grad), rg, atol=2e-3 * np.abs(rg).max(), rtol=2e-2, frac=0.99, name="perc_grad_" + name)
+        assert_close_frac(t2n(a.grad), rg, atol=2e-5 * np.abs(rg).max(), rtol=1e-3, frac=1.0, name="perc_grad_" + name)
     assert abs(float(ptl(pred.to(DEV), gt.to(DEV), m_gt.to(DEV))) - float(ref(pred, gt, m_gt))) < 1e-4   # mask_pred=None branch
 
 
@@ -190,7 +190,7 @@ def test_multi_texture_loss_perceptual_branch_vs_oracle(oracle_built):
     tex_loss.backward()
     assert abs(float(tex_loss) - float(ref_loss)) <= 2e-4 * max(1.0, abs(float(ref_loss)))
     rg = out_c["tex_flow"].grad.numpy()
-    assert_close_frac(t2n(out_g["tex_flow"].grad), rg, atol=2e-3 * np.abs(rg).max(), rtol=2e-2, frac=0.97, name="mtl_grad_flow")
+    assert_close_frac(t2n(out_g["tex_flow"].grad), rg, atol=2e-5 * np.abs(rg).max(), rtol=1e-3, frac=0.999, name="mtl_grad_flow")
 
 
 def _s1_pair(B, H, subdiv, seed, epoch):
@@ -225,7 +225,7 @@ def test_train_s1_step_with_perceptual_term_and_epoch_gating(oracle_built, epoch
     assert abs(w) > 1e-3
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.97, name="s1_e%d_grad_%s" % (epoch, k))
+        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.995, name="s1_e%d_grad_%s" % (epoch, k))
 
 
 def test_train_s1_step_at_bench_shape_vs_oracle(oracle_built):
@@ -237,7 +237,7 @@ def test_train_s1_step_at_bench_shape_vs_oracle(oracle_built):
     assert abs(float(total) - float(ref_total)) <= 3e-4 * max(1.0, abs(float(ref_total)))
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.97, name="s1_bench_grad_" + k)
+        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.998, name="s1_bench_grad_" + k)
 
 
 def test_train_s2_step_at_bench_shape_vs_oracle(oracle_built):
@@ -263,7 +263,7 @@ def test_train_s2_step_at_bench_shape_vs_oracle(oracle_built):
         assert abs(float(terms[k]) - float(ref_terms[k])) <= 3e-4 * max(1.0, abs(float(ref_terms[k]))), (k, float(terms[k]), float(ref_terms[k]))
     for k in ("delta_v", "cam_hypotheses", "cam_probs", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.97, name="s2_bench_grad_" + k)
+        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.998, name="s2_bench_grad_" + k)
 
 
 def test_baseline_config1_shape_single_image(oracle_built):
@@ -283,7 +283,7 @@ def test_baseline_config1_shape_single_image(oracle_built):
     ref.ambient_light_only()
     ri, rp, ra = ref(verts, faces, cams, tex)
     assert img.shape == (1, 4, 256, 256) and aggr.shape == (1, 2, 512, 512)
-    assert_close_frac(t2n(img), ri.numpy(), atol=1e-4, frac=0.999, max_outlier=0.05, name="cfg1_image")
+    assert_close_frac(t2n(img), ri.numpy(), atol=1e-4, frac=0.9999, max_outlier=1e-3, name="cfg1_image")
     assert_close_frac(t2n(p2f), rp.numpy(), atol=1e-4, frac=0.995, name="cfg1_p2f")
     pts = torch.rand(1, 300, 2, generator=gen) * 2 - 1
     v2d = r.project_points(verts.to(DEV), cams.to(DEV))

@@ -51,7 +51,7 @@ def test_train_s2_step_at_config4_shape_vs_oracle(oracle_built):
     assert abs(float(total) - float(ref_total)) <= 3e-4 * max(1.0, abs(float(ref_total)))
     for k in ("delta_v", "cam_hypotheses", "cam_probs", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.97, name="s2_cfg4_grad_" + k)
+        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.998, name="s2_cfg4_grad_" + k)   # measured 0.9996 .. 1.0
 
 
 def test_loss_kernels_at_config4_resolution(oracle_built):

@@ -414,8 +414,13 @@ def build_training_step(tv, faces, args, dev, world):
     rc = RenderCompareS1(net.get_mean_shape().detach(), net.faces, args.image_size, discriminator=ddp_disc,
                          texture_loss=PerceptualTextureLoss(dev), epoch=getattr(args, "epoch", 0)).to(dev)
     # same update rule as train_utils.py:186-187; `fused` runs it as one multi-tensor kernel on the GPU
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
-                           betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))
+    # capturable: the step is going to be captured into ONE HIP graph (bench.py --graph 1) -- the learning rate and the step
+    # counter then live on the device and the schedule below is device arithmetic inside the graph
+    capt = bool(getattr(args, "graph", 0)) and torch.device(dev).type == "cuda"
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad],
+                           lr=(torch.tensor(opts.learning_rate, device=dev) if capt else opts.learning_rate),
+                           betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"), capturable=capt)
+    it_dev = torch.zeros((), device=dev) if capt else None
     rank = torch.distributed.get_rank() if (world > 1 and torch.distributed.is_initialized()) else 0
     _, _, _, batch = make_s1_inputs(args.batch, args.image_size, args.subdivide, seed=100 + rank, device=dev)
     mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
@@ -423,8 +428,11 @@ def build_training_step(tv, faces, args, dev, world):
     state = dict(it=0)
 
     def step():
-        for g in opt.param_groups:
-            g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)  # train_utils.py:194
+        for g in opt.param_groups:                                    # train_utils.py:194
+            if capt:
+                g['lr'].copy_(opts.learning_rate / (1 + it_dev * 5e-4))
+            else:
+                g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)
         opt.zero_grad(set_to_none=True)
         # the reference computes the barrier distance transform on the host in set_input (train_s1.py:171-174)
         batch["dts_barrier"] = compute_dt_barrier(batch["masks"]).unsqueeze(1)
@@ -434,6 +442,8 @@ def build_training_step(tv, faces, args, dev, world):
         total.backward()
         opt.step()
         state["it"] += 1
+        if capt:
+            it_dev.add_(1)
         return total.detach()
 
     step.model = model
