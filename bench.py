@@ -290,6 +290,14 @@ def main():
         if bool(ok.item()) or discarded >= 2 or not use_model or whole_graph is not None:
             break
         discarded += 1
+        if rank == 0 and getattr(step_fn, "watch", None):    # UMR_WATCH_TERMS=1: which term went non-finite first
+            for i, (names, vals) in enumerate(step_fn.watch):
+                v = vals.tolist()
+                if not all(math.isfinite(x) for x in v) or i < 2:
+                    sys.stderr.write("bench.py: step %d terms %s\n" % (i, " ".join("%s=%.4g" % (n, x) for n, x in
+                                                                                    zip(list(names) + ["|delta_v|", "|cams|", "|flow|"], v))))
+                    if not all(math.isfinite(x) for x in v):
+                        break
         if rank == 0:     # what the discarded trajectory looked like (stderr: the JSON line on stdout stays alone)
             hist = [float(x) for x in torch.stack([h.detach().reshape(()) for h in measure.history]).tolist()]
             sys.stderr.write("bench.py: measurement %d discarded, loss per timed step: %s\n"

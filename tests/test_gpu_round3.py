@@ -203,8 +203,11 @@ def test_loss_and_geometry_operators_opcheck_and_match_the_function_path():
     gv, gc = v.grad.clone(), c.grad.clone(); v.grad = None; c.grad = None
     _, fo2, _ = UF.ProjectFacesFunction.apply(v, c, fi, 5.0, -2.732, False)
     (fo2 * w).sum().backward()
-    assert torch.equal(fo, fo2) and torch.equal(gc, c.grad)
-    assert float((gv - v.grad).abs().max()) <= 1e-5 * float(gv.abs().max())       # vertex scatter: float atomics
+    assert torch.equal(fo, fo2)
+    # backward: the face gradients are scattered onto the vertices with float atomics, and the camera gradient is reduced
+    # from those sums: equal up to summation order
+    assert float((gv - v.grad).abs().max()) <= 1e-5 * float(gv.abs().max())
+    assert float((gc - c.grad).abs().max()) <= 1e-5 * float(gc.abs().max())
     p, t = torch.rand(3, 32, 32, generator=g).to(DEV).requires_grad_(True), (torch.rand(3, 32, 32, generator=g) > 0.5).float().to(DEV)
     opcheck(torch.ops.umr.neg_iou.default, (p, t), test_utils=utils)
     l1 = torch.ops.umr.neg_iou(p, t)[0]; l1.sum().backward(); g1 = p.grad.clone(); p.grad = None

@@ -475,6 +475,8 @@ def build_training_step_s2(args, dev, world):
     mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
     input_imgs = (batch["imgs"] - mean) / std
     state = dict(it=0)
+    import os
+    watch = [] if os.environ.get("UMR_WATCH_TERMS") else None
 
     def step():
         for g in opt.param_groups:
@@ -484,7 +486,11 @@ def build_training_step_s2(args, dev, world):
         out = ddp_net(input_imgs)
         out["mean_shape"] = net.get_mean_shape()
         out["pred_vs"] = out["mean_shape"][None] + net.symmetrize(out["delta_v"])
-        total, _ = rc(out, batch)
+        total, terms = rc(out, batch)
+        if watch is not None:       # UMR_WATCH_TERMS=1: per-step loss terms + a few state norms, kept on the device (no sync)
+            watch.append((sorted(terms), torch.stack([terms[k].detach().reshape(()) for k in sorted(terms)] +
+                                                     [out["delta_v"].detach().abs().max(), out["cam_hypotheses"].detach().abs().max(),
+                                                      out["tex_flow"].detach().abs().max()])))
         total.backward()
         opt.step()
         batch["random_imgs"] = (batch["imgs"] * batch["masks"].unsqueeze(1)).detach()  # :268
@@ -492,4 +498,5 @@ def build_training_step_s2(args, dev, world):
         return total.detach()
 
     step.model = model
+    step.watch = watch
     return step
