@@ -21,6 +21,9 @@ cp("bench_hotpath_only.json", tag + "_bench_hotpath_only.json")
 cp("bench_s2.json", tag + "_bench_s2.json")
 if os.path.exists(os.path.join(SRC, "bench_hotpath_graph.json")):
     cp("bench_hotpath_graph.json", tag + "_bench_hotpath_graph.json")
+for extra in ("bench_full_graph.json", "bench_s2_cfg4.json", "bench_ddp1.json", "eval_bench.json"):
+    if os.path.exists(os.path.join(SRC, extra)) and os.path.getsize(os.path.join(SRC, extra)) > 0:
+        cp(extra, tag + "_" + extra)
 if os.path.exists(os.path.join(SRC, "valu_ubench.log")):
     cp("valu_ubench.log", tag + "_valu_ubench.log")
 cp("stats/t_kernel_stats.csv", tag + "_bench_kernel_stats.csv")
@@ -88,6 +91,38 @@ for name, key in (("textured forward", "forward_kernel"), ("silhouette forward",
         L.append("%s: avg %.1f us/launch, %.0f GB/s algorithmic = %.1f %% of 8 TB/s (%.1f MB/launch).\n"
                  % (name, k["avg_us"], k["achieved"], 100 * k["frac"], k["alg_bytes_per_launch"] / 1e6))
 L.append("train_s2 sequence, `--workload s2` (`profiles/%s_bench_s2.json`, 10 steps): %.0f images/s, %.1f ms/step.\n" % (tag, s2["value"], s2["ms_per_step"]))
+
+
+def _load(name):
+    pth = os.path.join(SRC, name)
+    try:
+        return json.load(open(pth)) if os.path.exists(pth) and os.path.getsize(pth) > 0 else None
+    except ValueError:
+        return None
+
+
+fg, c4, dd, ev = _load("bench_full_graph.json"), _load("bench_s2_cfg4.json"), _load("bench_ddp1.json"), _load("eval_bench.json")
+if fg:
+    L.append("Whole training step replayed from ONE HIP graph, `--graph 1` (`profiles/%s_bench_full_graph.json`): hip_graph = %s, "
+             "**%.0f images/s**, %.2f ms/step, host enqueue %.2f ms/step (eager line above: %.2f ms of host enqueue per %.2f ms step) -- "
+             "the step is bound by its GPU work, not by the launches.\n"
+             % (tag, fg["config"]["hip_graph"], fg["value"], fg["ms_per_step"], fg["config"]["host_enqueue_ms_per_step"],
+                full["config"]["host_enqueue_ms_per_step"], full["ms_per_step"]))
+if c4:
+    L.append("BASELINE configs[3] shape, `--workload s2 --image-size 512 --subdivide 4` (`profiles/%s_bench_s2_cfg4.json`; bs 16, "
+             "IS = 1024, 5120 faces, K = 8): **%.0f images/s**, %.1f ms/step; textured raster backward %.0f us/launch (N = 128 views), "
+             "%.1f %% of 8 TB/s algorithmic.\n" % (tag, c4["value"], c4["ms_per_step"], c4["roofline"]["avg_us"] or 0, 100 * (c4["roofline"]["frac"] or 0)))
+if dd:
+    cfg = dd["config"]
+    L.append("1-rank RCCL run, `--force-ddp 1` (`profiles/%s_bench_ddp1.json`): %.0f images/s; the model's %.0f MB of gradients "
+             "all-reduced stand-alone in %d buckets of %d MB: %.2f ms (one rank: RCCL's launch + local-copy floor).\n"
+             % (tag, dd["value"], cfg.get("allreduce_bytes", 0) / 1e6, cfg.get("ddp_buckets", 0), cfg.get("ddp_bucket_mb", 0),
+                cfg.get("allreduce_ms_standalone", float("nan"))))
+if ev:
+    L.append("Evaluation path (BASELINE configs[4], `tools/r3/eval_bench.py`, `profiles/%s_eval_bench.json`): %d synthetic pairs x 2 "
+             "directions x %d keypoints -- flow mode %.0f pairs/s (%.1f us/pair), cam mode %.0f pairs/s (%.1f us/pair), PCK counters on "
+             "the device.\n" % (tag, ev["pairs"], ev["keypoints"], ev["flow"]["pairs_per_s"], ev["flow"]["us_per_pair"],
+                                 ev["cam"]["pairs_per_s"], ev["cam"]["us_per_pair"]))
 bk = [r for r in ours if "k_raster_backward_fm<1, false, true" in r["Name"]]
 tsum = os.path.join(SRC, "raster_trace_summary.json")
 if os.path.exists(tsum):
@@ -123,6 +158,17 @@ L.append("Calibration: `%s` reads %d known bytes with dword loads; FETCH_SIZE re
 L.append("| kernel (N=16 launches inside bench) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch (corrected) |\n|---|---|---|---|")
 for k, v in tr["kernels"].items():
     L.append("| `%s` | %.0f | %.0f | %.1f MB |" % (short(k), v["FETCH_SIZE_KB"], v["WRITE_SIZE_KB"], v["hbm_bytes_per_launch"] / 1e6))
+L.append("\n## VALU roofline of the same launches (SQ PMC passes of the bench command, build %s)\n" % tr.get("build_id"))
+L.append("Peak = 157.3 TFLOP/s fp32 vector = 1228.9 G wave64-instructions/s.  `lane use` = SQ_THREAD_CYCLES_VALU / (64 x "
+         "SQ_ACTIVE_INST_VALU); wait / issue-stall / active = the three disjoint buckets of a wave's life.\n")
+L.append("| kernel | us (PMC pass) | issued VALU wave-instr | SALU wave-instr | lane use | % of VALU peak | wait | issue stall | active |\n|---|---|---|---|---|---|---|---|---|")
+for k, v in tr["kernels"].items():
+    u = v.get("valu")
+    if u:
+        L.append("| `%s` | %.1f | %.1f M | %.1f M | %.3f | %.1f | %.2f | %.2f | %.2f |"
+                 % (short(k)[:60], u["kernel_us_in_pmc_pass"], u["issued_wave_instr"] / 1e6, (u.get("salu_wave_instr") or 0) / 1e6,
+                    u.get("lane_use") or 0, 100 * u["frac_of_peak"], u.get("wave_wait_frac") or 0, u.get("wave_issue_stall_frac") or 0,
+                    u.get("wave_active_frac") or 0))
 L.append("\n## Kernel timings and SQ counters\n")
 L.append("`profiles/%s_microbench.log`: torch-event timings per autograd call (incl. face setup and allocation) and, last "
          "line, kernel-only HIP-event averages in us per launch [forward, backward] at N=16 / N=128.\n" % tag)
