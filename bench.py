@@ -31,6 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_RESULT_OUT = None
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 METRIC = "train images/sec (CUB 256^2, 642-vert mesh)"
 
@@ -107,6 +108,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a version banner to the C-level stdout at
+    # exit, MIOpen may chat -- keep a private handle on the real stdout for the result and send file descriptor 1 to stderr
+    global _RESULT_OUT          # (after the self-launch decision: the ranks it starts inherit the real stdout)
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
@@ -456,7 +464,7 @@ def main():
         n = args.cpu_sample or max(1, min(args.batch, softras.max_threads() // 2))
         out["cpu_baseline"] = cpu_baseline(args, n)
         out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=_RESULT_OUT, flush=True)
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
         dist.destroy_process_group()
