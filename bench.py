@@ -402,7 +402,8 @@ def main():
             traffic_note = "PMC FETCH_SIZE (x%.2f calibrated) + WRITE_SIZE per launch, tools/collect_traffic.sh on build %s" % (
                 tj.get("calibration", {}).get("fetch_correction_factor", 2.0), tj.get("build_id"))
             for kname, key in (("k_raster_backward_fm<1", "backward"), ("k_raster_forward<1", "forward_kernel"),
-                               ("k_raster_forward<2", "silhouette_forward"), ("k_raster_backward_fm<2", "silhouette_backward")):
+                               ("k_raster_forward<2", "silhouette_forward"), ("k_raster_backward_fm<2", "silhouette_backward"),
+                               ("k_raster_backward_fm_slots<2", "silhouette_backward")):
                 for kn, e in tj.get("kernels", {}).items():
                     if kname in kn and e.get("valu"):
                         v = e["valu"]
