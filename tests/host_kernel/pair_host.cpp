@@ -77,6 +77,9 @@ __device__ __forceinline__ float lean_segments(LeanSeg &s, const LeanFace &L, fl
 
 extern "C" {
 
+static float g_thin_h = THIN_FACE_H;   // k_face_setup's thin-face threshold (the product default; host_set_thin_h for A/B)
+void host_set_thin_h(float h) { g_thin_h = h; }
+
 // faces [n,9] -> per (face, pixel): live flag, soft fragment D, unclipped barycentrics, dx, dy, clipped depth zp
 int host_pairs(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,
                float near_, float far_, unsigned char *live, float *frag, float *dxy, float *zp_out) {
@@ -85,7 +88,7 @@ int host_pairs(const float *faces, int n, const float *xp, const float *yp, int 
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        k_face_setup(faces, nullptr, bbox, rec, n, thr, near_, far_, nullptr, 0);
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, near_, far_, nullptr, 0, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         Face fc;
@@ -114,7 +117,7 @@ int host_texels(const float *faces, int n, const float *xp, const float *yp, int
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         Face fc;
@@ -144,7 +147,7 @@ int host_general_frag(const float *faces, int n, const float *xp, const float *y
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
     }
     RasterArgs A = {};
     A.threshold = threshold; A.nis = nis; A.thr = thr; A.dist_mode = dist_mode;
@@ -190,7 +193,7 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_INV);
@@ -215,7 +218,7 @@ int host_accurate_pairs(const float *faces, int n, const float *xp, const float 
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0);
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         Face fc;

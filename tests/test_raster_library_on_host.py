@@ -1,0 +1,233 @@
+"""CPU tests (no GPU): the product's WHOLE raster translation unit -- umr_amd/csrc/raster.hip with k_face_setup, k_superblock_bin,
+k_raster_forward<...>, k_face_order, k_raster_backward_fm[_slots]<...>, the general-mode and pixel-major kernels, the launch
+sequences and the C-ABI entry points -- compiled for x86-64 on a wave64 emulator (tests/host_kernel/wave_emu.h: one fibre per
+lane, cross-lane operations and barriers with the hardware's EXEC semantics) and held to the SAME checks and bounds as the
+MI355X runs of tests/test_gpu_parity.py: the reference's goldens, the oracle on seeded scenes, variant-against-variant
+identities, degenerate faces.  What this cannot see is timing and the hardware's own transcendental / reciprocal rounding
+(expf and 1/x are the host's here); what it does see is every line of control flow, indexing, culling and reduction logic of
+the kernels -- on every CPU run, and for as many fuzzed scenes as one cares to throw at it (tools/fuzz_host_raster.py)."""
+import math
+
+import numpy as np
+import pytest
+
+import host_raster as HR
+from conftest import load_golden
+from helpers import assert_close_frac, scene
+
+pytestmark = pytest.mark.skipif(not HR.available(), reason="clang++ of the ROCm toolchain not present")
+
+RASTER = ["raster_softmax_ts36.npz", "raster_softmax_ts1.npz", "raster_hard_ts1.npz", "raster_hard_ts4.npz"]
+CFG = dict(near=1., far=100., eps=1e-3, sigma_val=1e-5, dist_eps_log=float(math.log(1e10 - 1.)), gamma_val=1e-4, double_side=True)
+
+
+@pytest.fixture(scope="module")
+def L():
+    return HR.lib(HR.build())
+
+
+def _golden_cfg(g):
+    return dict(near=float(g["near"]), far=float(g["far"]), eps=float(g["eps"]), sigma_val=float(g["sigma_val"]),
+                dist_eps_log=float(g["dist_eps_log"]), gamma_val=float(g["gamma_val"]), func_id_rgb=int(g["func_id_rgb"]),
+                double_side=bool(g["double_side"]))
+
+
+@pytest.mark.parametrize("name", RASTER)
+def test_goldens_from_the_reference(L, name):
+    """tests/test_gpu_parity.py::test_raster_cabi_vs_reference_golden, same bounds, on the emulated library."""
+    g = load_golden(name)
+    cfg = _golden_cfg(g)
+    o = HR.forward(g["faces"], g["textures"], int(g["image_size"]), background=g["background"], L=L, **cfg)
+    np.testing.assert_array_equal(o["faces_info"], g["faces_info"])
+    assert_close_frac(o["soft_colors"], g["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="host soft_colors")
+    if cfg["func_id_rgb"] == 1:
+        assert_close_frac(o["aggrs_info"], g["aggrs_info"], atol=0, rtol=3e-6, frac=1.0, name="host aggrs")
+        scale = np.abs(g["p2f_sum"]).max()
+        assert_close_frac(o["p2f_sum"], g["p2f_sum"], atol=4e-6 * scale, rtol=1e-5, frac=1.0, name="host p2f_sum")
+        assert_close_frac(o["p2f_info"], g["p2f_info"], atol=4e-6 * scale, rtol=1e-5, frac=1.0, name="host p2f_info")
+    else:
+        np.testing.assert_array_equal(o["aggrs_info"], g["aggrs_info"])
+    gf, gt = HR.backward(g["faces"], g["textures"], o["soft_colors"], o["aggrs_info"], g["grad_soft_colors"], int(g["image_size"]),
+                         L=L, **cfg)
+    sf, st = np.abs(g["grad_faces"]).max(), max(np.abs(g["grad_textures"]).max(), 1e-12)
+    assert_close_frac(gf, g["grad_faces"], atol=1.5e-5 * sf, rtol=1e-4, frac=1.0, name="host grad_faces")
+    assert_close_frac(gt, g["grad_textures"], atol=3e-6 * st, rtol=1e-4, frac=1.0, name="host grad_textures")
+    # the pixel-major backward (tile-binned, wave-reduced atomics) on the same state
+    L.umr_debug_set(b"bwd_pixel_major", 1)
+    try:
+        gf2, gt2 = HR.backward(g["faces"], g["textures"], o["soft_colors"], o["aggrs_info"], g["grad_soft_colors"],
+                               int(g["image_size"]), L=L, **cfg)
+    finally:
+        L.umr_debug_set(b"bwd_pixel_major", 0)
+    assert_close_frac(gf2, g["grad_faces"], atol=1.5e-5 * sf, rtol=1e-4, frac=1.0, name="host pixel-major grad_faces")
+    assert_close_frac(gt2, g["grad_textures"], atol=3e-6 * st, rtol=1e-4, frac=1.0, name="host pixel-major grad_textures")
+
+
+def _mode_cases():
+    return [str(c) for c in load_golden("raster_modes.npz")["cases"]]
+
+
+@pytest.mark.parametrize("case", _mode_cases())
+def test_other_mode_ids_vs_reference_golden(L, case):
+    """The general-mode kernels (raster_general.h): hard / barycentric distance, hard / sum alpha, vertex textures."""
+    g = load_golden("raster_modes.npz")
+    modes = [int(v) for v in g[case + "/modes"]]     # (dist, alpha, rgb, texture type)
+    cfg = dict(near=float(g["near"]), far=float(g["far"]), eps=float(g["eps"]), sigma_val=float(g[case + "/sigma_val"]),
+               dist_eps_log=float(g["dist_eps_log"]), gamma_val=float(g["gamma_val"]), func_id_rgb=modes[2],
+               double_side=bool(g["double_side"]), func_id_dist=modes[0], func_id_alpha=modes[1], tex_type=modes[3])
+    IS = int(g["image_size"])
+    o = HR.forward(g["faces"], g[case + "/textures"], IS, background=g["background"], L=L, **cfg)
+    assert_close_frac(o["soft_colors"], g[case + "/soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="host modes soft_colors")
+    if modes[2] == 0:
+        np.testing.assert_array_equal(o["aggrs_info"][:, 1], g[case + "/aggrs_info"][:, 1])
+    else:
+        assert_close_frac(o["aggrs_info"], g[case + "/aggrs_info"], atol=0, rtol=1e-5, frac=1.0, name="host modes aggrs")
+    gf, gt = HR.backward(g["faces"], g[case + "/textures"], o["soft_colors"], o["aggrs_info"], g["grad_soft_colors"], IS, L=L, **cfg)
+    rgf, rgt = g[case + "/grad_faces"], g[case + "/grad_textures"]
+    assert_close_frac(gf, rgf, atol=1e-5 * max(np.abs(rgf).max(), 1e-30), rtol=2e-4, frac=1.0, name="host modes grad_faces")
+    assert_close_frac(gt, rgt, atol=1e-5 * np.abs(rgt).max(), rtol=2e-4, frac=1.0, name="host modes grad_textures")
+
+
+def _scene_faces(n, subdiv, seed, scale=(0.6, 0.9)):
+    """Projected face vertices of the seeded icosphere scene (the oracle's projection: test infrastructure on both sides)."""
+    import torch
+    from oracle import torch_ref as TR
+    verts, faces, cams, gen = scene(n, subdiv, seed, scale)
+    proj = TR.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fv = TR.face_vertices(TR.look_at_ortho(proj), faces)
+    return fv.reshape(n, -1, 9).numpy().astype(np.float32), gen
+
+
+@pytest.mark.parametrize("IS,subdiv,TS", [(96, 2, 4), (100, 2, 1), (128, 3, 9)])
+def test_every_production_variant_vs_oracle(L, oracle_built, IS, subdiv, TS):
+    """One seeded scene through every kernel variant the training steps launch -- forward with / without p2f, with the
+    visibility planes, with the fused pool, background by value, silhouette only; backward full / vertex only / texel only
+    (cost-ordered start) / pooled gradient / silhouette (LDS slots) -- against the oracle and against each other.  IS = 96 and
+    100 are not powers of two (fp64 pixel centres; 100 is not a multiple of the 16-pixel block: ragged tiles)."""
+    import torch
+    from oracle import softras
+    faces, gen = _scene_faces(2, subdiv, seed=31 + IS)
+    F = faces.shape[1]
+    tex = torch.rand(2, F, TS, 3, generator=gen).numpy()
+    gsc = torch.randn(2, 4, IS, IS, generator=gen).numpy()
+    cfg = dict(CFG, func_id_rgb=1)
+    ref = softras.raster_forward(faces, tex, IS, background=(0.2, 0.4, 0.6), n_threads=4, **cfg)
+    rgf, rgt = softras.raster_backward(faces, tex, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], gsc, IS, n_threads=4, **cfg)
+    o = HR.forward(faces, tex, IS, background=(0.2, 0.4, 0.6), L=L, **cfg)
+    np.testing.assert_array_equal(o["faces_info"], ref["faces_info"])
+    assert_close_frac(o["soft_colors"], ref["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="host full soft_colors")
+    # saved soft-max state (sum, max): the same pair in all but isolated pixels, and everywhere the same TOTAL
+    # log(sum) + max / gamma -- a fragment at the very rim of the distance threshold (D ~ 1e-10: no visible weight) that the
+    # reference's rounding noise includes and exact geometry does not moves the running maximum, not the result
+    assert_close_frac(o["aggrs_info"], ref["aggrs_info"], atol=0, rtol=1e-5, frac=0.9999, name="host full aggrs")
+    tot = lambda a: np.log(a[:, 0].astype(np.float64)) + a[:, 1].astype(np.float64) / cfg["gamma_val"]
+    assert_close_frac(tot(o["aggrs_info"]), tot(ref["aggrs_info"]), atol=1e-2, frac=1.0, name="host full soft-max total (log)")
+    s = np.abs(ref["p2f_sum"]).max()
+    assert_close_frac(o["p2f_sum"], ref["p2f_sum"], atol=4e-6 * s, rtol=1e-5, frac=1.0, name="host full p2f_sum")
+    # forward variants: identical pixels
+    for kw in (dict(flags=HR.NO_P2F), dict(background_by_value=True), dict(visibility=True), dict(pooled=True),
+               dict(flags=HR.NO_P2F, pooled=True, visibility=True, background_by_value=True)):
+        if kw.get("pooled") and IS % 2:
+            continue
+        v = HR.forward(faces, tex, IS, background=(0.2, 0.4, 0.6), L=L, **cfg, **kw)
+        np.testing.assert_array_equal(v["soft_colors"], o["soft_colors"], err_msg=str(kw))
+        np.testing.assert_array_equal(v["aggrs_info"], o["aggrs_info"], err_msg=str(kw))
+        if kw.get("pooled"):
+            full = o["soft_colors"].reshape(2, 4, IS // 2, 2, IS // 2, 2)
+            np.testing.assert_allclose(v["pooled"], full.mean(axis=(3, 5)), rtol=0, atol=1e-6)
+        if kw.get("visibility"):
+            hard = HR.forward(faces, tex, IS, background=(0.2, 0.4, 0.6), L=L, **dict(cfg, func_id_rgb=0))
+            np.testing.assert_array_equal(v["visibility"], hard["aggrs_info"])
+            ids = HR.forward(faces, None, IS, flags=HR.FACE_ID_ONLY, L=L, **dict(cfg, func_id_rgb=0))
+            np.testing.assert_array_equal(ids["aggrs_info"], hard["aggrs_info"])
+    sil = HR.forward(faces, None, IS, flags=HR.ALPHA_ONLY, pooled=IS % 2 == 0, L=L, **cfg)
+    np.testing.assert_array_equal(sil["soft_colors"], o["soft_colors"][:, 3])
+    bins_off = None
+    L.umr_debug_set(b"superblock_bins", 0)
+    try:
+        bins_off = HR.forward(faces, tex, IS, background=(0.2, 0.4, 0.6), L=L, **cfg)
+    finally:
+        L.umr_debug_set(b"superblock_bins", 1)
+    np.testing.assert_array_equal(bins_off["soft_colors"], o["soft_colors"])
+    # backward variants
+    sf, st = np.abs(rgf).max(), np.abs(rgt).max()
+    gf, gt = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gsc, IS, L=L, **cfg)
+    assert_close_frac(gf, rgf, atol=1.5e-5 * sf, rtol=1e-4, frac=1.0, name="host bwd full gf")
+    assert_close_frac(gt, rgt, atol=3e-6 * st, rtol=1e-4, frac=1.0, name="host bwd full gt")
+    gf1, _ = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gsc, IS, need_gt=False, L=L, **cfg)
+    _, gt1 = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gsc, IS, need_gf=False, L=L, **cfg)   # k_face_order + state cull
+    assert_close_frac(gf1, gf, atol=1e-6 * sf, rtol=1e-5, frac=1.0, name="host bwd vertex-only vs full")
+    assert_close_frac(gt1, gt, atol=1e-6 * st, rtol=1e-5, frac=1.0, name="host bwd texel-only vs full")
+    L.umr_debug_set(b"face_order", 0)
+    try:
+        _, gt2 = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gsc, IS, need_gf=False, L=L, **cfg)
+    finally:
+        L.umr_debug_set(b"face_order", 1)
+    np.testing.assert_array_equal(gt2, gt1)       # the start order changes no result
+    if IS % 2 == 0:
+        gp = torch.randn(2, 4, IS // 2, IS // 2, generator=gen).numpy()
+        up = 0.25 * np.repeat(np.repeat(gp, 2, axis=2), 2, axis=3)
+        rgf_p, rgt_p = softras.raster_backward(faces, tex, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], up, IS, n_threads=4, **cfg)
+        for need in ((True, True), (False, True), (True, False)):
+            a, b = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, need_gf=need[0], need_gt=need[1],
+                               grad_flags=HR.BWD_GRAD_POOLED, L=L, **cfg)
+            if need[0]:
+                assert_close_frac(a, rgf_p, atol=1.5e-5 * np.abs(rgf_p).max(), rtol=1e-4, frac=1.0, name="host bwd pooled gf %s" % (need,))
+            if need[1]:
+                assert_close_frac(b, rgt_p, atol=3e-6 * np.abs(rgt_p).max(), rtol=1e-4, frac=1.0, name="host bwd pooled gt %s" % (need,))
+    # silhouette backward (k_raster_backward_fm_slots): the full backward with a zero rgb gradient
+    ga = gsc.copy()
+    ga[:, :3] = 0
+    rgf_a, _ = softras.raster_backward(faces, tex, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], ga, IS, n_threads=4, **cfg)
+    gfa, _ = HR.backward(faces, None, sil["soft_colors"], None, np.ascontiguousarray(ga[:, 3]), IS, need_gt=False,
+                         grad_flags=HR.BWD_ALPHA_ONLY, L=L, **cfg)
+    assert_close_frac(gfa, rgf_a, atol=1.5e-5 * np.abs(rgf_a).max(), rtol=1e-4, frac=1.0, name="host bwd silhouette gf")
+    if IS % 2 == 0:
+        gpa = torch.randn(2, IS // 2, IS // 2, generator=gen).numpy()
+        full = np.zeros((2, 4, IS, IS), np.float32)
+        full[:, 3] = 0.25 * np.repeat(np.repeat(gpa, 2, axis=1), 2, axis=2)
+        rgf_ap, _ = softras.raster_backward(faces, tex, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], full, IS, n_threads=4, **cfg)
+        gfap, _ = HR.backward(faces, None, sil["soft_colors"], None, gpa, IS, need_gt=False,
+                              grad_flags=HR.BWD_ALPHA_ONLY | HR.BWD_GRAD_POOLED, L=L, **cfg)
+        assert_close_frac(gfap, rgf_ap, atol=1.5e-5 * np.abs(rgf_ap).max(), rtol=1e-4, frac=1.0, name="host bwd silhouette pooled gf")
+
+
+def test_front_face_culling_hard_render_and_camera_groups(L, oracle_built):
+    """double_side = False (front faces only), the hard colour mode, and K views sharing one texture set (tex_group)."""
+    import torch
+    from oracle import softras
+    IS, K = 64, 2
+    faces, gen = _scene_faces(4, 2, seed=77)
+    F = faces.shape[1]
+    tex2 = torch.rand(2, F, 4, 3, generator=gen).numpy()
+    gsc = torch.randn(4, 4, IS, IS, generator=gen).numpy()
+    for rgb in (1, 0):
+        cfg = dict(CFG, func_id_rgb=rgb, double_side=False)
+        tex4 = np.repeat(tex2, K, axis=0)
+        ref = softras.raster_forward(faces, tex4, IS, n_threads=4, **cfg)
+        rgf, rgt = softras.raster_backward(faces, tex4, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], gsc, IS, n_threads=4, **cfg)
+        o = HR.forward(faces, tex4, IS, L=L, **cfg)
+        assert_close_frac(o["soft_colors"], ref["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="host one-sided rgb%d" % rgb)
+        grp = HR.forward(faces, tex2, IS, tex_group=K, L=L, **cfg)
+        np.testing.assert_array_equal(grp["soft_colors"], o["soft_colors"])
+        gf, gt = HR.backward(faces, tex4, o["soft_colors"], o["aggrs_info"], gsc, IS, L=L, **cfg)
+        assert_close_frac(gf, rgf, atol=1.5e-5 * np.abs(rgf).max(), rtol=1e-4, frac=1.0, name="host one-sided gf rgb%d" % rgb)
+        assert_close_frac(gt, rgt, atol=3e-6 * max(np.abs(rgt).max(), 1e-12), rtol=1e-4, frac=1.0, name="host one-sided gt rgb%d" % rgb)
+
+
+def test_argument_checks_of_the_entry_points(L):
+    """The refusals of umr_raster_forward / _backward (undefined mode ids, missing buffers, short workspace) -- host logic of the
+    same translation unit."""
+    g = load_golden("raster_softmax_ts1.npz")
+    cfg = _golden_cfg(g)
+    with pytest.raises(RuntimeError):
+        HR.forward(g["faces"], g["textures"], 64, L=L, **dict(cfg, func_id_dist=3))
+    with pytest.raises(RuntimeError):
+        HR.forward(g["faces"], g["textures"], 64, L=L, **dict(cfg, func_id_alpha=3))
+    with pytest.raises(RuntimeError):
+        HR.forward(g["faces"], g["textures"], 64, L=L, **dict(cfg, tex_type=1))           # vertex textures need TS = 3
+    with pytest.raises(RuntimeError):
+        HR.forward(g["faces"], g["textures"], 63, pooled=True, L=L, **cfg)                 # odd image + fused pool
+    with pytest.raises(RuntimeError):
+        HR.forward(g["faces"], g["textures"], 64, flags=HR.ALPHA_ONLY | HR.FACE_ID_ONLY, L=L, **cfg)
+    assert L.umr_raster_workspace_bytes(0, 10) == 0 and L.umr_raster_workspace_bytes(2, 80) > 2 * 80 * 256

@@ -21,7 +21,7 @@ tot_pairs=0; visits8=0; vq=0; sumq=0
 vq16=0; visits16=0  # wave owns 16x16 with 16 quadrants, 4 groups each own a 8x8's...? skip
 # variant B: wave owns 16x4 strip? variant C: 4 groups own 4 quadrants of 8x8 (fixed)
 # variant D: wave owns 16x16 block; group g owns quadrant rows: 4 quadrants each (sequential lists) -> visits = max over groups of sum of its 4 quadrant lists
-vD=0
+vD=0; vE=0
 for n in range(B):
     tiles = {}
     blocks = {}
@@ -62,8 +62,10 @@ for n in range(B):
             for q in ql:
                 g[g.index(min(g))]+=q
             vD+=max(g)
+            vE+=ql[0]+ql[4]+ql[8]+ql[12]   # variant E: 4 waves per block, each takes 4 quadrants of similar list length
 print("pairs/mesh", tot_pairs/B)
 print("8x8 visits/mesh", visits8/B, "eff", tot_pairs/(visits8*64))
 print("quadrant visits total/mesh", sumq/B, "-> /4 =", sumq/B/4, "eff", tot_pairs/(sumq*16))
 print("indep quadrants in 8x8 (max of 4)/mesh", vq/B, "eff", tot_pairs/(vq*64))
 print("16x16 block LPT over 4 groups /mesh", vD/B, "eff", tot_pairs/(vD*64))
+print("16x16 block, 4 waves, quadrants sorted by list length /mesh", vE/B, "eff", tot_pairs/(vE*64))

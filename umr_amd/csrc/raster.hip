@@ -48,6 +48,8 @@ int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping 
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
 int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts its waves in index order,
                                  // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
+float g_thin_face_h = THIN_FACE_H;   // umr_debug_set("thin_face_h_1e6", h * 1e6): faces with a height below h screen units evaluate
+                                     // inside pixels the reference's way (k_face_setup, bit 4 of the record's flags)
 bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
 
 // super-block edge: 64 pixels, or a sixteenth of the image rounded up to whole 16-pixel workgroup blocks when that is larger
@@ -68,7 +70,7 @@ void setup_bins(RasterArgs &A, void *workspace, int N, int F, int IS, hipStream_
     int *cnt = (int *)p, *lst = (int *)(p + ws_sbcount_bytes(N));
     superblock_geometry(IS, &A.sb_size, &A.sb_nx);
     A.sb_cap = sb_cap_for(F);
-    k_superblock_bin<<<dim3(A.sb_nx * A.sb_nx, N), 256, 0, st>>>(A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx, A.sb_cap);
+    UMR_LAUNCH(k_superblock_bin, dim3(A.sb_nx * A.sb_nx, N), 256, 0, st, A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx, A.sb_cap);
     A.sb_count = cnt; A.sb_list = lst;
 }
 
@@ -125,6 +127,7 @@ int umr_debug_set(const char *key, int value) {
     if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
     if (std::string(key) == "xcd_remap") { g_xcd_remap = value; return UMR_OK; }   // 0 off, 1 contiguous runs, 2 row-interleaved
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
+    if (std::string(key) == "thin_face_h_1e6") { g_thin_face_h = value < 0 ? THIN_FACE_H : 1e-6f * (float)value; return UMR_OK; }
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
     return UMR_ERR_ARG;
 }
@@ -214,8 +217,8 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     A.no_xcd_remap = g_xcd_remap == 1 ? 0 : (g_xcd_remap == 0 ? 1 : 2);
     const int total = N * F;
-    k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
-                                                      sqrtf(A.threshold), near_, far_);
+    UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
+                                                      sqrtf(A.threshold), near_, far_, nullptr, 0, g_thin_face_h);
     setup_bins(A, workspace, N, F, image_size, st);
     const int blocks = N * A.tiles_x * A.tiles_y;
     {
@@ -227,29 +230,29 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
                                 : (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
         // p2f accumulation and face culling are compile-time: as run-time flags they cost SGPRs in every variant
         if (general) {
-            k_raster_forward_general<<<blocks, BLK_THREADS, 0, st>>>(A);
+            UMR_LAUNCH(k_raster_forward_general, blocks, BLK_THREADS, 0, st, A);
         } else if (ids_only) {
-            if (double_side) k_raster_forward<3, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
-            else k_raster_forward<3, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+            if (double_side) UMR_LAUNCH((k_raster_forward<3, false, true>), blocks, BLK_THREADS, 0, st, A);
+            else UMR_LAUNCH((k_raster_forward<3, false, false>), blocks, BLK_THREADS, 0, st, A);
         } else if (alpha_only) {
-            k_raster_forward<2, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);   // alpha does not look at the side
+            UMR_LAUNCH((k_raster_forward<2, false, true>), blocks, BLK_THREADS, 0, st, A);   // alpha does not look at the side
         } else if (func_id_rgb == 0) {
-            if (double_side) k_raster_forward<0, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
-            else k_raster_forward<0, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+            if (double_side) UMR_LAUNCH((k_raster_forward<0, false, true>), blocks, BLK_THREADS, 0, st, A);
+            else UMR_LAUNCH((k_raster_forward<0, false, false>), blocks, BLK_THREADS, 0, st, A);
         } else if (visibility) {
             if (with_p2f) {
-                if (double_side) k_raster_forward<1, true, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
-                else k_raster_forward<1, true, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+                if (double_side) UMR_LAUNCH((k_raster_forward<1, true, true, true>), blocks, BLK_THREADS, 0, st, A);
+                else UMR_LAUNCH((k_raster_forward<1, true, false, true>), blocks, BLK_THREADS, 0, st, A);
             } else {
-                if (double_side) k_raster_forward<1, false, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
-                else k_raster_forward<1, false, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
+                if (double_side) UMR_LAUNCH((k_raster_forward<1, false, true, true>), blocks, BLK_THREADS, 0, st, A);
+                else UMR_LAUNCH((k_raster_forward<1, false, false, true>), blocks, BLK_THREADS, 0, st, A);
             }
         } else if (with_p2f) {
-            if (double_side) k_raster_forward<1, true, true><<<blocks, BLK_THREADS, 0, st>>>(A);
-            else k_raster_forward<1, true, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+            if (double_side) UMR_LAUNCH((k_raster_forward<1, true, true>), blocks, BLK_THREADS, 0, st, A);
+            else UMR_LAUNCH((k_raster_forward<1, true, false>), blocks, BLK_THREADS, 0, st, A);
         } else {
-            if (double_side) k_raster_forward<1, false, true><<<blocks, BLK_THREADS, 0, st>>>(A);
-            else k_raster_forward<1, false, false><<<blocks, BLK_THREADS, 0, st>>>(A);
+            if (double_side) UMR_LAUNCH((k_raster_forward<1, false, true>), blocks, BLK_THREADS, 0, st, A);
+            else UMR_LAUNCH((k_raster_forward<1, false, false>), blocks, BLK_THREADS, 0, st, A);
         }
     }
     return umr_launch_status();
@@ -310,14 +313,14 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
                          F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
     int *order = (int *)((char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F));
     unsigned short *cost = (unsigned short *)(order + (size_t)(N + 15) * F);
-    k_face_setup<<<(total + 63) / 64, 64, 0, st>>>(faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
-                                                   sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size);
+    UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
+                                                   sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size, g_thin_face_h);
     // light variants at small N: four runs of faces per XCD instead of one (fm_owned_face)
     A.fm_split = (face_major && N <= 16 && (alpha_only || !need_grad_faces) && F % 32 == 0) ? 4 : 1;
     if (ordered) {
         int G = std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / (F / 8)));
         if (g_face_order_group) G = std::min(G, g_face_order_group);
-        k_face_order<<<dim3(8, (N + G - 1) / G), ORDER_THREADS, 0, st>>>(cost, A.rec, soft_colors, order, N, F, image_size, G, order_mode, A.fm_split);
+        UMR_LAUNCH(k_face_order, dim3(8, (N + G - 1) / G), ORDER_THREADS, 0, st, cost, A.rec, soft_colors, order, N, F, image_size, G, order_mode, A.fm_split);
         A.order = order; A.order_group = G;
     }
     {
@@ -340,12 +343,12 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         ProfScope ps(st, alpha_only ? 3 : 1, (double)N * per_mesh);
         if (general) {
             setup_bins(A, workspace, N, F, image_size, st);
-            k_raster_backward_general<<<blocks, BLK_THREADS, 0, st>>>(A);
+            UMR_LAUNCH(k_raster_backward_general, blocks, BLK_THREADS, 0, st, A);
         } else if (alpha_only) launch_backward_fm<2>(A, st);
         else if (g_bwd_pixel_major || !lds_ok) {  // pixel-major variant (global atomics); kept for A/B and huge TS
             setup_bins(A, workspace, N, F, image_size, st);
-            if (func_id_rgb == 0) k_raster_backward<0><<<blocks, BLK_THREADS, 0, st>>>(A);
-            else k_raster_backward<1><<<blocks, BLK_THREADS, 0, st>>>(A);
+            if (func_id_rgb == 0) UMR_LAUNCH((k_raster_backward<0>), blocks, BLK_THREADS, 0, st, A);
+            else UMR_LAUNCH((k_raster_backward<1>), blocks, BLK_THREADS, 0, st, A);
         } else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);
         else launch_backward_fm<1>(A, st);
     }

@@ -256,21 +256,26 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
 // So horizontally adjacent lanes holding the same texel are first summed with DPP quad permutes (the partner's value
 // is read only when the partner is active at this point: bound_ctrl off -> `old`), and only the surviving lane of
 // each run issues the atomics.  Deterministic; only the summation order differs from lane-by-lane atomics.
+#ifdef UMR_HOST_SHIM   // tests/host_kernel/wave_emu.h: these DPP reads run under lane divergence (only the lanes that
+#define UMR_DPP_DIVERGENT emu_dpp_subset           // contribute to the face in this visit reach them)
+#else
+#define UMR_DPP_DIVERGENT __builtin_amdgcn_update_dpp
+#endif
 __device__ __forceinline__ float dpp_f(float old, float v, const int ctrl_sel) {
     // ctrl_sel: 0 -> quad_perm [1,0,3,2] (x^1), 1 -> quad_perm [2,3,0,1] (x^2), 2 -> row_shl:4, 3 -> row_shr:4
     const int o = __float_as_int(old), i = __float_as_int(v);
     int r;
-    if (ctrl_sel == 0) r = __builtin_amdgcn_update_dpp(o, i, 0xB1, 0xf, 0xf, false);
-    else if (ctrl_sel == 1) r = __builtin_amdgcn_update_dpp(o, i, 0x4E, 0xf, 0xf, false);
-    else if (ctrl_sel == 2) r = __builtin_amdgcn_update_dpp(o, i, 0x104, 0xf, 0xf, false);
-    else r = __builtin_amdgcn_update_dpp(o, i, 0x114, 0xf, 0xf, false);
+    if (ctrl_sel == 0) r = UMR_DPP_DIVERGENT(o, i, 0xB1, 0xf, 0xf, false);
+    else if (ctrl_sel == 1) r = UMR_DPP_DIVERGENT(o, i, 0x4E, 0xf, 0xf, false);
+    else if (ctrl_sel == 2) r = UMR_DPP_DIVERGENT(o, i, 0x104, 0xf, 0xf, false);
+    else r = UMR_DPP_DIVERGENT(o, i, 0x114, 0xf, 0xf, false);
     return __int_as_float(r);
 }
 __device__ __forceinline__ int dpp_i(int old, int v, const int ctrl_sel) {
-    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(old, v, 0xB1, 0xf, 0xf, false);
-    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(old, v, 0x4E, 0xf, 0xf, false);
-    if (ctrl_sel == 2) return __builtin_amdgcn_update_dpp(old, v, 0x104, 0xf, 0xf, false);
-    return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+    if (ctrl_sel == 0) return UMR_DPP_DIVERGENT(old, v, 0xB1, 0xf, 0xf, false);
+    if (ctrl_sel == 1) return UMR_DPP_DIVERGENT(old, v, 0x4E, 0xf, 0xf, false);
+    if (ctrl_sel == 2) return UMR_DPP_DIVERGENT(old, v, 0x104, 0xf, 0xf, false);
+    return UMR_DPP_DIVERGENT(old, v, 0x114, 0xf, 0xf, false);
 }
 __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a, float b, float c, int lane) {
 #if FM_TEXMERGE >= 1
@@ -312,11 +317,11 @@ template <int RGB, bool COMMON>
 void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
     const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
     const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
-    if (RGB == 2 && FM_SLOTS) k_raster_backward_fm_slots<2, true, false, COMMON><<<blocks, FM_WAVES * 64, 0, st>>>(A);
-    else if (RGB == 2) k_raster_backward_fm<2, true, false, COMMON><<<blocks, FM_WAVES * 64, 0, st>>>(A);
-    else if (A.need_gf && A.need_gt) k_raster_backward_fm<RGB, true, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
-    else if (A.need_gf) k_raster_backward_fm<RGB, true, false, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
-    else k_raster_backward_fm<RGB, false, true, COMMON><<<blocks, FM_WAVES * 64, lds, st>>>(A);
+    if (RGB == 2 && FM_SLOTS) UMR_LAUNCH((k_raster_backward_fm_slots<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
+    else if (RGB == 2) UMR_LAUNCH((k_raster_backward_fm<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
+    else if (A.need_gf && A.need_gt) UMR_LAUNCH((k_raster_backward_fm<RGB, true, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+    else if (A.need_gf) UMR_LAUNCH((k_raster_backward_fm<RGB, true, false, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+    else UMR_LAUNCH((k_raster_backward_fm<RGB, false, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
 }
 template <int RGB>
 void launch_backward_fm(const RasterArgs &A, hipStream_t st) {

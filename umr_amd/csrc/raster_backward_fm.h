@@ -17,7 +17,11 @@ template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>  // RGB 2 = silhouet
 #define BWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BWD_WPE, BWD_WPE)))
 #endif
 __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(const RasterArgs A) {
+#ifdef UMR_HOST_SHIM   // tests/host_kernel/wave_emu.h: the launch's dynamic LDS
+    float *s_tex = (float *)umr_host_dynamic_lds();
+#else
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
+#endif
 #if FM_BODY_SLOTS
     // sub-tile hand-out: the lane that owns a wanted candidate of the culling pass writes the sub-tile's origin (pixel-centre
     // coordinates and byte offsets into the full / pooled planes) into slot [its rank among the wanted]; visit v hands slot
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     // the scalar file is full, and every constant the allocator spills comes back as a v_readlane (VALU) per visit.
     // As VALU operands they are as cheap from a VGPR.  (#define FM_VCONST 0 keeps them scalar for A/B.)
 #ifndef FM_V
-#if FM_VCONST
+#if FM_VCONST && !defined(UMR_HOST_SHIM)
 #define FM_V(x) ({ float v_; asm volatile("v_mov_b32 %0, %1" : "=v"(v_) : "s"(x)); v_; })
 #else
 #define FM_V(x) (x)
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                                                      fastxy ? ndc_coord_fast(IS - 1 - pr0, IS, inv_is, true) : 0.f,
                                                      __int_as_float((int)o_pn), __int_as_float((int)o_gp));
                 }
+                UMR_WAVE_LDS_HANDOVER();
                 // the slot of visit v + 1 is read at the top of visit v: LDS operations of a wave complete in order, so a read
                 // issued behind this visit's texel atomics (ds_add_f32, ~12 cycles a lane) would stall the next visit on them
                 float4 sd_next = s_slot[wave][sub < nv ? sub : 0];
@@ -216,7 +221,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         // also carry the 9 vertex-gradient accumulators and the colour path (measured 4-6 % faster with
                         // the re-fetch there, 1-5 % slower for the texel-only and silhouette kernels)
                         const float *rp = A.rec + ((size_t)n * F + f) * REC;
+#ifndef UMR_HOST_SHIM
                         asm volatile("" : "+s"(rp));
+#endif
                         load_face(fc, rp);
                     }
                     if (mine < 0) continue;

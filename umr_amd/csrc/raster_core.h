@@ -10,6 +10,12 @@
 #define BLK_W 16   // measured on MI355X (N=128, F=1280, IS=512, soft-max forward): 16x16 1.55 ms, 32x8 / 16x8 1.64,
 #define BLK_H 16   // 32x16 1.81, 32x32 2.08, 8x8 2.28 -- 4 waves share one binning pass and still schedule finely
 #endif
+#ifndef THIN_FACE_H
+#define THIN_FACE_H 1.6e-2f     // screen units: default of k_face_setup's thin_h (umr_debug_set("thin_face_h_1e6", ..) overrides)
+#endif
+#ifndef TILE_CULL_NOISE
+#define TILE_CULL_NOISE 4e-6f   // screen units^2, see tile_may_hit
+#endif
 #define SB_SLOTS 256  // super-block slots per mesh in the workspace layout (<= 16 x 16 super-blocks of >= 64^2 pixels)
 #define SB_CAP 1024   // list capacity per slot (entries); a slot that more faces touch is scanned in full (superblock_list)
 #define BLK_WX (BLK_W / 8)                          // 8x8 wave tiles across / in the workgroup
@@ -74,7 +80,8 @@ struct RasterArgs {
 // ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
 __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
                              float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
-                             float near_, float far_, unsigned short *__restrict__ cost = nullptr, int IS = 0) {
+                             float near_, float far_, unsigned short *__restrict__ cost = nullptr, int IS = 0,
+                             float thin_h = 0.f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float *f = faces + (size_t)i * 9;
@@ -171,6 +178,15 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         // branch the reference's way (all three edge lines, smallest computed distance).  NaN den: flagged as well.
         if (!(fabsf(den) >= 1e-5f)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
     }
+    // ... and so does a THIN face (a height below thin_h screen units).  Inside a triangle the reference keeps the edge LINE with
+    // the smallest COMPUTED distance (:78-107); eval_pair picks the line by its true distance w_c^2 K_c first and evaluates
+    // only that one the reference's way.  The two agree unless two line distances tie within the rounding noise of the
+    // reference's formulation (~1e-5 .. 1e-4 screen units, growing as edges get shorter) -- a zone of that width around the
+    // bisectors, i.e. a fraction noise / height of a face's interior: 3e-5 of the inside pixels of a face of 0.05 units, 1 %
+    // at 0.01, a quarter at 1e-3 (measured on this source compiled for the host, tests/host_kernel), and there the soft
+    // fragment differs by up to 0.1 and the gradient goes to another pair of vertices.  Flagged faces take the reference's
+    // route whenever a lane is inside; the cost is theirs alone.
+    if (!(fminf(fminf(r[R_K0], r[R_K1]), r[R_K2]) >= thin_h * thin_h)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
 #pragma unroll
     for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
 }
@@ -225,7 +241,11 @@ struct FaceV : Face {   // + 15 VGPRs per lane, filled once per face by the face
     template <int I> __device__ __forceinline__ float inv() const { return vinv[I]; }
     template <int I> __device__ __forceinline__ float xy() const { return vxy[I]; }
     __device__ __forceinline__ void fill() {
+#ifdef UMR_HOST_SHIM   // tests/host_kernel: the same copies without the instruction
+#define UMR_VMOV(dst, src) dst = (src)
+#else
 #define UMR_VMOV(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
+#endif
         UMR_VMOV(vinv[0], g<R_INV + 0>()); UMR_VMOV(vinv[1], g<R_INV + 1>()); UMR_VMOV(vinv[2], g<R_INV + 2>());
         UMR_VMOV(vinv[3], g<R_INV + 3>()); UMR_VMOV(vinv[4], g<R_INV + 4>()); UMR_VMOV(vinv[5], g<R_INV + 5>());
         UMR_VMOV(vinv[6], g<R_INV + 6>()); UMR_VMOV(vinv[7], g<R_INV + 7>()); UMR_VMOV(vinv[8], g<R_INV + 8>());
@@ -358,7 +378,9 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
     const float dx = (t0 * fc.template xy<0>() + t1 * fc.template xy<2>()) + t2 * fc.template xy<4>();  // :95-96, :148-149
     const float dy = (t0 * fc.template xy<1>() + t1 * fc.template xy<3>()) + t2 * fc.template xy<5>();
     const float dis = dx * dx + dy * dy;
-    p.b0 = b0; p.b1 = b1; p.b2 = b2; p.dx = dx; p.dy = dy;
+    // the gradient's barycentrics are the reference's `t[k] + w[k]` (:640) with t[k] = b_k - w_k already rounded: for an
+    // ordinary face that is b_k to an ulp, for a degenerate one (|w| ~ 1e9) whatever survives the cancellation -- like there
+    p.b0 = t0 + w0; p.b1 = t1 + w1; p.b2 = t2 + w2; p.dx = dx; p.dy = dy;
     p.sign = inside ? 1.f : -1.f;
     // 1 / (1 + exp(-sign * dis / sigma))
     const float e = __expf((inside ? dis : -dis) * neg_inv_sigma);
@@ -404,8 +426,14 @@ __device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, c
     const float w0 = fmaf(i0.x, cx, fmaf(i0.y, cy, i0.z)) + (hx * fabsf(i0.x) + hy * fabsf(i0.y));
     const float w1 = fmaf(i0.w, cx, fmaf(i1.x, cy, i1.y)) + (hx * fabsf(i0.w) + hy * fabsf(i1.x));
     const float w2 = fmaf(i1.z, cx, fmaf(i1.w, cy, i2.x)) + (hx * fabsf(i1.z) + hy * fabsf(i1.w));
-    const bool out = w0 < -(thr * __frsqrt_rn(i2.y)) - 1e-3f || w1 < -(thr * __frsqrt_rn(i2.z)) - 1e-3f ||
-                     w2 < -(thr * __frsqrt_rn(i2.w)) - 1e-3f;
+    // The reference decides the threshold reject (:382) on ITS computed distance, whose rounding noise grows as the face gets
+    // thinner: measured on this source (tests/host_kernel), pixels up to 1.7e-6 / h beyond the threshold in exact geometry are
+    // still included for a face of height h (D ~ 1e-10: invisible in alpha, but such a fragment moves the running soft-max
+    // maximum and with it the p2f weights of the faces after it).  TILE_CULL_NOISE / h widens the band accordingly
+    // (0.015 px for a face of 0.07 units at IS = 512, a third of a pixel at 0.003 units).
+    const float r0 = __frsqrt_rn(i2.y), r1 = __frsqrt_rn(i2.z), r2 = __frsqrt_rn(i2.w);
+    const bool out = w0 < -((thr + TILE_CULL_NOISE * r0) * r0) - 1e-3f || w1 < -((thr + TILE_CULL_NOISE * r1) * r1) - 1e-3f ||
+                     w2 < -((thr + TILE_CULL_NOISE * r2) * r2) - 1e-3f;
     // A face one of whose heights is below ~3e-5 screen units (a sliver, a needle, a face seen edge-on) is not culled beyond
     // its bounding box: its barycentrics carry rounding noise of the size of this very test, and what the reference's
     // arithmetic makes of such a face (soft fragments up to 0.5 along its line) follows that noise, not the geometry.

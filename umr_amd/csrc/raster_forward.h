@@ -11,7 +11,9 @@ template <int RGB, bool P2F, bool TWO_SIDED, bool VIS = false>  // VIS (RGB == 1
 // Register budget for 7 waves per SIMD: the default allocation (106 SGPRs) admits 6; the kernels are VALU-issue bound
 // with every wave stalled ~50 % of its life, so the seventh wave pays (measured: 5 < 6 < 7 ~ 8 waves, -3..6 % time).
 // (the forward variants without p2f accumulators fit 8 waves and gain another 2-5 %; with p2f 8 is slower)
+#ifndef FWD_WPE_ATTR
 #define FWD_WPE_ATTR __attribute__((amdgpu_waves_per_eu(P2F ? 7 : 8, P2F ? 7 : 8)))
+#endif
 __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(const RasterArgs A) {
     __shared__ int s_list[LIST_CAP];
     __shared__ int s_wcnt[BLK_THREADS / 64];

@@ -8,6 +8,21 @@
 
 #define UMR_WAVE 64
 
+// Kernel launch, `kernel<<<grid, block, lds, stream>>>(args...)`, spelt as a macro: the tests' wave64 emulation build
+// (tests/host_kernel/wave_emu.h defines UMR_LAUNCH before this header is read) runs the very same launch sequences of the
+// entry points on the CPU.  A template kernel's name goes in parentheses.
+#ifndef UMR_LAUNCH
+#define UMR_LAUNCH(kernel, grid, block, lds, stream, ...) kernel<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__)
+#endif
+// Lanes of ONE wave handing data to each other through LDS without a barrier rely on the wave executing in lockstep (its LDS
+// operations complete in order).  The emulation build runs a wave's lanes one after the other between cross-lane operations
+// and needs such a point marked; on the device the marker is nothing.
+#ifdef UMR_HOST_SHIM
+#define UMR_WAVE_LDS_HANDOVER() umr_host_wave_fence()
+#else
+#define UMR_WAVE_LDS_HANDOVER() ((void)0)
+#endif
+
 static inline int umr_launch_status() { return hipGetLastError() == hipSuccess ? UMR_OK : UMR_ERR_LAUNCH; }
 
 // 64-lane butterfly sum; every lane ends with the total (ds_bpermute based, order fixed -> deterministic)
