@@ -73,7 +73,7 @@ static thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 extern "C" void emu_switch(void **save_sp, void *load_sp);
 asm(".text\n"
-    ".globl emu_switch\n"
+    ".weak emu_switch\n"            // one definition per translation unit of libumr_host.so; the linker keeps one
     ".type emu_switch,@function\n"
     "emu_switch:\n"
     "    pushq %rbp\n    pushq %rbx\n    pushq %r12\n    pushq %r13\n    pushq %r14\n    pushq %r15\n"

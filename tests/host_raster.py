@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SRC_DIR = os.path.join(HERE, "host_kernel")
-SO = os.path.join(SRC_DIR, "libraster_host.so")
+SO = os.path.join(SRC_DIR, "libumr_host.so")
+TUS = ["raster", "geometry", "losses", "perceptual", "edt", "atlas", "regs", "eval"]     # umr_amd/build.py SOURCES
 
 NO_P2F, ALPHA_ONLY, FACE_ID_ONLY = 1, 2, 4      # UMR_RASTER_* (include/umr_hip.h)
 BWD_GRAD_POOLED, BWD_ALPHA_ONLY = 1, 2          # UMR_BWD_*
@@ -23,14 +24,27 @@ def available():
 
 
 def build(extra_flags=(), out=SO):
+    """Every translation unit of libumr_hip.so (umr_amd/csrc/*.hip) compiled for x86-64 through host_kernel/host_tu.cpp and
+    linked into one library with the C ABI of include/umr_hip.h."""
+    from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(ROOT, "umr_amd", "csrc")
-    deps = [os.path.join(SRC_DIR, f) for f in ("raster_host.cpp", "wave_emu.h")] + \
-           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("raster") or f == "umr_common.h"] + \
-           [os.path.join(ROOT, "include", "umr_hip.h")]
-    if extra_flags or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call([CLANG, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-function",
-                               "-Wno-unknown-attributes", "-Wno-ignored-attributes", '-DUMR_SRC_HASH="host-emulation"'] +
-                              list(extra_flags) + [os.path.join(SRC_DIR, "raster_host.cpp"), "-o", out])
+    deps = [os.path.join(SRC_DIR, f) for f in ("host_tu.cpp", "wave_emu.h")] + \
+           [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "umr_hip.h")]
+    if not (extra_flags or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps)):
+        return out
+    objdir = out + ".objs"
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function", "-Wno-unknown-attributes",
+             "-Wno-ignored-attributes", '-DUMR_SRC_HASH="host-emulation"'] + list(extra_flags)
+
+    def one(tu):
+        obj = os.path.join(objdir, tu + ".o")
+        subprocess.check_call([CLANG] + flags + (["-DUMR_TU_STATS"] if tu == "raster" else []) +
+                              ['-DUMR_TU="../../umr_amd/csrc/%s.hip"' % tu, "-c", os.path.join(SRC_DIR, "host_tu.cpp"), "-o", obj])
+        return obj
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, TUS))
+    subprocess.check_call([CLANG, "-shared", "-o", out] + objs)
     return out
 
 
@@ -42,13 +56,59 @@ def lib(path=None):
     if path not in _LIB:
         from umr_amd._lib import SIGNATURES
         L = ctypes.CDLL(path)
-        for name in ("umr_raster_workspace_bytes", "umr_raster_forward", "umr_raster_forward_vis", "umr_raster_backward",
-                     "umr_debug_set", "umr_version", "umr_build_id"):
-            if name in SIGNATURES:
-                getattr(L, name).argtypes, getattr(L, name).restype = SIGNATURES[name]
+        L.umr_version.restype = ctypes.c_char_p
+        L.umr_build_id.restype = ctypes.c_char_p
+        for name, (argtypes, restype) in SIGNATURES.items():      # the product's own prototype table
+            getattr(L, name).argtypes, getattr(L, name).restype = argtypes, restype
         L.umr_host_emu_stats.argtypes = [ctypes.POINTER(ctypes.c_long)] * 3
         _LIB[path] = L
     return _LIB[path]
+
+
+class emulated_product:
+    """Context manager for TESTS: umr_amd's Python layer (functional.py, smr.py, loss_utils.py, train_step.py, ...) on HOST
+    tensors over the emulated library.  The product itself refuses host tensors and a missing libumr_hip.so (umr_amd/_lib.py:
+    no CPU path); for the duration of a test the accessors that enforce that are replaced and the raster operators get a
+    host kernel -- their own Python bodies, which then call into libumr_host.so.  Nothing under umr_amd/ knows about this."""
+    _ops_registered = False
+
+    def __enter__(self):
+        import sys
+        import torch
+        from umr_amd import _lib, ops
+        self._saved = (_lib._lib, _lib.ptr, _lib.stream_ptr, _lib.on_device, torch.cuda.synchronize)
+        orig_ptr = _lib.ptr
+        _lib._lib = lib()
+
+        def ptr(t):
+            if t is None:
+                return None
+            if t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("emulated_product: expected a contiguous host tensor")
+            return t.data_ptr()
+        _lib.ptr = ptr
+        _lib.on_device = lambda t: True
+        _lib.stream_ptr = lambda device=None: None
+        torch.cuda.synchronize = lambda *a, **k: None
+        self._by_name = []           # modules that did `from ._lib import ptr`
+        for name, mod in list(sys.modules.items()):
+            if name.startswith("umr_amd.") and getattr(mod, "ptr", None) is orig_ptr:
+                mod.ptr = ptr
+                self._by_name.append(mod)
+        self._orig_ptr = orig_ptr
+        if not emulated_product._ops_registered:
+            for op in (ops.soft_rasterize_op, ops.soft_rasterize_backward_op, ops.silhouette_op, ops.silhouette_backward_op):
+                op.register_kernel("cpu")(op._init_fn)
+            emulated_product._ops_registered = True
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        from umr_amd import _lib
+        _lib._lib, _lib.ptr, _lib.stream_ptr, _lib.on_device, torch.cuda.synchronize = self._saved
+        for mod in self._by_name:
+            mod.ptr = self._orig_ptr
+        return False
 
 
 def _p(a):

@@ -103,7 +103,8 @@ def test_directional_light_folded_into_projection_vs_oracle(oracle_built):
     ref = torch_ref.SoftRenderer(64, "softmax", n_threads=8)
     ri, _, _ = ref(vc, faces, cc, tc)
     (ri * gimg).sum().backward()
-    vg, cg, tg = (verts.to(DEV).requires_grad_(True), cams.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True))
+    vg, cg, tg = (verts.clone().to(DEV).requires_grad_(True), cams.clone().to(DEV).requires_grad_(True),
+                  tex.clone().to(DEV).requires_grad_(True))     # clones: .to() of a tensor already on DEV returns the tensor itself
     r = SoftRenderer(64, "softmax")
     assert r.light_intensity_directional == 0.5 and r.light_intensity_ambient == 0.8
     img, _, _ = r(vg, faces.to(DEV), cg, tg)
@@ -113,7 +114,7 @@ def test_directional_light_folded_into_projection_vs_oracle(oracle_built):
         ref_g = b.grad.numpy()
         assert_close_frac(t2n(a.grad), ref_g, atol=3e-5 * np.abs(ref_g).max(), rtol=1e-3, frac=1.0, name="lit_grad_" + name)
     # the light term really is in the vertex gradient: with the directional part off the gradient differs
-    v2 = verts.to(DEV).requires_grad_(True)
+    v2 = verts.clone().to(DEV).requires_grad_(True)
     r2 = SoftRenderer(64, "softmax")
     r2.light_intensity_directional = 0
     img2, _, _ = r2(v2, faces.to(DEV), cams.to(DEV), tex.to(DEV))

@@ -1,0 +1,100 @@
+"""CPU tests (no GPU): the `-m gpu` parity tests themselves -- tests/test_gpu_parity.py, test_gpu_round2.py, test_gpu_round3.py,
+test_gpu_zz_collapsed_edges.py, unmodified, with their MI355X bounds -- executed on HOST tensors over libumr_host.so: every
+translation unit of the product library (umr_amd/csrc/*.hip) compiled for x86-64 on the wave64 emulator of
+tests/host_kernel/wave_emu.h, driven by the product's own Python layer (functional.py, smr.py, loss_utils.py, train_step.py,
+eval_utils.py ...) through tests/host_raster.py::emulated_product.  So the reference's goldens, the oracle comparisons and the
+whole train_s1 / train_s2 steps check the kernels' SOURCE on every CPU run; the MI355X run of the same tests then adds what only
+the hardware can: its own exp / rcp rounding, real atomics and wave scheduling, and time.
+
+Left to the GPU box: timing, HIP-graph capture, RCCL, the reference's device code (oracle/ref_gpu), the torch operator
+registrations' opcheck, and the shapes too large for an emulator (config 4, bench shape; the longer identity tests are covered
+at smaller size by tests/test_raster_library_on_host.py)."""
+import importlib
+import inspect
+import pathlib
+
+import pytest
+
+import host_raster as HR
+
+pytestmark = pytest.mark.skipif(not HR.available(), reason="clang++ of the ROCm toolchain not present")
+
+GPU_TESTS = {
+    "test_gpu_parity": [
+        "test_raster_cabi_vs_reference_golden", "test_raster_flags_and_fused_pool", "test_raster_rejects_undefined_modes",
+        "test_smr_softrenderer_vs_reference_golden", "test_full_size_vs_oracle", "test_losses_vs_reference_goldens",
+        "test_projection_gradients_vs_torch_autograd", "test_empty_scene_and_offscreen_mesh", "test_train_s1_step_vs_oracle",
+        "test_backward_variants_agree", "test_face_major_backward_non_pow2_and_determinism", "test_train_s2_step_vs_oracle",
+        "test_dt_barrier_vs_scipy", "test_upsample2x_matches_torch", "test_eval_metrics_vs_reference_restatement",
+        "test_front_face_culling_and_depth_range_vs_oracle", "test_degenerate_faces_do_not_poison_the_image",
+        "test_visibility_only_kernel_matches_hard_render", "test_texture_atlas_and_textured_obj_vs_reference_golden",
+        "test_camera_hypothesis_groups_equal_explicit_repeats", "test_rotate_cam_y_kernel_vs_quaternion_product"],
+    "test_gpu_round2": [
+        "test_cos_sim_head_vs_reference_golden", "test_part_match_reductions_vs_reference_golden",
+        "test_directional_light_folded_into_projection_vs_oracle", "test_perceptual_texture_loss_vs_oracle",
+        "test_multi_texture_loss_perceptual_branch_vs_oracle", "test_train_s1_step_with_perceptual_term_and_epoch_gating",
+        "test_baseline_config1_shape_single_image"],
+    "test_gpu_round3": [
+        "test_small_regularisers_and_masked_l1_vs_reference_goldens", "test_rotate_cam_vs_reference_golden",
+        "test_keypoint_transfer_vs_reference_golden"],
+    "test_gpu_zz_collapsed_edges": ["test_collapsed_edges_stay_finite_and_follow_the_reference"],
+}
+
+
+def _cases():
+    out = []
+    for mod_name, names in GPU_TESTS.items():
+        mod = importlib.import_module(mod_name)
+        for name in names:
+            fn = getattr(mod, name)
+            combos = [{}]
+            for mark in [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]:
+                keys = [k.strip() for k in mark.args[0].split(",")]
+                new = []
+                for c in combos:
+                    for v in mark.args[1]:
+                        v = v.values if hasattr(v, "values") else v
+                        new.append(dict(c, **dict(zip(keys, v if len(keys) > 1 else (v,)))))
+                combos = new
+            for kw in combos:
+                tag = "-".join(str(v) for v in kw.values())
+                out.append(pytest.param(mod_name, name, kw, id="%s::%s%s" % (mod_name, name, "[%s]" % tag if tag else "")))
+    return out
+
+
+def test_the_product_still_refuses_host_tensors_outside_the_emulation():
+    """emulated_product is a test harness, not a CPU path of the product: outside it the Python layer raises on a host tensor.
+    (Runs before the module's emulation fixture is set up.)"""
+    import torch
+    from umr_amd import _lib, functional as UF
+    t = torch.zeros(2, 4, 3)
+    assert not _lib.on_device(t)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _lib.ptr(t)
+    with pytest.raises((RuntimeError, TypeError)):
+        UF.soft_rasterize(torch.zeros(1, 4, 3, 3), torch.zeros(1, 4, 1, 3), 16)
+
+
+@pytest.fixture(scope="module")
+def emulated():
+    HR.lib(HR.build())
+    with HR.emulated_product() as e:
+        yield e
+
+
+@pytest.mark.parametrize("mod_name,name,kw", _cases())
+def test_gpu_test_on_the_emulated_library(emulated, oracle_built, tmp_path, mod_name, name, kw):
+    mod = importlib.import_module(mod_name)
+    fn = getattr(mod, name)
+    params = inspect.signature(fn).parameters
+    kw = dict(kw)
+    if "oracle_built" in params:
+        kw["oracle_built"] = oracle_built
+    if "tmp_path" in params:
+        kw["tmp_path"] = pathlib.Path(tmp_path)
+    saved = mod.DEV
+    mod.DEV = "cpu"
+    try:
+        fn(**kw)
+    finally:
+        mod.DEV = saved

@@ -105,11 +105,16 @@ def build_id():
     return lib().umr_build_id().decode()
 
 
+def on_device(t):
+    """True for a tensor this library can take: a CUDA (ROCm) tensor.  Every entry of the Python layer checks through here."""
+    return t.is_cuda
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL).  Tensors must be CUDA (ROCm) and contiguous."""
     if t is None:
         return None
-    if not t.is_cuda:
+    if not on_device(t):
         raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % t.device)
     if not t.is_contiguous():
         raise RuntimeError("umr_amd: tensor must be contiguous")

@@ -91,9 +91,9 @@ int umr_texture_atlas(const float *textures, float *image, unsigned char *image_
     const int tile_w = W / res_out;
     if (image || image_u8) {
         const int n = H * W;
-        k_texture_atlas<<<(n + 255) / 256, 256, 0, s>>>(textures, image, image_u8, F, res_in, res_out, tile_w, H, eps);
+        UMR_LAUNCH(k_texture_atlas, (n + 255) / 256, 256, 0, s, textures, image, image_u8, F, res_in, res_out, tile_w, H, eps);
     }
-    if (uv) k_atlas_uv<<<(F + 255) / 256, 256, 0, s>>>(uv, F, res_out, tile_w, H);
+    if (uv) UMR_LAUNCH(k_atlas_uv, (F + 255) / 256, 256, 0, s, uv, F, res_out, tile_w, H);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 }

@@ -22,7 +22,11 @@ namespace {
 #define EDT_COLS 16
 #define EDT_BIG (2 * EDT_INF)
 __global__ void k_edt_columns(const float *__restrict__ mask, int *__restrict__ g, int H, int W, int nseg) {
+#ifdef UMR_HOST_SHIM   // tests/host_kernel/wave_emu.h: the launch's dynamic LDS
+    int *s_sum = (int *)umr_host_dynamic_lds();
+#else
     extern __shared__ int s_sum[];  // [4][nseg][EDT_COLS]: last fg, first fg, last bg, first bg
+#endif
     const int b = blockIdx.y, c = threadIdx.x % EDT_COLS, seg = threadIdx.x / EDT_COLS;
     const int x = blockIdx.x * EDT_COLS + c;
     const bool on = x < W;
@@ -73,7 +77,11 @@ __global__ void k_edt_columns(const float *__restrict__ mask, int *__restrict__ 
 // one block per image row; LDS holds the row's squared column distances for both transforms
 __global__ void k_edt_rows(const int *__restrict__ g, float *__restrict__ out, int *__restrict__ sq_out,
                            int *__restrict__ sq_in, int H, int W, float k, float inv_max) {
+#ifdef UMR_HOST_SHIM   // tests/host_kernel/wave_emu.h: the launch's dynamic LDS
+    int *s_g = (int *)umr_host_dynamic_lds();
+#else
     extern __shared__ int s_g[];  // [2][W]
+#endif
     const int b = blockIdx.y, y = blockIdx.x;
     const int *go = g + ((size_t)b * 2 * H + y) * W, *gi = go + (size_t)H * W;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
@@ -121,10 +129,10 @@ int umr_dt_barrier(const float *mask, float *out, int *sq_out, int *sq_in, int B
     hipStream_t st = (hipStream_t)stream;
     const int nseg = max(1, min(64, (H + 15) / 16));   // <= 16 rows per thread up to H = 1024
     dim3 g1((W + EDT_COLS - 1) / EDT_COLS, B);
-    k_edt_columns<<<g1, EDT_COLS * nseg, (size_t)4 * nseg * EDT_COLS * sizeof(int), st>>>(mask, (int *)workspace, H, W, nseg);
+    UMR_LAUNCH(k_edt_columns, g1, EDT_COLS * nseg, (size_t)4 * nseg * EDT_COLS * sizeof(int), st, mask, (int *)workspace, H, W, nseg);
     dim3 g2(H, B);
     const int threads = W >= 256 ? 256 : ((W + 63) / 64) * 64;
-    k_edt_rows<<<g2, threads, (size_t)2 * W * sizeof(int), st>>>((const int *)workspace, out, sq_out, sq_in, H, W, k,
+    UMR_LAUNCH(k_edt_rows, g2, threads, (size_t)2 * W * sizeof(int), st, (const int *)workspace, out, sq_out, sq_in, H, W, k,
                                                               1.f / (float)(H > W ? H : W));
     return umr_launch_status();
 }

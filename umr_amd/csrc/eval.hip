@@ -237,9 +237,9 @@ int umr_kp_flow_transfer(const float *kp_src, int kp_stride, const float *flow_s
     if (workspace_bytes < umr_kp_flow_workspace_bytes(pairs, K, F)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     float *score = (float *)workspace, *p2face = score + (size_t)pairs * K * F;
-    k_kp_face_scores<<<dim3((F + 127) / 128, pairs), 128, 0, st>>>(kp_src, kp_stride, flow_src, flow_tgt, patch, score, p2face, K, F, TT,
+    UMR_LAUNCH(k_kp_face_scores, dim3((F + 127) / 128, pairs), 128, 0, st, kp_src, kp_stride, flow_src, flow_tgt, patch, score, p2face, K, F, TT,
                                                                     image_size, sigma);
-    k_kp_pick<<<dim3(K, pairs), 256, 0, st>>>(score, p2face, face_idx, k2k, kp_gt, gt_stride, vis, counters, K, F,
+    UMR_LAUNCH(k_kp_pick, dim3(K, pairs), 256, 0, st, score, p2face, face_idx, k2k, kp_gt, gt_stride, vis, counters, K, F,
                                               (1.f + 2.f * padding_frac) / 2.f, thr_a, thr_b);
     return umr_launch_status();
 }
@@ -252,8 +252,8 @@ int umr_kp_cam_transfer(const float *kp_src, int kp_stride, const float *verts_s
     if (pairs <= 0 || K <= 0 || V <= 0 || image_size < 2 || kp_stride < 2) return UMR_ERR_ARG;
     if ((kp_gt != nullptr) != (counters != nullptr) || (kp_gt && (!vis || gt_stride < 2))) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    k_nearest_fg_pixel<<<dim3(V, pairs), 256, 0, st>>>(verts_tgt, mask_tgt, pixel_of_vertex, V, image_size);
-    k_kp_cam_pick<<<(pairs * K + 127) / 128, 128, 0, st>>>(kp_src, kp_stride, verts_src, pixel_of_vertex, vert_idx, k2k, kp_gt, gt_stride,
+    UMR_LAUNCH(k_nearest_fg_pixel, dim3(V, pairs), 256, 0, st, verts_tgt, mask_tgt, pixel_of_vertex, V, image_size);
+    UMR_LAUNCH(k_kp_cam_pick, (pairs * K + 127) / 128, 128, 0, st, kp_src, kp_stride, verts_src, pixel_of_vertex, vert_idx, k2k, kp_gt, gt_stride,
                                                            vis, counters, K, V, image_size, (1.f + 2.f * padding_frac) / 2.f, thr_a,
                                                            thr_b, pairs);
     return umr_launch_status();

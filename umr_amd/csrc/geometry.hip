@@ -267,7 +267,7 @@ int umr_project_faces_lit_forward(const float *verts, const float *cams, const i
     if (mesh_group < 1 || N % mesh_group) return UMR_ERR_ARG;
     if ((long long)N * F * 3 > 0x7fffffffLL) return UMR_ERR_ARG;
     const int total = N * F;
-    k_project_faces<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+    UMR_LAUNCH(k_project_faces, (total + 255) / 256, 256, 0, (hipStream_t)stream,
         verts, cams, faces_idx, face_pre, face_out, light_out, N, V, F, offset_z, eye_z, mesh_group,
         make_light(light_ambient, light_directional, light_color3, light_direction3));
     return umr_launch_status();
@@ -295,10 +295,10 @@ int umr_project_faces_lit_backward(const float *grad_face_out, const float *grad
     hipStream_t st = (hipStream_t)stream;
     if (!umr_zero_async(workspace, umr_project_workspace_bytes(N, V), st)) return UMR_ERR_LAUNCH;
     const int total = N * F;
-    k_scatter_face_grads<<<(total + 255) / 256, 256, 0, st>>>(grad_face_out, grad_face_pre, grad_light, face_out, faces_idx,
+    UMR_LAUNCH(k_scatter_face_grads, (total + 255) / 256, 256, 0, st, grad_face_out, grad_face_pre, grad_light, face_out, faces_idx,
                                                               (float *)workspace, N, V, F, mesh_group,
                                                               make_light(0.f, light_directional, light_color3, light_direction3));
-    k_project_backward<0><<<N, 256, 0, st>>>((const float *)workspace, verts, cams, grad_verts, grad_cams, V, mesh_group);
+    UMR_LAUNCH((k_project_backward<0>), N, 256, 0, st, (const float *)workspace, verts, cams, grad_verts, grad_cams, V, mesh_group);
     return umr_launch_status();
 }
 
@@ -316,7 +316,7 @@ int umr_project_points_forward(const float *verts, const float *cams, float *out
     if (!verts || !cams || !out || N <= 0 || V <= 0 || (long long)N * V > 0x7fffffffLL) return UMR_ERR_ARG;
     if (out_dim != 2 && out_dim != 3) return UMR_ERR_ARG;
     const int total = N * V;
-    k_project_points<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(verts, cams, out, N, V, out_dim, offset_z);
+    UMR_LAUNCH(k_project_points, (total + 255) / 256, 256, 0, (hipStream_t)stream, verts, cams, out, N, V, out_dim, offset_z);
     return umr_launch_status();
 }
 
@@ -324,9 +324,9 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
                                 float *grad_cams, int N, int V, int out_dim, void *stream) {
     if (!grad_out || !verts || !cams || !grad_cams || N <= 0 || V <= 0) return UMR_ERR_ARG;
     if (out_dim == 2)
-        k_project_backward<1><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V, 1);
+        UMR_LAUNCH((k_project_backward<1>), N, 256, 0, (hipStream_t)stream, grad_out, verts, cams, grad_verts, grad_cams, V, 1);
     else if (out_dim == 3)
-        k_project_backward<2><<<N, 256, 0, (hipStream_t)stream>>>(grad_out, verts, cams, grad_verts, grad_cams, V, 1);
+        UMR_LAUNCH((k_project_backward<2>), N, 256, 0, (hipStream_t)stream, grad_out, verts, cams, grad_verts, grad_cams, V, 1);
     else
         return UMR_ERR_ARG;
     return umr_launch_status();
@@ -334,13 +334,13 @@ int umr_project_points_backward(const float *grad_out, const float *verts, const
 
 int umr_rotate_cam_axis(const float *cam, const float *angle_deg, const float *axis3, float *out, int B, void *stream) {
     if (!cam || !angle_deg || !axis3 || !out || B <= 0) return UMR_ERR_ARG;
-    k_rotate_cam_axis<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(cam, angle_deg, axis3[0], axis3[1], axis3[2], out, B);
+    UMR_LAUNCH(k_rotate_cam_axis, (B + 63) / 64, 64, 0, (hipStream_t)stream, cam, angle_deg, axis3[0], axis3[1], axis3[2], out, B);
     return umr_launch_status();
 }
 
 int umr_rotate_cam_y(const float *cam, const float *angle_deg, float *out, int B, void *stream) {
     if (!cam || !angle_deg || !out || B <= 0) return UMR_ERR_ARG;
-    k_rotate_cam_y<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(cam, angle_deg, out, B);
+    UMR_LAUNCH(k_rotate_cam_y, (B + 63) / 64, 64, 0, (hipStream_t)stream, cam, angle_deg, out, B);
     return umr_launch_status();
 }
 

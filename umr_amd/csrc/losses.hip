@@ -364,8 +364,8 @@ int umr_neg_iou_forward(const float *predict, long predict_stride, const float *
     if (sums_bytes < (size_t)N * (size_t)iou_stride(P) * sizeof(float)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)iou_blocks(P), (unsigned)N);
-    k_iou_partial<<<grid, 256, 0, st>>>(predict, predict_stride, target, sums, P);
-    k_iou_finalize<<<(N + 63) / 64, 64, 0, st>>>(sums, loss, N, P);
+    UMR_LAUNCH(k_iou_partial, grid, 256, 0, st, predict, predict_stride, target, sums, P);
+    UMR_LAUNCH(k_iou_finalize, (N + 63) / 64, 64, 0, st, sums, loss, N, P);
     return umr_launch_status();
 }
 
@@ -374,7 +374,7 @@ int umr_neg_iou_backward(const float *predict, long predict_stride, const float 
                          void *stream) {
     if (!predict || !target || !sums || !grad_loss || !grad_predict || N <= 0 || P <= 0) return UMR_ERR_ARG;
     dim3 grid((unsigned)min((long)1024, (P + 255) / 256), (unsigned)N);
-    k_iou_backward<<<grid, 256, 0, (hipStream_t)stream>>>(predict, predict_stride, target, sums, grad_loss, grad_predict,
+    UMR_LAUNCH(k_iou_backward, grid, 256, 0, (hipStream_t)stream, predict, predict_stride, target, sums, grad_loss, grad_predict,
                                                          grad_stride, P);
     return umr_launch_status();
 }
@@ -386,11 +386,11 @@ int umr_chamfer_forward(const float *a, const float *b, float *dist1, float *dis
     hipStream_t st = (hipStream_t)stream;
     dim3 g1((n + 255) / 256, B), g2((m + 255) / 256, B);
     if (D == 2) {
-        k_chamfer_nn<2><<<g1, 256, 0, st>>>(a, b, dist1, idx1, n, m);
-        k_chamfer_nn<2><<<g2, 256, 0, st>>>(b, a, dist2, idx2, m, n);
+        UMR_LAUNCH((k_chamfer_nn<2>), g1, 256, 0, st, a, b, dist1, idx1, n, m);
+        UMR_LAUNCH((k_chamfer_nn<2>), g2, 256, 0, st, b, a, dist2, idx2, m, n);
     } else {
-        k_chamfer_nn<3><<<g1, 256, 0, st>>>(a, b, dist1, idx1, n, m);
-        k_chamfer_nn<3><<<g2, 256, 0, st>>>(b, a, dist2, idx2, m, n);
+        UMR_LAUNCH((k_chamfer_nn<3>), g1, 256, 0, st, a, b, dist1, idx1, n, m);
+        UMR_LAUNCH((k_chamfer_nn<3>), g2, 256, 0, st, b, a, dist2, idx2, m, n);
     }
     return umr_launch_status();
 }
@@ -406,11 +406,11 @@ int umr_chamfer_backward(const float *a, const float *b, const int *idx1, const 
     if (!umr_zero_async(grad_b, (size_t)B * m * D * sizeof(float), st)) return UMR_ERR_LAUNCH;
     dim3 ga((n + 255) / 256, B), gb((m + 255) / 256, B);
     if (D == 2) {
-        k_chamfer_bwd<2><<<ga, 256, 0, st>>>(a, b, idx1, g1, grad_a, grad_b, n, m);
-        k_chamfer_bwd<2><<<gb, 256, 0, st>>>(b, a, idx2, g2, grad_b, grad_a, m, n);
+        UMR_LAUNCH((k_chamfer_bwd<2>), ga, 256, 0, st, a, b, idx1, g1, grad_a, grad_b, n, m);
+        UMR_LAUNCH((k_chamfer_bwd<2>), gb, 256, 0, st, b, a, idx2, g2, grad_b, grad_a, m, n);
     } else {
-        k_chamfer_bwd<3><<<ga, 256, 0, st>>>(a, b, idx1, g1, grad_a, grad_b, n, m);
-        k_chamfer_bwd<3><<<gb, 256, 0, st>>>(b, a, idx2, g2, grad_b, grad_a, m, n);
+        UMR_LAUNCH((k_chamfer_bwd<3>), ga, 256, 0, st, a, b, idx1, g1, grad_a, grad_b, n, m);
+        UMR_LAUNCH((k_chamfer_bwd<3>), gb, 256, 0, st, b, a, idx2, g2, grad_b, grad_a, m, n);
     }
     return umr_launch_status();
 }
@@ -419,7 +419,7 @@ int umr_grid_sample_forward(const float *image, const float *grid, float *out, i
                             long P, void *stream) {
     if (!image || !grid || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0) return UMR_ERR_ARG;
     dim3 g((unsigned)((P + 255) / 256), (unsigned)B);
-    k_grid_sample_fwd<<<g, 256, 0, (hipStream_t)stream>>>(image, grid, out, C, H, W, P);
+    UMR_LAUNCH(k_grid_sample_fwd, g, 256, 0, (hipStream_t)stream, image, grid, out, C, H, W, P);
     return umr_launch_status();
 }
 
@@ -428,14 +428,14 @@ int umr_grid_sample_backward(const float *image, const float *grid, const float 
     if (!image || !grid || !grad_out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0) return UMR_ERR_ARG;
     if (!grad_grid && !grad_image) return UMR_OK;
     dim3 g((unsigned)((P + 255) / 256), (unsigned)B);
-    k_grid_sample_bwd<<<g, 256, 0, (hipStream_t)stream>>>(image, grid, grad_out, grad_grid, grad_image, C, H, W, P);
+    UMR_LAUNCH(k_grid_sample_bwd, g, 256, 0, (hipStream_t)stream, image, grid, grad_out, grad_grid, grad_image, C, H, W, P);
     return umr_launch_status();
 }
 
 int umr_laplacian_forward(const float *x, const int *nbr_off, const int *nbr_idx, float *lap, float *loss,
                           int B, int V, void *stream) {
     if (!x || !nbr_off || !nbr_idx || !lap || !loss || B <= 0 || V <= 0) return UMR_ERR_ARG;
-    k_laplacian_fwd<<<B, 256, 0, (hipStream_t)stream>>>(x, nbr_off, nbr_idx, lap, loss, V);
+    UMR_LAUNCH(k_laplacian_fwd, B, 256, 0, (hipStream_t)stream, x, nbr_off, nbr_idx, lap, loss, V);
     return umr_launch_status();
 }
 
@@ -443,7 +443,7 @@ int umr_laplacian_backward(const float *lap, const int *nbr_off, const int *nbr_
                            float *grad_x, int B, int V, void *stream) {
     if (!lap || !nbr_off || !nbr_idx || !grad_loss || !grad_x || B <= 0 || V <= 0) return UMR_ERR_ARG;
     dim3 g((V + 255) / 256, B);
-    k_laplacian_bwd<<<g, 256, 0, (hipStream_t)stream>>>(lap, nbr_off, nbr_idx, grad_loss, grad_x, V);
+    UMR_LAUNCH(k_laplacian_bwd, g, 256, 0, (hipStream_t)stream, lap, nbr_off, nbr_idx, grad_loss, grad_x, V);
     return umr_launch_status();
 }
 
@@ -452,7 +452,7 @@ int umr_flatten_forward(const float *x, const int *quads, float *loss, int B, in
     hipStream_t st = (hipStream_t)stream;
     if (!umr_zero_async(loss, (size_t)B * sizeof(float), st)) return UMR_ERR_LAUNCH;
     dim3 g(1, B);   // one block per mesh (grid-stride over the edges): a single add into loss[b] -> bit-reproducible
-    k_flatten<false><<<g, 256, 0, st>>>(x, quads, loss, nullptr, nullptr, V, E);
+    UMR_LAUNCH((k_flatten<false>), g, 256, 0, st, x, quads, loss, nullptr, nullptr, V, E);
     return umr_launch_status();
 }
 
@@ -460,14 +460,14 @@ int umr_flatten_backward(const float *x, const int *quads, const float *grad_los
                          int E, void *stream) {
     if (!x || !quads || !grad_loss || !grad_x || B <= 0 || V <= 0 || E <= 0) return UMR_ERR_ARG;
     dim3 g((E + 255) / 256, B);
-    k_flatten<true><<<g, 256, 0, (hipStream_t)stream>>>(x, quads, nullptr, grad_loss, grad_x, V, E);
+    UMR_LAUNCH((k_flatten<true>), g, 256, 0, (hipStream_t)stream, x, quads, nullptr, grad_loss, grad_x, V, E);
     return umr_launch_status();
 }
 
 int umr_visible_face_mask(const float *face_ids, float *mask, int B, long P, int F, void *stream) {
     if (!face_ids || !mask || B <= 0 || P <= 0 || F <= 0) return UMR_ERR_ARG;
     dim3 g((unsigned)min((long)512, (P + 255) / 256), (unsigned)B);
-    k_visible_mask<<<g, 256, 0, (hipStream_t)stream>>>(face_ids, mask, P, F);
+    UMR_LAUNCH(k_visible_mask, g, 256, 0, (hipStream_t)stream, face_ids, mask, P, F);
     return umr_launch_status();
 }
 
@@ -534,7 +534,7 @@ int umr_upsample2x_bilinear_forward(const float *in, float *out, long planes, in
     const unsigned per = 4u * H * W;
     for (long p0 = 0; p0 < planes; p0 += 65535) {          // grid.y limit
         const long np = planes - p0 < 65535 ? planes - p0 : 65535;
-        k_upsample2x_fwd<<<dim3((per + 255) / 256, (unsigned)np), 256, 0, (hipStream_t)stream>>>(
+        UMR_LAUNCH(k_upsample2x_fwd, dim3((per + 255) / 256, (unsigned)np), 256, 0, (hipStream_t)stream,
             in + (size_t)p0 * H * W, out + (size_t)p0 * per, H, W, pow2_shift(2 * W));
     }
     return umr_launch_status();
@@ -545,7 +545,7 @@ int umr_upsample2x_bilinear_backward(const float *grad_out, float *grad_in, long
     const unsigned per = (unsigned)H * W;
     for (long p0 = 0; p0 < planes; p0 += 65535) {
         const long np = planes - p0 < 65535 ? planes - p0 : 65535;
-        k_upsample2x_bwd<<<dim3((per + 255) / 256, (unsigned)np), 256, 0, (hipStream_t)stream>>>(
+        UMR_LAUNCH(k_upsample2x_bwd, dim3((per + 255) / 256, (unsigned)np), 256, 0, (hipStream_t)stream,
             grad_out + (size_t)p0 * 4 * per, grad_in + (size_t)p0 * per, H, W, pow2_shift(W));
     }
     return umr_launch_status();

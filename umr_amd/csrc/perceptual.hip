@@ -449,8 +449,8 @@ int umr_cos_sim_forward(int ntaps, const float *const *f0, const float *const *f
     int maxp = 0;
     for (int t = 0; t < ntaps; ++t) maxp = P[t] > maxp ? P[t] : maxp;
     if ((maxp + 63) / 64 > UMR_COS_CHUNKS) return UMR_ERR_ARG;     // feature maps of up to 64 * UMR_COS_CHUNKS pixels
-    k_cos_forward<<<dim3((maxp + 63) / 64, N, ntaps), 256, 0, st>>>(A, partial);
-    k_cos_finalize<<<(N + 63) / 64, 64, 0, st>>>(A, partial, val);
+    UMR_LAUNCH(k_cos_forward, dim3((maxp + 63) / 64, N, ntaps), 256, 0, st, A, partial);
+    UMR_LAUNCH(k_cos_finalize, (N + 63) / 64, 64, 0, st, A, partial, val);
     return umr_launch_status();
 }
 
@@ -474,7 +474,7 @@ int umr_cos_sim_backward(int ntaps, const float *const *f0, const float *const *
     A.bwd_start[0] = 0;
     for (int t = 0; t < ntaps; ++t)
         A.bwd_start[t + 1] = A.bwd_start[t] + ((P[t] + 63) / 64) * ((C[t] + COS_BWD_CH - 1) / COS_BWD_CH);
-    k_cos_backward<<<dim3(A.bwd_start[ntaps], N), 256, 0, (hipStream_t)stream>>>(A, grad_val);
+    UMR_LAUNCH(k_cos_backward, dim3(A.bwd_start[ntaps], N), 256, 0, (hipStream_t)stream, A, grad_val);
     return umr_launch_status();
 }
 
@@ -482,7 +482,7 @@ int umr_perceptual_prologue_forward(const float *img, const float *mask, float *
                                     const float *shift3, const float *scale3, void *stream) {
     if (!img || !mask || !out || !shift3 || !scale3 || B <= 0 || C <= 0 || C > 3 || HW <= 0 || HW > 0x7fffffffL || B > 65535)
         return UMR_ERR_ARG;
-    k_pp_forward<<<dim3((unsigned)((HW + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+    UMR_LAUNCH(k_pp_forward, dim3((unsigned)((HW + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream,
         img, mask, out, C, (unsigned)HW, make_float3(shift3[0], shift3[1], shift3[2]), make_float3(scale3[0], scale3[1], scale3[2]));
     return umr_launch_status();
 }
@@ -492,7 +492,7 @@ int umr_perceptual_prologue_backward(const float *grad_out, const float *img, co
     if (!grad_out || !img || !mask || !scale3 || B <= 0 || C <= 0 || C > 3 || HW <= 0 || HW > 0x7fffffffL || B > 65535)
         return UMR_ERR_ARG;
     if (!grad_img && !grad_mask) return UMR_OK;
-    k_pp_backward<<<dim3((unsigned)((HW + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+    UMR_LAUNCH(k_pp_backward, dim3((unsigned)((HW + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream,
         grad_out, img, mask, grad_img, grad_mask, C, (unsigned)HW, make_float3(scale3[0], scale3[1], scale3[2]));
     return umr_launch_status();
 }
@@ -527,10 +527,10 @@ int umr_part_match_forward(const float *render_a, const float *render_b, const f
                              workspace_bytes);
     if (rc != UMR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    k_part_pass1<<<dim3(A.chunks, B), 256, 0, st>>>(A);
-    k_part_stats<<<(B + 63) / 64, 64, 0, st>>>(A, l_lm);
-    k_part_pass2<<<dim3(A.chunks, B), 256, 0, st>>>(A);
-    k_part_sum2<<<(B + 63) / 64, 64, 0, st>>>(A, l_eqv);
+    UMR_LAUNCH(k_part_pass1, dim3(A.chunks, B), 256, 0, st, A);
+    UMR_LAUNCH(k_part_stats, (B + 63) / 64, 64, 0, st, A, l_lm);
+    UMR_LAUNCH(k_part_pass2, dim3(A.chunks, B), 256, 0, st, A);
+    UMR_LAUNCH(k_part_sum2, (B + 63) / 64, 64, 0, st, A, l_eqv);
     return umr_launch_status();
 }
 
@@ -544,7 +544,7 @@ int umr_part_match_backward(const float *render_a, const float *render_b, const 
                              (void *)workspace, workspace_bytes);
     if (rc != UMR_OK) return rc;
     A.g_eqv = grad_l_eqv; A.g_lm = grad_l_lm; A.ga = grad_render_a; A.gb = grad_render_b;
-    k_part_backward<<<dim3(A.chunks, B), 256, 0, (hipStream_t)stream>>>(A);
+    UMR_LAUNCH(k_part_backward, dim3(A.chunks, B), 256, 0, (hipStream_t)stream, A);
     return umr_launch_status();
 }
 

@@ -117,14 +117,14 @@ int umr_row_norm_mean_forward(const float *x, float *out, float *scratch, size_t
     const int nb = reg_blocks(rows);
     if (scratch_bytes < (size_t)nb * sizeof(float)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    k_reg_partial<0><<<nb, 256, 0, st>>>(x, scratch, rows, width, 0);
-    k_reg_finalize<<<1, 64, 0, st>>>(scratch, out, nb, 1.f / (float)rows);
+    UMR_LAUNCH((k_reg_partial<0>), nb, 256, 0, st, x, scratch, rows, width, 0);
+    UMR_LAUNCH(k_reg_finalize, 1, 64, 0, st, scratch, out, nb, 1.f / (float)rows);
     return umr_launch_status();
 }
 
 int umr_row_norm_mean_backward(const float *x, const float *grad_out, float *grad_x, long rows, int width, void *stream) {
     if (!x || !grad_out || !grad_x || rows <= 0 || width <= 0) return UMR_ERR_ARG;
-    k_reg_backward<0><<<(unsigned)((rows + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, grad_out, grad_x, rows, width, 0, 1.f / (float)rows);
+    UMR_LAUNCH((k_reg_backward<0>), (unsigned)((rows + 255) / 256), 256, 0, (hipStream_t)stream, x, grad_out, grad_x, rows, width, 0, 1.f / (float)rows);
     return umr_launch_status();
 }
 
@@ -133,14 +133,14 @@ int umr_abs_mean_forward(const float *x, float *out, float *scratch, size_t scra
     const int nb = reg_blocks(rows);
     if (scratch_bytes < (size_t)nb * sizeof(float)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    k_reg_partial<1><<<nb, 256, 0, st>>>(x, scratch, rows, width, column);
-    k_reg_finalize<<<1, 64, 0, st>>>(scratch, out, nb, 1.f / (float)rows);
+    UMR_LAUNCH((k_reg_partial<1>), nb, 256, 0, st, x, scratch, rows, width, column);
+    UMR_LAUNCH(k_reg_finalize, 1, 64, 0, st, scratch, out, nb, 1.f / (float)rows);
     return umr_launch_status();
 }
 
 int umr_abs_mean_backward(const float *x, const float *grad_out, float *grad_x, long rows, int width, int column, void *stream) {
     if (!x || !grad_out || !grad_x || rows <= 0 || width <= 0 || column < 0 || column >= width) return UMR_ERR_ARG;
-    k_reg_backward<1><<<(unsigned)((rows + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, grad_out, grad_x, rows, width, column,
+    UMR_LAUNCH((k_reg_backward<1>), (unsigned)((rows + 255) / 256), 256, 0, (hipStream_t)stream, x, grad_out, grad_x, rows, width, column,
                                                                                        1.f / (float)rows);
     return umr_launch_status();
 }
@@ -151,8 +151,8 @@ int umr_masked_l1_forward(const float *img_pred, const float *img_gt, const floa
     const int nb = reg_blocks((long)C * HW);
     if (scratch_bytes < (size_t)nb * B * sizeof(float)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    k_ml1_partial<<<dim3(nb, B), 256, 0, st>>>(img_pred, img_gt, mask_gt, mask_pred, scratch, C, HW);
-    k_ml1_finalize<<<(B + 63) / 64, 64, 0, st>>>(scratch, per_sample, B, nb, 1.f / ((float)C * (float)HW));
+    UMR_LAUNCH(k_ml1_partial, dim3(nb, B), 256, 0, st, img_pred, img_gt, mask_gt, mask_pred, scratch, C, HW);
+    UMR_LAUNCH(k_ml1_finalize, (B + 63) / 64, 64, 0, st, scratch, per_sample, B, nb, 1.f / ((float)C * (float)HW));
     return umr_launch_status();
 }
 
@@ -161,7 +161,7 @@ int umr_masked_l1_backward(const float *img_pred, const float *img_gt, const flo
                            void *stream) {
     if (!img_pred || !img_gt || !mask_gt || !mask_pred || !grad_per_sample || B <= 0 || C <= 0 || HW <= 0) return UMR_ERR_ARG;
     if (!grad_img_pred && !grad_mask_pred) return UMR_OK;
-    k_ml1_backward<<<dim3((unsigned)((HW + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(
+    UMR_LAUNCH(k_ml1_backward, dim3((unsigned)((HW + 255) / 256), B), 256, 0, (hipStream_t)stream,
         img_pred, img_gt, mask_gt, mask_pred, grad_per_sample, grad_img_pred, grad_mask_pred, C, HW, 1.f / ((float)C * (float)HW));
     return umr_launch_status();
 }

@@ -80,6 +80,14 @@ static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {   // 
     umr_k_zero<<<blocks, 256, 0, st>>>((unsigned *)p, words);
     return hipGetLastError() == hipSuccess;
 }
+#elif defined(UMR_HOST_EMU)   // tests/host_kernel/wave_emu.h: the emulation build zero-fills through the same kernel
+static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {
+    const size_t words = bytes / 4;
+    if (!words) return true;
+    const unsigned blocks = (unsigned)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048);
+    UMR_LAUNCH(umr_k_zero, blocks, 256, 0, st, (unsigned *)p, words);
+    return true;
+}
 #endif
 
 // ---- non-finite tripwire (debug builds only: -DUMR_TRAP=1, tools/debug/bench_trap.py) -----------------------------------

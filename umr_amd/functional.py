@@ -73,7 +73,7 @@ class SoftRasterizeFunction:
                                "aggr_func_alpha='prod', texture_type='surface')")
         if _FUNC_SAMPLE[texture_type] == 1 and textures.shape[2] != 3:
             raise RuntimeError("soft_rasterize: texture_type='vertex' needs textures [N,F,3,3]; got %s" % (tuple(textures.shape),))
-        if not face_vertices.is_cuda:
+        if not _lib.on_device(face_vertices):
             raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
         if want_visibility and modes != 1:
             raise RuntimeError("soft_rasterize: want_visibility needs aggr_func_rgb='softmax' with UMR's own modes")
@@ -93,7 +93,7 @@ class SilhouetteFunction:
     @staticmethod
     def apply(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
         from . import ops  # noqa: F401
-        if not face_vertices.is_cuda:
+        if not _lib.on_device(face_vertices):
             raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
         out, _ = torch.ops.umr.silhouette(face_vertices, int(image_size), float(near), float(far), bool(fill_back), float(eps),
                                           float(sigma_val), float(dist_eps), float(gamma_val), bool(pool))
@@ -127,7 +127,7 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
                    pool=False, need_p2f=True, want_visibility=False):
     """Same signature and return as soft_renderer.functional.soft_rasterize
     (functional/soft_rasterize.py:111-125): (soft_colors [N,4,IS,IS], p2f_info [N,F,2], aggrs_info)."""
-    if not face_vertices.is_cuda:
+    if not _lib.on_device(face_vertices):
         # the reference's guard (:117-118) is dead code; ours is real
         raise TypeError('Rasterize module supports only GPU (ROCm) tensors')
     return SoftRasterizeFunction.apply(face_vertices, textures, image_size, background_color, near, far,

@@ -59,7 +59,7 @@ def texture_atlas(textures, texture_res=16, want=("image", "u8", "uv")):
     """GPU atlas bake.  textures [F, R*R, 3] float32 on the GPU -> dict of device tensors:
     image [H,W,3] f32 (un-flipped, as create_texture_image_cuda returns it), u8 [H,W,3] uint8 (clipped, x255,
     rows reversed: the array save_obj.py:50-53 hands to imsave), uv [F,3,2] (vt coordinates)."""
-    if not (textures.is_cuda and textures.dtype == torch.float32 and textures.dim() == 3 and textures.shape[2] == 3):
+    if not (_lib.on_device(textures) and textures.dtype == torch.float32 and textures.dim() == 3 and textures.shape[2] == 3):
         raise RuntimeError("texture_atlas: textures must be a float32 [F, R*R, 3] GPU tensor")
     textures = textures.detach().contiguous()
     nf, r_in = textures.shape[0], int(round(textures.shape[1] ** 0.5))
