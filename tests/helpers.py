@@ -47,7 +47,10 @@ def _record(name, n, frac_ok, max_err, atol, rtol, need, max_outlier):
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "parity_measured.jsonl"), "a") as fh:
+        # runs of the same checks on the CPU emulation of the library (tests/test_gpu_suite_on_emulator.py,
+        # tests/test_raster_library_on_host.py) are kept apart from the MI355X measurements
+        emu = any(k in rec["test"] for k in ("on_emulator", "on_host"))
+        with open(os.path.join(d, "parity_measured_emulator.jsonl" if emu else "parity_measured.jsonl"), "a") as fh:
             fh.write(json.dumps(rec) + "\n")
     except OSError:
         pass
