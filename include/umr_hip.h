@@ -42,7 +42,13 @@ const char *umr_build_id(void);
  * forgets them. */
 int umr_profile_enable(int on);
 /* A/B switches for benchmarking kernel variants ("bwd_pixel_major": 1 selects the tile-binned
- * pixel-major backward with global atomics instead of the default face-major one). */
+ * pixel-major backward with global atomics instead of the default face-major one; "superblock_bins",
+ * "xcd_remap", "face_order", "face_order_group": see raster.hip), and one switch that trades time for
+ * exactness: "thin_face_h_1e6" = h * 1e6 -- faces with a height below h screen units evaluate inside pixels
+ * the reference's way, all three edge lines and the smallest COMPUTED distance (:78-107).  Default 16000
+ * (h = 0.016); 1000000000 = every face: the nearest-edge choice then never differs from the reference's
+ * (alpha bit-identical to the CPU restatement on fuzzed scenes) for +15..33 % kernel time; negative =
+ * back to the default. */
 int umr_debug_set(const char *key, int value);
 int umr_profile_collect(int which, double *total_ms, long *launches, double *total_bytes);
 

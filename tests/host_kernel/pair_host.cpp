@@ -201,7 +201,7 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
         for (int t = 0; t < ntiles; ++t) {
             const float cx = tiles[4 * t], cy = tiles[4 * t + 1], hx = tiles[4 * t + 2], hy = tiles[4 * t + 3];
             bool hit = !(cx - hx > bb.y || cx + hx < bb.x || cy - hy > bb.w || cy + hy < bb.z);   // the kernels' bbox test first
-            if (hit) hit = tile_may_hit(q[0], q[1], q[2], cx, cy, hx, hy, thr);
+            if (hit) hit = tile_may_hit(q[0], q[1], q[2], cx, cy, hx, hy, thr + rec[(size_t)i * REC + R_CULL]);   // as the kernels call it
             out[(size_t)i * ntiles + t] = hit ? 1 : 0;
         }
     }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                 if (hit) {  // one lane per candidate face: exact-ish tile/triangle test
                     const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_INV);
                     hit = tile_may_hit(q[0], q[1], q[2], 0.5f * (t.wxlo + t.wxhi), 0.5f * (t.wylo + t.wyhi),
-                                       0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr);
+                                       0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr + rec_n[(size_t)fcand * REC + R_CULL]);
                 }
             }
             unsigned long long m = __ballot(hit);

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const float4 i0 = make_float4(fc.template g<R_INV + 0>(), fc.template g<R_INV + 1>(), fc.template g<R_INV + 2>(), fc.template g<R_INV + 3>());
             const float4 i1 = make_float4(fc.template g<R_INV + 4>(), fc.template g<R_INV + 5>(), fc.template g<R_INV + 6>(), fc.template g<R_INV + 7>());
             const float4 i2 = make_float4(fc.template g<R_INV + 8>(), fc.template g<R_K0>(), fc.template g<R_K1>(), fc.template g<R_K2>());
+            const float thr_cull = A.thr + A.rec[((size_t)n * F + f) * REC + R_CULL];   // band of the cull: + the reference's noise
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
 #if FM_BODY_SLOTS
             // this lane's place inside a sub-tile, as the increments the slot's origin takes (exact: see the visit)
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     const float cxl = ndc_coord_fast(px0, IS, inv_is, pow2), cxh = ndc_coord_fast(px1, IS, inv_is, pow2);
                     const float cyh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), cyl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
                     want = tile_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), 0.5f * (cxh - cxl),
-                                        0.5f * (cyh - cyl), A.thr);
+                                        0.5f * (cyh - cyl), thr_cull);
 #if FM_STATE_CULL
                     // Exact sub-tile skips from the saved forward state, decided HERE by the one lane that owns the
                     // candidate (64 candidates per pass) instead of by a whole wave visit that finds its four sub-tiles dead:

@@ -14,7 +14,7 @@
 #define THIN_FACE_H 1.6e-2f     // screen units: default of k_face_setup's thin_h (umr_debug_set("thin_face_h_1e6", ..) overrides)
 #endif
 #ifndef TILE_CULL_NOISE
-#define TILE_CULL_NOISE 4e-6f   // screen units^2, see tile_may_hit
+#define TILE_CULL_NOISE 5e-6f   // constant of the per-face widening of the tile cull (k_face_setup -> R_CULL, tile_may_hit)
 #endif
 #define SB_SLOTS 256  // super-block slots per mesh in the workspace layout (<= 16 x 16 super-blocks of >= 64^2 pixels)
 #define SB_CAP 1024   // list capacity per slot (entries); a slot that more faces touch is scanned in full (superblock_list)
@@ -30,7 +30,8 @@ namespace {
 enum { R_XLO = 0, R_XHI = 1, R_YLO = 2, R_YHI = 3, R_X0 = 4, R_Y0 = 5, R_X1 = 6, R_Y1 = 7, R_X2 = 8, R_Y2 = 9,
        R_Z0 = 10, R_Z1 = 11, R_Z2 = 12, R_RZ0 = 13, R_RZ1 = 14, R_RZ2 = 15,
        R_INV = 16, R_K0 = 25, R_K1 = 26, R_K2 = 27, R_FLAGS = 28, R_FRONT = 29, R_OX = 30, R_OY = 31,
-       R_EDGE = 32 };
+       R_EDGE = 32,
+       R_CULL = R_EDGE + 6 };   // spare slot of edge block 0: how far beyond sqrt(threshold) the reference still includes pixels
 
 struct RasterArgs {
     const float4 *bbox;   // [N*F] (xlo, xhi, ylo, yhi) = bbox dilated by sqrt(threshold)
@@ -189,6 +190,24 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     if (!(fminf(fminf(r[R_K0], r[R_K1]), r[R_K2]) >= thin_h * thin_h)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
 #pragma unroll
     for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
+    // Widening of the tile cull (tile_may_hit).  Outside the triangle the reference computes the closest point through an edge
+    // parameter t = (w . a - a[v1]) / den whose operands are differences of O(1 + |p|^2) products (:82-84, :133-137): its
+    // rounding error, times |w| ~ threshold distance / height, divided by den = |edge|^2, times |edge| again for the point.  So
+    // pixels up to ~ c (1 + |p|^2) (1 + thr / h_min) / L_min BEYOND sqrt(threshold) in exact geometry still pass the reference's
+    // own reject (:382) with D ~ 1e-10 -- invisible in alpha, but such a fragment moves the running soft-max maximum (and with
+    // it the p2f weights of later faces) and, outside the silhouette where every weight is that small, colour and texel
+    // gradients by O(1).  c measured on this source compiled for the host (tools/r3/reference_noise.py cull): 1.8e-6 for faces on
+    // the screen, 4.8e-6 up to 2.5 screen half-widths out; 5e-6 here.  0.04 px for a BASELINE face at IS = 512 (h 0.07, L 0.08),
+    // a pixel for a sliver of 0.001 units; a degenerate face (h = 0 or L = 0) gets inf and is culled by its box alone.
+    float k_min = fminf(fminf(r[R_K0], r[R_K1]), r[R_K2]), l2_min = 3.0e38f, p2_max = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int a = (c + 1) % 3;
+        const float ex = px[a] - px[c], ey = py[a] - py[c];
+        l2_min = fminf(l2_min, ex * ex + ey * ey);
+        p2_max = fmaxf(p2_max, px[c] * px[c] + py[c] * py[c]);
+    }
+    r[R_CULL] = TILE_CULL_NOISE * (1.f + p2_max) * (1.f + thr / sqrtf(k_min)) / sqrtf(l2_min);
 }
 
 __device__ __forceinline__ float ndc_coord(int i, int IS) {  // (2i + 1 - IS) / IS, evaluated in double (:325-326)
@@ -426,14 +445,10 @@ __device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, c
     const float w0 = fmaf(i0.x, cx, fmaf(i0.y, cy, i0.z)) + (hx * fabsf(i0.x) + hy * fabsf(i0.y));
     const float w1 = fmaf(i0.w, cx, fmaf(i1.x, cy, i1.y)) + (hx * fabsf(i0.w) + hy * fabsf(i1.x));
     const float w2 = fmaf(i1.z, cx, fmaf(i1.w, cy, i2.x)) + (hx * fabsf(i1.z) + hy * fabsf(i1.w));
-    // The reference decides the threshold reject (:382) on ITS computed distance, whose rounding noise grows as the face gets
-    // thinner: measured on this source (tests/host_kernel), pixels up to 1.7e-6 / h beyond the threshold in exact geometry are
-    // still included for a face of height h (D ~ 1e-10: invisible in alpha, but such a fragment moves the running soft-max
-    // maximum and with it the p2f weights of the faces after it).  TILE_CULL_NOISE / h widens the band accordingly
-    // (0.015 px for a face of 0.07 units at IS = 512, a third of a pixel at 0.003 units).
-    const float r0 = __frsqrt_rn(i2.y), r1 = __frsqrt_rn(i2.z), r2 = __frsqrt_rn(i2.w);
-    const bool out = w0 < -((thr + TILE_CULL_NOISE * r0) * r0) - 1e-3f || w1 < -((thr + TILE_CULL_NOISE * r1) * r1) - 1e-3f ||
-                     w2 < -((thr + TILE_CULL_NOISE * r2) * r2) - 1e-3f;
+    // `thr` = sqrt(threshold) + the face's R_CULL: the reference decides the threshold reject (:382) on ITS computed distance, so
+    // the band has to be wider than the exact one by that distance's rounding noise (k_face_setup).
+    const bool out = w0 < -(thr * __frsqrt_rn(i2.y)) - 1e-3f || w1 < -(thr * __frsqrt_rn(i2.z)) - 1e-3f ||
+                     w2 < -(thr * __frsqrt_rn(i2.w)) - 1e-3f;
     // A face one of whose heights is below ~3e-5 screen units (a sliver, a needle, a face seen edge-on) is not culled beyond
     // its bounding box: its barycentrics carry rounding noise of the size of this very test, and what the reference's
     // arithmetic makes of such a face (soft fragments up to 0.5 along its line) follows that noise, not the geometry.
