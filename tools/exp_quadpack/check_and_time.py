@@ -33,26 +33,28 @@ def proto(L):
 def check():
     import host_raster as HR
     from test_raster_library_on_host import _scene_faces, CFG
-    so = "/tmp/libqp_host.so"
-    subprocess.check_call([HR.CLANG, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-function",
-                           "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-include", os.path.join(ROOT, "tests", "host_kernel", "wave_emu.h"),
-                           "-x", "c++", os.path.join(HERE, "qp_forward.hip"), "-o", so])
-    L = proto(ctypes.CDLL(so))
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
-    for IS, subdiv, n in ((64, 1, 2), (96, 2, 2), (100, 2, 1), (128, 3, 2), (256, 3, 1)):
-        faces, _ = _scene_faces(n, subdiv, seed=7 + IS)
-        ref = HR.forward(faces, None, IS, flags=HR.ALPHA_ONLY, pooled=IS % 2 == 0, **dict(CFG, func_id_rgb=1))
-        N, F = faces.shape[:2]
-        alpha = np.full((N, IS, IS), np.nan, np.float32)
-        pooled = np.full((N, IS // 2, IS // 2), np.nan, np.float32) if IS % 2 == 0 else None
-        wsb = L.umr_exp_qp_workspace_bytes(N, F)
-        ws = np.zeros(wsb + 64, np.uint8)
-        rc = L.umr_exp_sil_forward_qp(p(faces), p(alpha), p(pooled), N, F, IS, SCAL["near"], SCAL["far"], SCAL["sigma_val"], SCAL["dist_eps"],
-                                      p(ws), wsb, None)
-        assert rc == 0
-        same = np.array_equal(alpha, ref["soft_colors"]) and (pooled is None or np.array_equal(pooled, ref["pooled"]))
-        print("IS %d, %d faces x %d: alpha%s bit-identical to the product kernel: %s" % (IS, F, N, " and pooled" if pooled is not None else "", same))
-        assert same
+    for lds in (0, 1):
+        so = "/tmp/libqp_host_%d.so" % lds
+        subprocess.check_call([HR.CLANG, "-DQP_LDS_REC=%d" % lds, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unused-function", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-include",
+                               os.path.join(ROOT, "tests", "host_kernel", "wave_emu.h"), "-x", "c++", os.path.join(HERE, "qp_forward.hip"), "-o", so])
+        L = proto(ctypes.CDLL(so))
+        for IS, subdiv, n in ((64, 1, 2), (96, 2, 2), (100, 2, 1), (128, 3, 2), (256, 3, 1)):
+            faces, _ = _scene_faces(n, subdiv, seed=7 + IS)
+            ref = HR.forward(faces, None, IS, flags=HR.ALPHA_ONLY, pooled=IS % 2 == 0, **dict(CFG, func_id_rgb=1))
+            N, F = faces.shape[:2]
+            alpha = np.full((N, IS, IS), np.nan, np.float32)
+            pooled = np.full((N, IS // 2, IS // 2), np.nan, np.float32) if IS % 2 == 0 else None
+            wsb = L.umr_exp_qp_workspace_bytes(N, F)
+            ws = np.zeros(wsb + 64, np.uint8)
+            rc = L.umr_exp_sil_forward_qp(p(faces), p(alpha), p(pooled), N, F, IS, SCAL["near"], SCAL["far"], SCAL["sigma_val"], SCAL["dist_eps"],
+                                          p(ws), wsb, None)
+            assert rc == 0
+            same = np.array_equal(alpha, ref["soft_colors"]) and (pooled is None or np.array_equal(pooled, ref["pooled"]))
+            print("records from %s: IS %d, %d faces x %d: alpha%s bit-identical to the product kernel: %s"
+                  % ("LDS" if lds else "global memory", IS, F, N, " and pooled" if pooled is not None else "", same))
+            assert same
 
 
 def time_gpu():
@@ -61,10 +63,11 @@ def time_gpu():
     so = os.path.join(ROOT, "gpurun_out", "libqp.so")
     os.makedirs(os.path.dirname(so), exist_ok=True)
     out = {}
-    for wpe in (6, 7, 8):
+    VARIANTS = [(0, 6), (0, 8), (1, 5), (1, 6)]     # (records staged in LDS, waves per SIMD asked for)
+    for lds, wpe in VARIANTS:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-                               "-ffp-contract=off", "-fno-slp-vectorize", "-DQP_WPE=%d" % wpe, os.path.join(HERE, "qp_forward.hip"), "-o",
-                               so.replace(".so", "_%d.so" % wpe)])
+                               "-ffp-contract=off", "-fno-slp-vectorize", "-DQP_WPE=%d" % wpe, "-DQP_LDS_REC=%d" % lds,
+                               os.path.join(HERE, "qp_forward.hip"), "-o", so.replace(".so", "_%d_%d.so" % (lds, wpe))])
     from tests.helpers import scene
     from umr_amd import functional as UF
     dev = torch.device("cuda:0")
@@ -97,8 +100,8 @@ def time_gpu():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / iters
         rec = {"product_us": round(timed(run_product), 1)}
-        for wpe in (6, 7, 8):
-            Lx = proto(ctypes.CDLL(so.replace(".so", "_%d.so" % wpe)))
+        for lds, wpe in VARIANTS:
+            Lx = proto(ctypes.CDLL(so.replace(".so", "_%d_%d.so" % (lds, wpe))))
             a_x = torch.full((N, IS, IS), float("nan"), device=dev)
             p_x = torch.full((N, IS // 2, IS // 2), float("nan"), device=dev)
             wsx = torch.empty(Lx.umr_exp_qp_workspace_bytes(N, Fn), dtype=torch.uint8, device=dev)
@@ -108,8 +111,9 @@ def time_gpu():
                 assert rc == 0
             run_exp(); run_product()
             torch.cuda.synchronize()
-            rec["identical_wpe%d" % wpe] = bool(torch.equal(a_x, a_ref) and torch.equal(p_x, p_ref))
-            rec["quadpack_wpe%d_us" % wpe] = round(timed(run_exp), 1)
+            key = "quadpack_%s_wpe%d" % ("lds" if lds else "global", wpe)
+            rec[key + "_identical"] = bool(torch.equal(a_x, a_ref) and torch.equal(p_x, p_ref))
+            rec[key + "_us"] = round(timed(run_exp), 1)
         out[tag] = rec
         print(tag, json.dumps(rec), flush=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "quadpack.json"), "w"), indent=1)

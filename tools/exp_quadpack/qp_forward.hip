@@ -12,7 +12,14 @@
 // mesh on the bench scene (-20 %).  Silhouette variant only (k_raster_forward<2>'s job): alpha = 1 - prod(1 - D_f).
 #include "../../umr_amd/csrc/raster_core.h"
 
-#define QP_CAP 256      // faces per sub-chunk of the block list = capacity of a quadrant list
+#ifndef QP_LDS_REC
+#define QP_LDS_REC 0    // 1: the sub-chunk's face records are staged in LDS once per block and read from there per visit
+#endif                  //    (7 x ds_read_b128 instead of 7 x global_load_dwordx4 per lane and visit)
+#if QP_LDS_REC
+#define QP_CAP 128      // faces per sub-chunk of the block list = capacity of a quadrant list (LDS: 128 x 112 B of records)
+#else
+#define QP_CAP 256
+#endif
 
 namespace {
 
@@ -26,9 +33,11 @@ struct FaceL {   // per-lane copy of the record fields the silhouette path reads
     __device__ __forceinline__ bool ill_conditioned() const { return (__float_as_int(r[R_FLAGS]) & 16) != 0; }
 };
 
-__device__ __forceinline__ void load_face_lane(FaceL &fc, const float *rg) {
+__device__ __forceinline__ void load_face_lane(FaceL &fc, const float *rg, const float4 *staged = nullptr) {
     const float4 *q = (const float4 *)rg;
-    const float4 a = q[0], b = q[1], c = q[2], e = q[4], f = q[5], g = q[6], h = q[7];
+    float4 a, b, c, e, f, g, h;
+    if (staged) { a = staged[0]; b = staged[1]; c = staged[2]; e = staged[3]; f = staged[4]; g = staged[5]; h = staged[6]; }
+    else { a = q[0]; b = q[1]; c = q[2]; e = q[4]; f = q[5]; g = q[6]; h = q[7]; }
     fc.r[0] = a.x; fc.r[1] = a.y; fc.r[2] = a.z; fc.r[3] = a.w;
     fc.r[4] = b.x; fc.r[5] = b.y; fc.r[6] = b.z; fc.r[7] = b.w;
     fc.r[8] = c.x; fc.r[9] = c.y;
@@ -54,6 +63,9 @@ __global__ __launch_bounds__(BLK_THREADS) QP_ATTR void k_sil_forward_qp(const Ra
     __shared__ int q_list[16][QP_CAP];
     __shared__ int q_cnt[16];
     __shared__ int q_perm[16];
+#if QP_LDS_REC
+    __shared__ float4 s_rec[QP_CAP][7];
+#endif
     Tile t;
     tile_setup(t, A);
     const int F = A.F, IS = A.IS;
@@ -83,6 +95,12 @@ __global__ __launch_bounds__(BLK_THREADS) QP_ATTR void k_sil_forward_qp(const Ra
         for (int c0 = 0; c0 < count; c0 += QP_CAP) {
             const int c1 = min(count, c0 + QP_CAP);
             if (c0 > 0) __syncthreads();           // the previous sub-chunk's lists are still being walked
+#if QP_LDS_REC
+            for (int e = tid; e < (c1 - c0) * 7; e += BLK_THREADS) {      // stage the records of this sub-chunk's faces
+                const int fi = e / 7, part = e - fi * 7;
+                s_rec[fi][part] = ((const float4 *)(rec_n + (size_t)s_list[c0 + fi] * REC))[part < 3 ? part : part + 1];
+            }
+#endif
             // ---- per-quadrant lists of this sub-chunk, ascending ----
             int qn = 0;
             for (int b = c0; b < c1; b += 16) {
@@ -101,7 +119,11 @@ __global__ __launch_bounds__(BLK_THREADS) QP_ATTR void k_sil_forward_qp(const Ra
                 }
                 const unsigned long long m = __ballot(hit);
                 const unsigned m16 = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
+#if QP_LDS_REC
+                if (hit) q_list[grp][qn + __builtin_popcount(m16 & ((1u << j) - 1u))] = li - c0;     // index into s_rec
+#else
                 if (hit) q_list[grp][qn + __builtin_popcount(m16 & ((1u << j) - 1u))] = f;
+#endif
                 qn += __builtin_popcount(m16);
             }
             if (j == 0) q_cnt[grp] = qn;
@@ -133,7 +155,12 @@ __global__ __launch_bounds__(BLK_THREADS) QP_ATTR void k_sil_forward_qp(const Ra
                 const bool act = i < n_mine;
                 const int f = mylist[act ? i : 0];
                 FaceL fc;
+#if QP_LDS_REC
+                const int fi = act && n_mine > 0 ? f : 0;
+                load_face_lane(fc, rec_n + (size_t)s_list[c0 + fi] * REC, s_rec[fi]);
+#else
                 load_face_lane(fc, rec_n + (size_t)(act && n_mine > 0 ? f : 0) * REC);
+#endif
                 Pair p;
                 const bool live = eval_pair(p, fc, xp, yp, A.threshold, A.nis) & valid & act;
                 alpha *= live ? 1.f - p.frag : 1.f;
