@@ -43,12 +43,16 @@ const char *umr_build_id(void);
 int umr_profile_enable(int on);
 /* A/B switches for benchmarking kernel variants ("bwd_pixel_major": 1 selects the tile-binned
  * pixel-major backward with global atomics instead of the default face-major one; "superblock_bins",
- * "xcd_remap", "face_order", "face_order_group": see raster.hip), and one switch that trades time for
- * exactness: "thin_face_h_1e6" = h * 1e6 -- faces with a height below h screen units evaluate inside pixels
- * the reference's way, all three edge lines and the smallest COMPUTED distance (:78-107).  Default 16000
- * (h = 0.016); 1000000000 = every face: the nearest-edge choice then never differs from the reference's
- * (alpha bit-identical to the CPU restatement on fuzzed scenes) for +15..33 % kernel time; negative =
- * back to the default. */
+ * "xcd_remap", "face_order", "face_order_group": see raster.hip), and two switches that trade time for
+ * exactness.  Inside a triangle the reference keeps the edge line with the smallest COMPUTED
+ * distance (:78-107); the kernels pick it by its true distance unless the face is thin.
+ *   "exact_edges" (default 1): inside pixels whose SECOND nearest edge line is closer than sqrt(20 sigma) evaluate
+ *       all three lines the reference's way -- the nearest-edge choice then never differs from the reference's
+ *       (MI355X, BASELINE size: every one of 2.1 M colour values within 8e-7, every vertex-gradient value
+ *       within 6e-7 of the largest).  0 = pick by true distance everywhere but in thin faces: 8..15 % less
+ *       kernel time, for isolated pixels off by up to ~1e-4 in alpha and faces off by ~1 % in their gradient.
+ *   "thin_face_h_1e6" = h * 1e6: faces with a height below h screen units do so for every inside pixel.
+ *       Default 16000 (h = 0.016, +1..2 %); 1000000000 = every face (+15..33 %); negative = default. */
 int umr_debug_set(const char *key, int value);
 int umr_profile_collect(int which, double *total_ms, long *launches, double *total_bytes);
 

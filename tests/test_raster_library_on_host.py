@@ -231,3 +231,25 @@ def test_argument_checks_of_the_entry_points(L):
     with pytest.raises(RuntimeError):
         HR.forward(g["faces"], g["textures"], 64, flags=HR.ALPHA_ONLY | HR.FACE_ID_ONLY, L=L, **cfg)
     assert L.umr_raster_workspace_bytes(0, 10) == 0 and L.umr_raster_workspace_bytes(2, 80) > 2 * 80 * 256
+
+
+def test_default_build_takes_the_references_decisions_on_fuzzed_scenes(L, oracle_built):
+    """tools/fuzz_host_raster.py's six scene classes (spheres, dense three-pixel meshes, triangle soups, sub-pixel faces, needles,
+    degenerate faces), a few scenes each: with the default switches ("exact_edges" = 1, thin faces and the noise-widened cull,
+    DESIGN.md 4.1 / 4.4) the emulated kernels take every discrete decision as the reference does -- no pixel with a missing or
+    extra face, alpha within a few ulp of the oracle's (1e-6), no colour value off by 1e-4, every gradient (full, texel-only,
+    silhouette backward) within 1e-5 of the scene's largest.  (3 600 scenes of the same generator: profiles/r03_emulator_fuzz.json.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(HR.ROOT, "tools"))
+    import fuzz_host_raster as FZ
+    stats = {}
+    for i in range(24):
+        kind = ["sphere", "dense", "soup", "tiny", "needles", "degenerate"][i % 6]
+        bad, memb = FZ.run_one(np.random.default_rng([2024, i]), kind, 64, L, stats)
+        assert not bad and memb == 0, (i, kind, bad, memb)
+    for kind, rec in stats.items():
+        assert rec["nonfinite_host_only"] == 0 and rec["membership_pixels"] == 0, (kind, rec)
+        assert rec["alpha_err_max"] <= 1e-6, (kind, rec)
+        assert rec["rgb_err_gt_1e4"] == 0, (kind, rec)
+        assert max(rec["gf_err_max"], rec["gt_err_max"], rec["gfa_err_max"]) <= 1e-5, (kind, rec)

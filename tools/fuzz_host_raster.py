@@ -137,8 +137,10 @@ if __name__ == "__main__":
     ap.add_argument("--classes", default="sphere,dense,soup,tiny,needles,degenerate")
     ap.add_argument("--lib", default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--exact-edges", type=int, default=0, help="umr_debug_set(\"exact_edges\", v) before the run")
     a = ap.parse_args()
     L = HR.lib(a.lib or HR.build())
+    L.umr_debug_set(b"exact_edges", a.exact_edges)
     stats = {}
     t0 = time.time()
     kinds = a.classes.split(",")

@@ -39,6 +39,9 @@ if os.environ.get("UMR_FOG"):
 if os.environ.get("UMR_THIN"):     # thin-face threshold of k_face_setup in 1e-6 screen units (0 = off, 1000000000 = every face)
     _lib.debug_set("thin_face_h_1e6", int(os.environ["UMR_THIN"]))
     tag += " [thin_face_h %se-6]" % os.environ["UMR_THIN"]
+if os.environ.get("UMR_EXACT"):    # per-lane doubt criterion of eval_pair (umr_debug_set("exact_edges"))
+    _lib.debug_set("exact_edges", int(os.environ["UMR_EXACT"]))
+    tag += " [exact_edges %s]" % os.environ["UMR_EXACT"]
 out = {"tag": tag}
 out["n16_ts36_texonly_pooled"] = timed(bench, 16, 3, 512, 36, pool=True, need_p2f=False, need_gf=False, iters=20)
 out["n16_ts36_p2f"] = timed(bench, 16, 3, 512, 36, iters=20)

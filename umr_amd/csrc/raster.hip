@@ -50,6 +50,9 @@ int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every fa
                                  // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
 float g_thin_face_h = THIN_FACE_H;   // umr_debug_set("thin_face_h_1e6", h * 1e6): faces with a height below h screen units evaluate
                                      // inside pixels the reference's way (k_face_setup, bit 4 of the record's flags)
+bool g_exact_edges = true;           // umr_debug_set("exact_edges", 0 | 1): eval_pair's amb_thr = 20 sigma (see there).  On by default:
+                                     // the nearest-edge choice inside a face is then the reference's in every pixel; 0 trades that
+                                     // for 8-15 % of the raster kernels' time
 bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
 
 // super-block edge: 64 pixels, or a sixteenth of the image rounded up to whole 16-pixel workgroup blocks when that is larger
@@ -127,6 +130,7 @@ int umr_debug_set(const char *key, int value) {
     if (std::string(key) == "superblock_bins") { g_superblocks = value != 0; return UMR_OK; }
     if (std::string(key) == "xcd_remap") { g_xcd_remap = value; return UMR_OK; }   // 0 off, 1 contiguous runs, 2 row-interleaved
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
+    if (std::string(key) == "exact_edges") { g_exact_edges = value != 0; return UMR_OK; }
     if (std::string(key) == "thin_face_h_1e6") { g_thin_face_h = value < 0 ? THIN_FACE_H : 1e-6f * (float)value; return UMR_OK; }
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
     return UMR_ERR_ARG;
@@ -210,6 +214,7 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;  // :332
     A.gamma = gamma_val; A.double_side = double_side; A.with_p2f = with_p2f; A.tex_group = tex_group;
+    A.amb_thr = g_exact_edges ? 20.f * sigma_val : 0.f;
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;
@@ -296,6 +301,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     A.thr = sqrtf(A.threshold); A.nis = -1.f / sigma_val; A.r_range = 1.f / (far_ - near_); A.inv_gamma = 1.f / gamma_val;
     A.grad_pooled = grad_is_pooled; A.need_gf = need_grad_faces; A.need_gt = need_grad_textures;
     A.tex_group = tex_group;
+    A.amb_thr = g_exact_edges ? 20.f * sigma_val : 0.f;
     A.dist_mode = func_id_dist; A.alpha_mode = func_id_alpha; A.rgb_mode = func_id_rgb; A.tex_vertex = texture_sample_type;
     A.tiles_x = (image_size + BLK_W - 1) / BLK_W;
     A.tiles_y = (image_size + BLK_H - 1) / BLK_H;

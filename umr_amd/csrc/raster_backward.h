@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                 int tix = 0;
                 bool contrib = false;
                 Pair p;
-                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis)) {
+                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr)) {
                     float c_xy = g3 * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;
                     }
                     Pair p;
-                    if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis)) continue;
+                    if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis, A.amb_thr)) continue;
                     if (RGB == 2) {  // silhouette: d alpha only (:584, :632-642); soft_colors/grad are [N,IS,IS] | [N,H,H]
                         if (!fc.depth_in_range()) {
                             float u0, u1, u2;

@@ -68,6 +68,7 @@ struct RasterArgs {
     int order_group;
     int fm_split;      // runs of faces per XCD and mesh in the face-major backward (fm_owned_face); 0 / 1 = one
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
+    float amb_thr;    // eval_pair: 0, or 20 sigma with umr_debug_set("exact_edges", 1)
     // read by the general-mode kernels only (raster_general.h): the reference's func_id_dist / func_id_alpha /
     // func_id_rgb and texture_sample_type
     int dist_mode, alpha_mode, rgb_mode, tex_vertex;
@@ -297,11 +298,19 @@ __device__ __forceinline__ float div_r(float a, float b, float r) {
     return fmaf(fmaf(-b, q, a), r, q);
 }
 
+__device__ __forceinline__ float fmed3_(float a, float b, float c) {   // v_med3_f32
+#ifdef UMR_HOST_SHIM
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#else
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#endif
+}
+
 // bbox reject (:355), barycentric (:25-29), euclidean distance (:63-152), threshold reject (:382),
 // sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
 template <class FaceT>
 __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, float yp, float threshold,
-                                          float neg_inv_sigma) {
+                                          float neg_inv_sigma, float amb_thr = 0.f) {
     // Written branch-free (predicates + selects): per-lane divergence would otherwise cost ~80 scalar
     // exec-mask instructions per face visit.  Dead lanes compute garbage that the returned predicate masks.
     const bool inb = !((xp > fc.template g<R_XHI>()) | (xp < fc.template g<R_XLO>()) | (yp > fc.template g<R_YHI>()) | (yp < fc.template g<R_YLO>()));
@@ -363,9 +372,16 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
     // beforehand by its true line distance (above) is equivalent only while the three `den` are well conditioned; faces
     // flagged by k_face_setup (wave-uniform) take the reference's own route here.  With no usable edge the reference ends
     // with dis_x = dis_y = 0 (:72-73,:105-106).
+    // amb_thr > 0 (umr_debug_set("exact_edges", 1); RasterArgs::amb_thr = 20 sigma): ANY face takes this route for the lanes
+    // where the choice of the edge can matter and can be in doubt -- inside, with the SECOND nearest edge line closer than
+    // sqrt(20 sigma).  Elsewhere the fast pick is provably the reference's result: beyond 17.4 sigma the fragment is 1.0f
+    // whichever line is taken (e^-17.4 < 2^-25; its gradient factor 1 - D is then 0.0f), and a nearest line inside 17.4 sigma with
+    // the next one beyond 20 sigma leaves a gap of 2.6 sigma ~ 0.1 px at the band's edge, two orders above the noise of the
+    // computed distances of faces that are not flagged thin.
     bool no_edge = false;
-    if (fc.ill_conditioned()) {
-        if (inside) {
+    if (fc.ill_conditioned() | (amb_thr > 0.f)) {          // wave-uniform: the default build pays nothing for unflagged faces
+        const bool doubt = inside & (fc.ill_conditioned() | (fmed3_(m0, m1, m2) < amb_thr));
+        if (doubt) {
             float dmin = 100000000.f;
             int kb = -1;
             float tbest = 0.f;

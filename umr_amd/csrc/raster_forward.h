@@ -95,7 +95,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     continue;
                 }
                 Pair p;
-                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis) & t.valid;
+                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr) & t.valid;
                 if (RGB == 2) {
                     alpha *= live ? 1.f - p.frag : 1.f;
                     continue;

@@ -19,7 +19,7 @@ struct GenFrag {       // one (pixel, face) pair in any distance mode
 
 __device__ __forceinline__ void gen_fragment(GenFrag &g, const Face &fc, const RasterArgs &A, float xp, float yp, bool valid) {
     if (A.dist_mode == 2) {
-        g.live = eval_pair(g.p, fc, xp, yp, A.threshold, A.nis) & valid;
+        g.live = eval_pair(g.p, fc, xp, yp, A.threshold, A.nis, A.amb_thr) & valid;
         g.frag = g.p.frag;
         g.dis = g.p.dx * g.p.dx + g.p.dy * g.p.dy;
         return;
