@@ -23,7 +23,7 @@ def rotate_cam_y(cam, angle_deg):
 
 class RenderCompareS1Ref:
     def __init__(self, template_verts, faces, image_size=256, weights=None, n_threads=1, backend="port",
-                 texture_loss=None, epoch=0):
+                 texture_loss=None, epoch=0, discriminator=None):
         """texture_loss: callable(img_pred, img_gt, mask_gt, mask_pred) (TR.PerceptualTextureLoss in the reference,
         train_s1.py:150); None = the masked L1 of loss_utils.py:103-116.  epoch: train_s1.py:250-255 gates the
         symmetry term (epoch < stop_ori_epoch) and the deformation term (epoch > update_template_freq)."""
@@ -31,6 +31,7 @@ class RenderCompareS1Ref:
         self.w = weights or S1Weights()
         self.texture_loss = texture_loss or TR.texture_loss_masks
         self.epoch = epoch
+        self.discriminator = discriminator           # train_s1.py:88-90, :243; None = mean of the unseen-view mask instead
         self.faces = faces.long()
         mk = lambda kind: TR.SoftRenderer(image_size, kind, backend=backend, n_threads=n_threads)
         self.renderer, self.dis_renderer, self.hard_renderer, self.tex_renderer = mk("softmax"), mk("softmax"), mk("hard"), mk("softmax")
@@ -61,7 +62,12 @@ class RenderCompareS1Ref:
         _, _, aggr = self.hard_renderer(pred_vs.detach(), faces, proj_cam.detach())
         t["tex_cycle"], _ = TR.tex_cycle(tex_flow, p2f.detach(), aggr[:, 1].reshape(bs, -1).detach())
         pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, rotate_cam_y(proj_cam.detach(), batch["gan_angles"]))
-        t["gan"] = pred_unseen[:, 3].mean()
+        if self.discriminator is not None:           # train_s1.py:238-244
+            pred = torch.cat((pred_seen.detach(), pred_unseen))
+            labels = torch.cat((torch.ones(pred_seen.shape[0]), torch.zeros(pred_unseen.shape[0])), dim=0)
+            t["gan"] = torch.nn.functional.binary_cross_entropy_with_logits(self.discriminator(pred[:, 3].unsqueeze(1)).squeeze(), labels)
+        else:
+            t["gan"] = pred_unseen[:, 3].mean()
         total = t["mask"] * w.mask_loss_wt + t["triangle"] * w.triangle_reg_wt + t["flatten"] * w.flatten_reg_wt
         if self.epoch < w.stop_ori_epoch:            # train_s1.py:250-252
             total = total + t["ori"] * w.ori_reg_wt
