@@ -84,11 +84,12 @@ class RenderCompareS2Ref:
     MultiTextureLoss uses PerceptualTextureLoss (loss_utils.py:291-292); None = masked L1 (loss_utils.py:103-116)."""
 
     def __init__(self, template_verts, faces, part_vertex_ids, uv_img, uv_sampler, image_size=256, num_hypo_cams=8,
-                 weights=None, n_threads=1, backend="port", tex_size=6, texture_loss=None):
+                 weights=None, n_threads=1, backend="port", tex_size=6, texture_loss=None, discriminator=None, num_sym_faces=0):
         from umr_amd.train_step import S2Weights
         self.w = weights or S2Weights()
         self.texture_loss = texture_loss or TR.texture_loss_masks
         self.K, self.image_size = num_hypo_cams, image_size
+        self.discriminator = discriminator            # train_s2.py:91-93, :262; None = mean of the unseen-view colours instead
         self.faces = faces.long()
         mk = lambda kind: TR.SoftRenderer(image_size, kind, backend=backend, n_threads=n_threads)
         self.mask_r, self.tex_r, self.hard_r, self.dis_r, self.part_r = mk("softmax"), mk("softmax"), mk("hard"), mk("softmax"), mk("softmax")
@@ -99,6 +100,8 @@ class RenderCompareS2Ref:
         self.part_ids = [torch.as_tensor(part_vertex_ids[n]).long() for n in names]
         tex = TR.grid_sample(uv_img.float().view(1, 1, 128, 256), uv_sampler)
         tex = tex.view(1, -1, tex.size(2), tex_size, tex_size).permute(0, 2, 3, 4, 1)
+        if num_sym_faces:                             # loss_utils.py:347-348: the sampler covers F - n faces, the last n are repeated
+            tex = torch.cat([tex, tex[:, -num_sym_faces:]], 1)
         stex = torch.round(tex.reshape(tex.size(1), -1))
         nf, nt = stex.size()
         one_hot = torch.zeros(nf * nt, 5)
@@ -131,7 +134,12 @@ class RenderCompareS2Ref:
         _, p2f, aggr = self.hard_r(pred_vs.detach(), faces, proj_cam)
         t["tex_cycle"], _ = TR.tex_cycle(tex_flow, p2f.detach(), aggr[:, 1].reshape(bs, -1).detach())
         pred_unseen, _, _ = self.dis_r(pred_vs, faces, rotate_cam_y(proj_cam, batch["gan_angles"]), tex.detach())
-        t["gan"] = pred_unseen[:, 0:3].mean()
+        if self.discriminator is not None:            # train_s2.py:256-263
+            pred = torch.cat((batch["random_imgs"], pred_unseen[:, 0:3]))
+            labels = torch.cat((torch.ones(batch["random_imgs"].shape[0]), torch.zeros(pred_vs.shape[0])), dim=0)
+            t["gan"] = torch.nn.functional.binary_cross_entropy_with_logits(self.discriminator(pred).squeeze(), labels)
+        else:
+            t["gan"] = pred_unseen[:, 0:3].mean()
         projs = []
         for i in range(1, 5):
             stex = self.stex[:, :, :, i].unsqueeze(-1).repeat(B, 1, 1, 3)

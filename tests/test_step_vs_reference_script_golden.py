@@ -104,3 +104,70 @@ def test_product_step_on_the_gpu_vs_the_reference_script(epoch):
     total, terms = RenderCompareS1(tv, faces, int(g["image_size"]), discriminator=disc.to("cuda:0"), epoch=epoch).to("cuda:0")(out, batch(epoch))
     total.backward()
     _check(g, epoch, total, terms, leaves, "gpu", 1e-5, 2e-5)     # measured on the MI355X: camera gradient 1.1e-7 of scale, texture flow 1.8e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------- train_s2
+TERMS_S2 = dict(cam_div="cam_div_loss", mask="mask_loss", triangle="triangle_loss", flatten="flatten_loss", deform="deform_loss", tex="tex_loss",
+                tex_dt="tex_dt_loss", tex_cycle="tex_cycle_loss", gan="gan_loss", part="part_loss", corr="corr_loss")
+
+
+def _inputs_s2(g, dev):
+    t = lambda k: torch.from_numpy(g[k].astype(np.float32)).to(dev)
+    tv, faces = t("template_verts"), torch.from_numpy(g["faces"]).long().to(dev)
+    leaves = {k: t(k).requires_grad_(True) for k in ("delta_v", "cam_hypotheses", "cam_probs", "tex_flow")}
+    out = dict(leaves, cam=t("cam"), mean_shape=tv, pred_vs=tv[None] + leaves["delta_v"])
+    batch = dict(imgs=t("imgs"), masks=t("masks"), dts_barrier=t("dts_barrier"), part_segs=t("part_segs"), random_imgs=t("random_imgs"),
+                 gan_angles=t("gan_angles"), **{n + "_points": t(n + "_points") for n in ("head", "belly", "back", "neck")})
+    ids = {n: g["part_ids_" + n] for n in ("head", "belly", "neck", "back")}
+    return tv, faces, leaves, out, batch, ids, t("uv_img").view(1, 1, 128, 256), t("uv_sampler"), _Disc(t("disc_w")), int(g["num_sym_faces"])
+
+
+def _check_s2(g, total, terms, leaves, name, tol_terms, grad_atol):
+    for k, ref_name in TERMS_S2.items():
+        ref = float(g[ref_name])
+        assert abs(float(terms[k]) - ref) <= tol_terms * max(1.0, abs(ref)), (name, k, float(terms[k]), ref)
+    assert abs(float(total) - float(g["total_loss"])) <= tol_terms * max(1.0, abs(float(g["total_loss"]))), name
+    for k, v in leaves.items():
+        r = g["grad_" + k]
+        # delta_v: see _check (the adversarial term's rotated camera)
+        assert_close_frac(v.grad.detach().cpu().numpy(), r, atol=grad_atol * np.abs(r).max(), rtol=1e-3, frac=0.95 if k == "delta_v" else 1.0,
+                          max_outlier=5e-3 * np.abs(r).max(), name="%s_step_s2_grad_%s" % (name, k))
+
+
+def test_restatement_of_the_s2_step_vs_the_reference_script(oracle_built):
+    """tests/golden/step_s2.npz: experiments/train_s2.py: ShapenetTrainer.forward() (:201-316) itself (oracle/gen_golden_steps.py s2),
+    K = 8 hypotheses at 256 x 256: eleven terms, the total, gradients with respect to delta_v, the camera hypotheses, their
+    probabilities and the texture flow."""
+    from oracle.train_step_ref import RenderCompareS2Ref
+    g = load_golden("step_s2.npz")
+    tv, faces, leaves, out, batch, ids, uv_img, uv_sampler, disc, nsym = _inputs_s2(g, "cpu")
+    ref = RenderCompareS2Ref(tv, faces, ids, uv_img, uv_sampler, int(g["image_size"]), 8, n_threads=8, discriminator=disc, num_sym_faces=nsym)
+    total, terms = ref(out, batch)
+    total.backward()
+    _check_s2(g, total, terms, leaves, "restatement", 3e-6, 2e-5)
+
+
+@pytest.mark.skipif(not HR.available(), reason="clang++ of the ROCm toolchain not present")
+def test_product_s2_step_on_the_emulator_vs_the_reference_script():
+    from umr_amd.train_step import RenderCompareS2
+    g = load_golden("step_s2.npz")
+    HR.lib(HR.build())
+    with HR.emulated_product():
+        tv, faces, leaves, out, batch, ids, uv_img, uv_sampler, disc, nsym = _inputs_s2(g, "cpu")
+        step = RenderCompareS2(tv, faces, ids, uv_img, uv_sampler, int(g["image_size"]), 8, texture_loss_type="l1", discriminator=disc,
+                               num_sym_faces=nsym)
+        total, terms = step(out, batch)
+        total.backward()
+    _check_s2(g, total, terms, leaves, "emulator", 3e-6, 2e-5)
+
+
+@pytest.mark.gpu
+def test_product_s2_step_on_the_gpu_vs_the_reference_script():
+    from umr_amd.train_step import RenderCompareS2
+    g = load_golden("step_s2.npz")
+    tv, faces, leaves, out, batch, ids, uv_img, uv_sampler, disc, nsym = _inputs_s2(g, "cuda:0")
+    step = RenderCompareS2(tv, faces, ids, uv_img, uv_sampler, int(g["image_size"]), 8, texture_loss_type="l1", discriminator=disc.to("cuda:0"),
+                           num_sym_faces=nsym).to("cuda:0")
+    total, terms = step(out, batch)
+    total.backward()
+    _check_s2(g, total, terms, leaves, "gpu", 1e-5, 2e-5)
