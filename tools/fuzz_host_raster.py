@@ -137,10 +137,12 @@ if __name__ == "__main__":
     ap.add_argument("--classes", default="sphere,dense,soup,tiny,needles,degenerate")
     ap.add_argument("--lib", default=None)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--exact-edges", type=int, default=0, help="umr_debug_set(\"exact_edges\", v) before the run")
+    ap.add_argument("--exact-edges", type=int, default=1, help="umr_debug_set(\"exact_edges\", v) before the run")
+    ap.add_argument("--thin-h-1e6", type=int, default=-1, help="umr_debug_set(\"thin_face_h_1e6\", v); negative = the default")
     a = ap.parse_args()
     L = HR.lib(a.lib or HR.build())
     L.umr_debug_set(b"exact_edges", a.exact_edges)
+    L.umr_debug_set(b"thin_face_h_1e6", a.thin_h_1e6)
     stats = {}
     t0 = time.time()
     kinds = a.classes.split(",")
