@@ -129,7 +129,7 @@ static void lane_entry() {
     abort();   // a finished lane is never resumed
 }
 
-// park the running lane at a cross-lane operation and return, once released, the thread id base of its wave
+// park the running lane at a cross-lane operation (operand deposited); returns once the scheduler has released it
 static inline void park(int state, int kind, int prio, uint32_t operand) {
     Block *b = g_block;
     const int t = b->cur;
