@@ -253,3 +253,43 @@ def test_default_build_takes_the_references_decisions_on_fuzzed_scenes(L, oracle
         assert rec["alpha_err_max"] <= 1e-6, (kind, rec)
         assert rec["rgb_err_gt_1e4"] == 0, (kind, rec)
         assert max(rec["gf_err_max"], rec["gt_err_max"], rec["gfa_err_max"]) <= 1e-5, (kind, rec)
+
+
+def test_emulated_library_exports_the_whole_c_abi(L):
+    """libumr_host.so is the SAME translation units as libumr_hip.so: every entry point include/umr_hip.h declares is in it."""
+    import re
+    import os
+    hdr = open(os.path.join(HR.ROOT, "include", "umr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(umr_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.umr_version() == b"umr_hip 0.3 gfx950" and L.umr_build_id() == b"host-emulation"
+
+
+def test_exactness_switches_change_what_they_say(L, oracle_built):
+    """umr_debug_set("exact_edges", 0) -- the fast nearest-edge pick -- and "thin_face_h_1e6": on a scene of small faces the fast
+    pick differs from the oracle in isolated pixels / faces (that is what the switch trades), the default does not, and with the
+    thin-face threshold at infinity the fast pick is exact again (every inside lane on the reference's route)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(HR.ROOT, "tools"))
+    import fuzz_host_raster as FZ
+
+    def run(**switches):
+        for k, v in switches.items():
+            L.umr_debug_set(k.encode(), v)
+        try:
+            stats = {}
+            for i in range(5):
+                FZ.run_one(np.random.default_rng([7, i]), "dense", 64, L, stats)
+            return stats["dense"]
+        finally:
+            L.umr_debug_set(b"exact_edges", 1)
+            L.umr_debug_set(b"thin_face_h_1e6", -1)
+    default, fast, brute = run(), run(exact_edges=0), run(exact_edges=0, thin_face_h_1e6=1000000000)
+    assert max(default["gf_err_max"], default["gfa_err_max"]) <= 1e-5 and default["alpha_err_max"] <= 1e-6
+    assert max(brute["gf_err_max"], brute["gfa_err_max"]) <= 1e-5 and brute["alpha_err_max"] <= 1e-6
+    assert max(fast["gf_err_max"], fast["gfa_err_max"]) > 1e-4          # the fast pick is measurably not the reference's choice ...
+    assert fast["alpha_err_max"] <= 2e-2 and fast["membership_pixels"] == 0   # ... within the bounds DESIGN.md 4.4 states
