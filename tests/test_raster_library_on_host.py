@@ -282,7 +282,7 @@ def test_exactness_switches_change_what_they_say(L, oracle_built):
             L.umr_debug_set(k.encode(), v)
         try:
             stats = {}
-            for i in range(5):
+            for i in (6, 11, 27, 29):          # scenes in which the fast pick is known to take another edge somewhere (seeded, deterministic)
                 FZ.run_one(np.random.default_rng([7, i]), "dense", 64, L, stats)
             return stats["dense"]
         finally:
@@ -291,5 +291,5 @@ def test_exactness_switches_change_what_they_say(L, oracle_built):
     default, fast, brute = run(), run(exact_edges=0), run(exact_edges=0, thin_face_h_1e6=1000000000)
     assert max(default["gf_err_max"], default["gfa_err_max"]) <= 1e-5 and default["alpha_err_max"] <= 1e-6
     assert max(brute["gf_err_max"], brute["gfa_err_max"]) <= 1e-5 and brute["alpha_err_max"] <= 1e-6
-    assert max(fast["gf_err_max"], fast["gfa_err_max"]) > 1e-4          # the fast pick is measurably not the reference's choice ...
+    assert max(fast["gf_err_max"], fast["gfa_err_max"]) > 1e-3          # the fast pick is measurably not the reference's choice (1.3 - 5.4 % here) ...
     assert fast["alpha_err_max"] <= 2e-2 and fast["membership_pixels"] == 0   # ... within the bounds DESIGN.md 4.4 states
