@@ -49,6 +49,9 @@ def run(iters=3, scale=(0.6, 0.9), N=16, IS=512, subdiv=3, TS=36, timed=True):
     return out
 
 
+if os.environ.get("UMR_LIB_FILE"):      # an experimental build (tools/r4/build_asm.py, build_variants.py)
+    _lib.LIB_PATH = os.path.abspath(os.environ["UMR_LIB_FILE"])
+
 if __name__ == "__main__":
     it = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     sc = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.6, 0.9)
@@ -56,4 +59,4 @@ if __name__ == "__main__":
     for kv in os.environ.get("UMR_DEBUG_SET", "").split(","):      # e.g. UMR_DEBUG_SET=exact_edges=0,face_order=0
         if "=" in kv:
             _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
-    print(json.dumps({"scale": sc, "N": n, "us_per_launch": run(it, sc, n)}), flush=True)
+    print(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "set": os.environ.get("UMR_DEBUG_SET", ""), "scale": sc, "N": n, "us_per_launch": run(it, sc, n)}), flush=True)
