@@ -196,7 +196,7 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
         k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
-        const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_INV);
+        const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_I0);
         const float4 bb = bbox[i];
         for (int t = 0; t < ntiles; ++t) {
             const float cx = tiles[4 * t], cy = tiles[4 * t + 1], hx = tiles[4 * t + 2], hy = tiles[4 * t + 3];

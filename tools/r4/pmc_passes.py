@@ -28,7 +28,10 @@ GROUPS = {
     "tcp": "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum",
 }
 used = {}
+only = os.environ.get("PMC_GROUPS")
 for g, names in GROUPS.items():
+    if only and g not in only.split(","):
+        continue
     ok = [n for n in names.split() if n in avail]
     if not ok:
         continue

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                 const float4 bb = bbox_n[fcand];
                 hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
                 if (hit) {  // one lane per candidate face: exact-ish tile/triangle test
-                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_INV);
+                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_I0);
                     hit = tile_may_hit(q[0], q[1], q[2], 0.5f * (t.wxlo + t.wxhi), 0.5f * (t.wylo + t.wyhi),
                                        0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr + rec_n[(size_t)fcand * REC + R_CULL]);
                 }
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                 int tix = 0;
                 bool contrib = false;
                 Pair p;
-                if (t.valid && eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr)) {
+                if (eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr, t.valid) && t.valid) {
                     float c_xy = g3 * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
                        // (a third, vertical step measured slower)
 #endif
 #ifndef FM_VREC
-#define FM_VREC 1         // 1: the face's inverse barycentric matrix and corner coordinates as VGPR operands (FaceV)
+#define FM_VREC 1         // 1: the face's barycentric rows and corner coordinates as VGPR operands (FaceV)
 #endif
 #ifndef FM_FMA_ACC
 #define FM_FMA_ACC 1      // 1: gradient accumulators updated with explicit fused multiply-adds (the summation order of the

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
         fidx = e & 0xffff;
     }
     const bool live = fidx < F;
-    const int n = nb, f = live ? fidx : 0;
+    // (explicitly wave-uniform: the record's address below feeds scalar loads)
+    const int n = __builtin_amdgcn_readfirstlane(nb), f = __builtin_amdgcn_readfirstlane(live ? fidx : 0);
     const size_t npix = (size_t)IS * IS;
     // wave-uniform bases of this mesh's per-pixel planes; every per-pixel load below is base + 32-bit byte offset
     const int H2 = IS >> 1;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     bool visited = false;                   // wave-uniform: some sub-tile survived the culling pass
     if (live) {
         // VGPR-resident operands where the register budget of 7 waves / SIMD has room for them (silhouette and
-        // texel-gradient-only variants: 56-60 VGPRs with them; the full variant would spill)
+        // texel-gradient-only variants; the full variant would spill)
         constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF);
         typename std::conditional<VREC, FaceV, Face>::type fc;
         load_face(fc, A.rec + ((size_t)n * F + f) * REC);
@@ -110,9 +111,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const bool pow2 = COMMON ? true : ((IS & (IS - 1)) == 0);
             const float inv_is = 1.f / (float)IS;
             const int ntx = tx1 - tx0 + 1, ntiles = ntx * (ty1 - ty0 + 1);
-            const float4 i0 = make_float4(fc.template g<R_INV + 0>(), fc.template g<R_INV + 1>(), fc.template g<R_INV + 2>(), fc.template g<R_INV + 3>());
-            const float4 i1 = make_float4(fc.template g<R_INV + 4>(), fc.template g<R_INV + 5>(), fc.template g<R_INV + 6>(), fc.template g<R_INV + 7>());
-            const float4 i2 = make_float4(fc.template g<R_INV + 8>(), fc.template g<R_K0>(), fc.template g<R_K1>(), fc.template g<R_K2>());
+            // the record's floats [R_I0, R_I0 + 12) as tile_may_hit takes them
+            const float4 i0 = make_float4(fc.template g<R_I0>(), fc.template g<R_I3>(), fc.template g<R_I1>(), fc.template g<R_I4>());
+            const float4 i1 = make_float4(fc.template g<R_I2>(), fc.template g<R_I5>(), fc.template g<R_I6>(), fc.template g<R_I7>());
+            const float4 i2 = make_float4(fc.template g<R_I8>(), fc.template g<R_K2>(), fc.template g<R_K0>(), fc.template g<R_K1>());
             const float thr_cull = A.thr + A.rec[((size_t)n * F + f) * REC + R_CULL];   // band of the cull: + the reference's noise
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
 #if FM_BODY_SLOTS
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #ifndef UMR_HOST_SHIM
                         asm volatile("" : "+s"(rp));
 #endif
-                        load_face(fc, rp);
+                        reload_face(fc, rp);
                     }
                     if (mine < 0) continue;
 #if FM_BODY_SLOTS

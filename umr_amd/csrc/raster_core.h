@@ -18,20 +18,41 @@
 #endif
 #define SB_SLOTS 256  // super-block slots per mesh in the workspace layout (<= 16 x 16 super-blocks of >= 64^2 pixels)
 #define SB_CAP 1024   // list capacity per slot (entries); a slot that more faces touch is scanned in full (superblock_list)
+#ifndef UMR_REGION_VOTE
+#define UMR_REGION_VOTE 0   // 1: eval_pair votes per visit and runs a specialised body when its lanes all lie inside / all outside
+#endif                      // the face.  Measured on MI355X (profiles/r04_ab_region_vote.jsonl): the bodies are 15-25 % shorter, a
+                            // visit is uniform too rarely at 8x8 / 4x4 granularity and the vote costs two VALU + a branch each
+                            // way -- +-1 % on every kernel, silhouette forward 2 % slower.  Off; the bodies stay for a caller
+                            // that KNOWS the side (REGION 1 / 2 of eval_pair_region).
 #define BLK_WX (BLK_W / 8)                          // 8x8 wave tiles across / in the workgroup
 #define BLK_THREADS (BLK_WX * (BLK_H / 8) * 64)
 
 namespace {
 
 // Record layout (floats) written by k_face_setup: 256 bytes per face.
-//   [0,32)  wave-uniform part, fetched with 2 x s_load_dwordx16 into SGPRs
-//   [32,56) three 32-byte edge blocks {a0, a1, a2, a[v1], den, RN(1/den), -, -}; a lane reads ONLY the block
+//   [0,32)  wave-uniform part, fetched with 2 x s_load_dwordx16 into SGPRs.  Quantities that enter the geometry as 2-vectors
+//           sit in EVEN-ALIGNED PAIRS so that they are operands of packed fp32 instructions straight from the scalar file:
+//           on gfx950 a v_mul_f32 with an SGPR source issues in 4.2 cycles per wave, a v_pk_mul_f32 with an SGPR PAIR source in
+//           4.3 -- two products for the price of one (tools/ubench/valu_ubench2.hip, profiles/r04_valu_ubench2.log)
+//   [32,36) reciprocal depths (third scalar load, only in the kernels that interpolate depth)
+//   [40,64) three 32-byte edge blocks {a0, a1, a2, a[v1], den, RN(1/den), -, -}; a lane reads ONLY the block
 //           of its nearest edge (per-lane address, 2 x global_load_dwordx4, L1-resident)
-enum { R_XLO = 0, R_XHI = 1, R_YLO = 2, R_YHI = 3, R_X0 = 4, R_Y0 = 5, R_X1 = 6, R_Y1 = 7, R_X2 = 8, R_Y2 = 9,
-       R_Z0 = 10, R_Z1 = 11, R_Z2 = 12, R_RZ0 = 13, R_RZ1 = 14, R_RZ2 = 15,
-       R_INV = 16, R_K0 = 25, R_K1 = 26, R_K2 = 27, R_FLAGS = 28, R_FRONT = 29, R_OX = 30, R_OY = 31,
-       R_EDGE = 32,
-       R_CULL = R_EDGE + 6 };   // spare slot of edge block 0: how far beyond sqrt(threshold) the reference still includes pixels
+enum { R_XLO = 0, R_XHI = 1, R_YLO = 2, R_YHI = 3,
+       R_X0 = 4, R_Y0 = 5, R_X1 = 6, R_Y1 = 7, R_X2 = 8, R_Y2 = 9,       // corners as (x, y) pairs
+       R_CX = 10, R_CY = 11,      // the obtuse corner (0, 0 without one): operand of the override test (:116,:119,:122)
+       R_OX = 12, R_OY = 13,      // ... and the vector it is tested against: corner k -> p_{k+2} - p_k
+       R_FLAGS = 14,              // bits 0-1 obtuse corner + 1 | 2 slow division | 3 depth always in range | 4 ill-conditioned / thin
+                                  // | 5 front-facing
+       R_CULL = 15,               // how far beyond sqrt(threshold) the reference still includes pixels (tile_may_hit)
+       // inverse barycentric matrix, rows 0 and 1 interleaved: (inv0, inv3) (inv1, inv4) (inv2, inv5) -> (w0, w1) in three packed ops
+       R_I0 = 16, R_I3 = 17, R_I1 = 18, R_I4 = 19, R_I2 = 20, R_I5 = 21, R_I6 = 22, R_I7 = 23, R_I8 = 24,
+       R_K2 = 25, R_K0 = 26, R_K1 = 27,                                  // squared heights; (K0, K1) is a pair
+       R_Z0 = 28, R_Z1 = 29, R_Z2 = 30,
+       R_LUT = 31,                // the face's region table (eval_pair): 16 entries of 2 bits
+       R_RZ0 = 32, R_RZ1 = 33, R_RZ2 = 34,
+       R_EDGE = 40 };
+// position of inv[i] (row-major 3 x 3, the reference's face_inv) in the record
+__host__ __device__ constexpr int r_inv(int i) { return i == 0 ? R_I0 : i == 1 ? R_I1 : i == 2 ? R_I2 : i == 3 ? R_I3 : i == 4 ? R_I4 : i == 5 ? R_I5 : R_I6 + (i - 6); }
 
 struct RasterArgs {
     const float4 *bbox;   // [N*F] (xlo, xhi, ylo, yhi) = bbox dilated by sqrt(threshold)
@@ -133,35 +154,58 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         const bool front = (y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0);
         cost[i] = (unsigned short)(key | (front ? 0x8000 : 0));
     }
-    // ---- packed record: three 64-byte lines, fetched by the raster kernels with 3 x s_load_dwordx16 ----
+    // ---- packed record ----
     float *r = rec + (size_t)i * REC;
+#pragma unroll
+    for (int k = 0; k < REC; ++k) r[k] = 0.f;
     r[R_XLO] = xlo; r[R_XHI] = xhi; r[R_YLO] = ylo; r[R_YHI] = yhi;
     r[R_X0] = x0; r[R_Y0] = y0; r[R_X1] = x1; r[R_Y1] = y1; r[R_X2] = x2; r[R_Y2] = y2;
     r[R_Z0] = z0; r[R_Z1] = z1; r[R_Z2] = z2;
     r[R_RZ0] = 1.f / z0; r[R_RZ1] = 1.f / z1; r[R_RZ2] = 1.f / z2;  // correctly rounded (Markstein division)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) r[R_INV + k] = inv[k];
+    for (int k = 0; k < 9; ++k) r[r_inv(k)] = inv[k];
     // squared height of corner c over its opposite edge: inside the triangle the squared distance to that
     // edge's line is w_c^2 K_c -- used only to PICK the nearest edge (:99), the distance itself is then
     // evaluated with the reference's own formula
     const float det_raw = x2 * (y0 - y1) + x0 * (y1 - y2) + x1 * (y2 - y0);
+    float kh[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int a = (c + 1) % 3, b = (c + 2) % 3;
         const float ex = px[a] - px[b], ey = py[a] - py[b];
-        r[R_K0 + c] = det_raw * det_raw / fmaxf(ex * ex + ey * ey, 1e-30f);
+        kh[c] = det_raw * det_raw / fmaxf(ex * ex + ey * ey, 1e-30f);
     }
+    r[R_K0] = kh[0]; r[R_K1] = kh[1]; r[R_K2] = kh[2];
     // depth chain may use reciprocal-multiply division only when every z is an ordinary positive number
     const bool sane = z0 > 1e-20f && z1 > 1e-20f && z2 > 1e-20f && z0 < 1e20f && z1 < 1e20f && z2 < 1e20f;
     // bit 3: every vertex depth strictly inside (near, far) => the interpolated depth (a convex combination of the
     // 1/z_k with positive clipped weights) can never be rejected by the depth-range test (:404, :592)
     const float zmin = fminf(fminf(z0, z1), z2), zmax = fmaxf(fmaxf(z0, z1), z2);
     const bool inrange = sane && zmin > near_ * 1.0001f && zmax < far_ * 0.9999f;
-    // bits 0-1: obtuse corner + 1 (0 = none); bit 2: slow division path
-    r[R_FLAGS] = __int_as_float((obt + 1) | (sane ? 0 : 4) | (inrange ? 8 : 0));
-    r[R_FRONT] = ((y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0)) ? 1.f : 0.f;  // :42-44
-    // vector of the obtuse-corner override test (:116,:119,:122): corner k -> p_{k+2} - p_k
+    const bool front = (y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0);  // :42-44
+    // The reference's region if-chain (:112-126) as a table of the region code m = n0 | n1 << 1 | n2 << 2 (n_k = w_k <= 0), entries
+    // v0 + 1 in 2 bits: no flag -> -1 (the reference's out-of-bounds case, defined as "skip"); one flag: the opposite edge (n0 -> 1,
+    // n1 -> 2, n2 -> 0); two flags: the vertex region between them ({n0,n1} -> 2, {n2,n0} -> 1, {n1,n2} -> 0); all three
+    // (degenerate faces only) ends like {n1,n2}.  Entries 8 + m: the same with the override of the obtuse corner applied
+    // (:116,:119,:122: in ITS vertex region the other edge is taken when the pixel lies beyond it) -- corner 0: region {n1,n2} = 6
+    // and 7 -> edge 2; corner 1: {n2,n0} = 5 -> edge 0; corner 2: {n0,n1} = 3 -> edge 1.  eval_pair indexes with m + 8 * override.
+    unsigned lut = 0;
+    {
+        const int base[8] = {-1, 1, 2, 2, 0, 1, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            int v = base[m];
+            lut |= (unsigned)(v + 1) << (2 * m);
+            if (obt == 0 && (m == 6 || m == 7)) v = 2;
+            if (obt == 1 && m == 5) v = 0;
+            if (obt == 2 && m == 3) v = 1;
+            lut |= (unsigned)(v + 1) << (2 * (8 + m));
+        }
+    }
+    r[R_LUT] = __int_as_float((int)lut);
+    int flags = (obt + 1) | (sane ? 0 : 4) | (inrange ? 8 : 0) | (front ? 32 : 0);
     const int ob = obt < 0 ? 0 : obt;
+    r[R_CX] = obt < 0 ? 0.f : px[ob]; r[R_CY] = obt < 0 ? 0.f : py[ob];
     r[R_OX] = px[(ob + 2) % 3] - px[ob];
     r[R_OY] = py[(ob + 2) % 3] - py[ob];
     // edge e = (e, e+1): a_e[j] = sym[e][j] - sym[e+1][j] (:82-84,:133-135); den_e = a_e[e] - a_e[e+1]
@@ -178,7 +222,7 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         // bit 4: some edge is shorter than ~3e-3 screen units (0.8 px at IS = 512): its `den` -- a squared length obtained
         // by cancellation of O(1) terms -- is rounding noise, possibly exactly 0.  eval_pair then evaluates the inside
         // branch the reference's way (all three edge lines, smallest computed distance).  NaN den: flagged as well.
-        if (!(fabsf(den) >= 1e-5f)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
+        if (!(fabsf(den) >= 1e-5f)) flags |= 16;
     }
     // ... and so does a THIN face (a height below thin_h screen units).  Inside a triangle the reference keeps the edge LINE with
     // the smallest COMPUTED distance (:78-107); eval_pair picks the line by its true distance w_c^2 K_c first and evaluates
@@ -188,9 +232,8 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     // at 0.01, a quarter at 1e-3 (measured on this source compiled for the host, tests/host_kernel), and there the soft
     // fragment differs by up to 0.1 and the gradient goes to another pair of vertices.  Flagged faces take the reference's
     // route whenever a lane is inside; the cost is theirs alone.
-    if (!(fminf(fminf(r[R_K0], r[R_K1]), r[R_K2]) >= thin_h * thin_h)) r[R_FLAGS] = __int_as_float(__float_as_int(r[R_FLAGS]) | 16);
-#pragma unroll
-    for (int k = R_EDGE + 24; k < REC; ++k) r[k] = 0.f;
+    if (!(fminf(fminf(kh[0], kh[1]), kh[2]) >= thin_h * thin_h)) flags |= 16;
+    r[R_FLAGS] = __int_as_float(flags);
     // Widening of the tile cull (tile_may_hit).  Outside the triangle the reference computes the closest point through an edge
     // parameter t = (w . a - a[v1]) / den whose operands are differences of O(1 + |p|^2) products (:82-84, :133-137): its
     // rounding error, times |w| ~ threshold distance / height, divided by den = |edge|^2, times |edge| again for the point.  So
@@ -200,7 +243,7 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
     // gradients by O(1).  c measured on this source compiled for the host (tools/r3/reference_noise.py cull): 1.8e-6 for faces on
     // the screen, 4.8e-6 up to 2.5 screen half-widths out; 5e-6 here.  0.04 px for a BASELINE face at IS = 512 (h 0.07, L 0.08),
     // a pixel for a sliver of 0.001 units; a degenerate face (h = 0 or L = 0) gets inf and is culled by its box alone.
-    float k_min = fminf(fminf(r[R_K0], r[R_K1]), r[R_K2]), l2_min = 3.0e38f, p2_max = 0.f;
+    float k_min = fminf(fminf(kh[0], kh[1]), kh[2]), l2_min = 3.0e38f, p2_max = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int a = (c + 1) % 3;
@@ -237,38 +280,83 @@ __device__ __forceinline__ float4 ld_u4(const char *base, unsigned byte_off) {
     return *(const float4 *)(base + byte_off);
 }
 
-struct Face {  // wave-uniform: 32 SGPRs + the record's address
+// Wave votes over the lanes that reach them (EXEC), straight on the lane mask: HIP's __all / __any take an int and cost a
+// select and a compare per vote.  The emulation build (tests/host_kernel) maps them to its subset vote.
+#ifdef UMR_HOST_SHIM
+__device__ __forceinline__ bool wave_all(bool p) { return __all(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return !__all(!p); }
+#define UMR_KEEP_BRANCH() ((void)0)
+#else
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+#define UMR_KEEP_BRANCH() asm volatile("" ::: "memory")   // a rare wave-uniform path stays a branch (no if-conversion into selects)
+#endif
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f cv4f_t;
+__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
+
+struct Face {  // wave-uniform: 32 (+ 4) SGPRs + the record's address
     v16f qa, qb;
+    v4f qc;               // reciprocal depths: loaded only where a kernel reads them (an unused load is dropped by the compiler)
     const char *edges;    // three 32-byte edge blocks (global memory, read per lane: uniform base + k * 32)
     template <int I> __device__ __forceinline__ float g() const {
         if constexpr (I < 16) return qa[I];
-        else return qb[I - 16];
+        else if constexpr (I < 32) return qb[I - 16];
+        else return qc[I - 32];
     }
-    // hot arithmetic operands: inverse barycentric matrix and corner coordinates.  FaceV (below) overrides these with
-    // VGPR-resident copies: on gfx950 a VALU instruction with an SGPR source issues at half the rate of the same
-    // instruction on VGPRs (tools/ubench/valu_ubench.hip: v_mul_f32 2.4 vs 4.3 cycles per wave-instruction)
-    template <int I> __device__ __forceinline__ float inv() const { return g<R_INV + I>(); }
-    template <int I> __device__ __forceinline__ float xy() const { return g<R_X0 + I>(); }
-    __device__ __forceinline__ int obt() const { return (__float_as_int(g<R_FLAGS>()) & 3) - 1; }
-    __device__ __forceinline__ bool front() const { return g<R_FRONT>() != 0.f; }
-    __device__ __forceinline__ bool slow() const { return (__float_as_int(g<R_FLAGS>()) & 4) != 0; }
-    __device__ __forceinline__ bool depth_in_range() const { return (__float_as_int(g<R_FLAGS>()) & 8) != 0; }
-    __device__ __forceinline__ bool ill_conditioned() const { return (__float_as_int(g<R_FLAGS>()) & 16) != 0; }
+    // an even-aligned pair (I, I + 1) of the record as a 2-vector: an SGPR pair, i.e. one source operand of a packed fp32 op
+    template <int I> __device__ __forceinline__ v2f g2() const {
+        static_assert((I & 1) == 0 && I < 32, "pairs are even-aligned and live in the first 32 floats");
+        if constexpr (I < 16) return __builtin_shufflevector(qa, qa, I, I + 1);
+        else return __builtin_shufflevector(qb, qb, I - 16, I - 15);
+    }
+    template <int I> __device__ __forceinline__ float inv() const { return g<r_inv(I)>(); }   // the reference's face_inv[I]
+    // barycentrics (:25-29) and the offset sum (:95-96, :148-149) in the reference's operation order, rounded once per
+    // operation; here two rows / both components at a time as packed ops on SGPR pairs
+    __device__ __forceinline__ void bary(float &w0, float &w1, float &w2, float xp, float yp) const {
+        const v2f w01 = (g2<R_I0>() * splat2(xp) + g2<R_I1>() * splat2(yp)) + g2<R_I2>();
+        w0 = w01.x; w1 = w01.y;
+        w2 = (g<R_I6>() * xp + g<R_I7>() * yp) + g<R_I8>();
+    }
+    __device__ __forceinline__ void offset(float &dx, float &dy, float t0, float t1, float t2) const {
+        const v2f d = (splat2(t0) * g2<R_X0>() + splat2(t1) * g2<R_X1>()) + splat2(t2) * g2<R_X2>();
+        dx = d.x; dy = d.y;
+    }
+    __device__ __forceinline__ int flags() const { return __float_as_int(g<R_FLAGS>()); }
+    __device__ __forceinline__ int obt() const { return (flags() & 3) - 1; }
+    __device__ __forceinline__ bool front() const { return (flags() & 32) != 0; }
+    __device__ __forceinline__ bool slow() const { return (flags() & 4) != 0; }
+    __device__ __forceinline__ bool depth_in_range() const { return (flags() & 8) != 0; }
+    __device__ __forceinline__ bool ill_conditioned() const { return (flags() & 16) != 0; }
+    __device__ __forceinline__ unsigned region_lut() const { return (unsigned)__float_as_int(g<R_LUT>()); }
 };
 
-struct FaceV : Face {   // + 15 VGPRs per lane, filled once per face by the face-major backward (a wave owns one face)
+// + 15 VGPRs per lane, filled once per face by the face-major backward (a wave owns one face for all its visits): the operands
+// of the barycentric rows and of the offset sums as VGPR copies.  On gfx950 a VALU instruction with an SGPR source issues at half
+// the rate of the same instruction on VGPRs (v_mul_f32 2.6 vs 4.2 cycles per wave-instruction); plain full-rate ops on these copies
+// measured faster in the backward than packed ops on them (dependent packed ops want a wait state in between).
+struct FaceV : Face {
     float vinv[9], vxy[6];
-    template <int I> __device__ __forceinline__ float inv() const { return vinv[I]; }
-    template <int I> __device__ __forceinline__ float xy() const { return vxy[I]; }
+    __device__ __forceinline__ void bary(float &w0, float &w1, float &w2, float xp, float yp) const {
+        w0 = (vinv[0] * xp + vinv[1] * yp) + vinv[2];
+        w1 = (vinv[3] * xp + vinv[4] * yp) + vinv[5];
+        w2 = (vinv[6] * xp + vinv[7] * yp) + vinv[8];
+    }
+    __device__ __forceinline__ void offset(float &dx, float &dy, float t0, float t1, float t2) const {
+        dx = (t0 * vxy[0] + t1 * vxy[2]) + t2 * vxy[4];
+        dy = (t0 * vxy[1] + t1 * vxy[3]) + t2 * vxy[5];
+    }
     __device__ __forceinline__ void fill() {
 #ifdef UMR_HOST_SHIM   // tests/host_kernel: the same copies without the instruction
 #define UMR_VMOV(dst, src) dst = (src)
 #else
 #define UMR_VMOV(dst, src) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(src))
 #endif
-        UMR_VMOV(vinv[0], g<R_INV + 0>()); UMR_VMOV(vinv[1], g<R_INV + 1>()); UMR_VMOV(vinv[2], g<R_INV + 2>());
-        UMR_VMOV(vinv[3], g<R_INV + 3>()); UMR_VMOV(vinv[4], g<R_INV + 4>()); UMR_VMOV(vinv[5], g<R_INV + 5>());
-        UMR_VMOV(vinv[6], g<R_INV + 6>()); UMR_VMOV(vinv[7], g<R_INV + 7>()); UMR_VMOV(vinv[8], g<R_INV + 8>());
+        UMR_VMOV(vinv[0], inv<0>()); UMR_VMOV(vinv[1], inv<1>()); UMR_VMOV(vinv[2], inv<2>());
+        UMR_VMOV(vinv[3], inv<3>()); UMR_VMOV(vinv[4], inv<4>()); UMR_VMOV(vinv[5], inv<5>());
+        UMR_VMOV(vinv[6], inv<6>()); UMR_VMOV(vinv[7], inv<7>()); UMR_VMOV(vinv[8], inv<8>());
         UMR_VMOV(vxy[0], g<R_X0>()); UMR_VMOV(vxy[1], g<R_Y0>()); UMR_VMOV(vxy[2], g<R_X1>());
         UMR_VMOV(vxy[3], g<R_Y1>()); UMR_VMOV(vxy[4], g<R_X2>()); UMR_VMOV(vxy[5], g<R_Y2>());
 #undef UMR_VMOV
@@ -278,7 +366,14 @@ struct FaceV : Face {   // + 15 VGPRs per lane, filled once per face by the face
 __device__ __forceinline__ void load_face(Face &fc, const float *rg) {
     cv16f_t *r = (cv16f_t *)rg;
     fc.qa = r[0]; fc.qb = r[1];
+    fc.qc = *(cv4f_t *)(rg + R_RZ0);
     fc.edges = (const char *)(rg + R_EDGE);
+}
+
+// the 32 wave-uniform floats again (face-major backward: keeps them loop-VARIANT, see FM_RELOAD_PER_TILE)
+__device__ __forceinline__ void reload_face(Face &fc, const float *rg) {
+    cv16f_t *r = (cv16f_t *)rg;
+    fc.qa = r[0]; fc.qb = r[1];
 }
 
 struct Pair {  // per-lane result of the pixel/face geometry
@@ -308,48 +403,43 @@ __device__ __forceinline__ float fmed3_(float a, float b, float c) {   // v_med3
 
 // bbox reject (:355), barycentric (:25-29), euclidean distance (:63-152), threshold reject (:382),
 // sigmoid (:383).  Returns false when the reference would `continue` before touching the pixel.
-template <class FaceT>
-__device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, float yp, float threshold,
-                                          float neg_inv_sigma, float amb_thr = 0.f) {
+//
+// Arithmetic: every product and sum is the reference's, in the reference's order, rounded once each (-ffp-contract=off); where
+// two of them are independent and their scalar operands sit in an aligned pair of the record they are issued as ONE packed
+// instruction (v_pk_mul_f32 / v_pk_add_f32 are per-component IEEE operations: the bits are those of the two scalar ops).
+//
+// REGION (compile time; raster kernels pick it per visit with one wave vote, see eval_pair_voted):
+//   0  lanes on both sides of the boundary: everything below
+//   1  every ACTIVE lane is inside the triangle: the outside branch (:110-151) is dead -- no region table, no override test, no
+//      clamps, no threshold reject -- the result for each lane is what REGION 0 gives it
+//   2  every ACTIVE lane is outside: the inside branch (:68-109) is dead -- no nearest-line pick, no doubt path
+template <int REGION, class FaceT>
+__device__ __forceinline__ bool eval_pair_region(Pair &p, const FaceT &fc, float xp, float yp, float w0, float w1, float w2, bool inside,
+                                                 float threshold, float neg_inv_sigma, float amb_thr) {
     // Written branch-free (predicates + selects): per-lane divergence would otherwise cost ~80 scalar
     // exec-mask instructions per face visit.  Dead lanes compute garbage that the returned predicate masks.
     const bool inb = !((xp > fc.template g<R_XHI>()) | (xp < fc.template g<R_XLO>()) | (yp > fc.template g<R_YHI>()) | (yp < fc.template g<R_YLO>()));
-    // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
-    // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
-    const float w0 = (fc.template inv<0>() * xp + fc.template inv<1>() * yp) + fc.template inv<2>();
-    const float w1 = (fc.template inv<3>() * xp + fc.template inv<4>() * yp) + fc.template inv<5>();
-    const float w2 = (fc.template inv<6>() * xp + fc.template inv<7>() * yp) + fc.template inv<8>();
-    p.w0 = w0; p.w1 = w1; p.w2 = w2;
-    const bool inside = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
-    // inside: nearest edge LINE, first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
-    // corner k+2 and its squared distance is w_c^2 K_c
-    const float m0 = w2 * w2 * fc.template g<R_K2>(), m1 = w0 * w0 * fc.template g<R_K0>(), m2 = w1 * w1 * fc.template g<R_K1>();
-    const bool c1 = m1 < m0;
-    const float best = c1 ? m1 : m0;
-    const int kin = (m2 < best) ? 2 : (c1 ? 1 : 0);
-    // outside: region selection (:112-126), lowest priority first so the highest-priority match is applied last
-    const int ob = fc.obt();
-    // obtuse corner's coordinates: a wave-uniform pick among SGPRs, written with masks so that it stays three scalar
-    // and/or ops -- as nested selects the compiler turns it into a dynamically indexed vector read, which on gfx9
-    // means copying 16 SGPRs to VGPRs (8 v_mov_b64 + s_set_gpr_idx) on every face visit
-    const int mk0 = -(int)(ob == 0), mk1 = -(int)(ob == 1), mk2 = -(int)(ob == 2);
-    const float cx = __int_as_float((__float_as_int(fc.template g<R_X0>()) & mk0) | (__float_as_int(fc.template g<R_X1>()) & mk1) |
-                                    (__float_as_int(fc.template g<R_X2>()) & mk2));
-    const float cy = __int_as_float((__float_as_int(fc.template g<R_Y0>()) & mk0) | (__float_as_int(fc.template g<R_Y1>()) & mk1) |
-                                    (__float_as_int(fc.template g<R_Y2>()) & mk2));
-    const bool ovr = (xp - cx) * fc.template g<R_OX>() + (yp - cy) * fc.template g<R_OY>() > 0;
-    // Region code m = n0 | n1 << 1 | n2 << 2 with n_k = (w_k <= 0); the reference's if-chain (:112-126) is a table of
-    // m -- single flag: opposite edge (n0 -> 1, n1 -> 2, n2 -> 0); two flags: the vertex region between them
-    // ({n0,n1} -> 2, {n2,n0} -> 1, {n1,n2} -> 0; all three -- degenerate faces only -- ends like {n1,n2}); none: -1 --
-    // plus ONE wave-uniform exception: in the vertex region of the flagged obtuse corner `ob` the other edge is taken
-    // when the pixel lies on its far side (`ovr`).  Entries are stored +1 in 2 bits each.
-    const int m = min((w0 <= 0 ? 1 : 0) | (w1 <= 0 ? 2 : 0) | (w2 <= 0 ? 4 : 0), 6);
-    constexpr unsigned KOUT_LUT = (0u << 0) | (2u << 2) | (3u << 4) | (3u << 6) | (1u << 8) | (2u << 10) | (1u << 12);
-    const int m_ob = ob == 0 ? 6 : (ob == 1 ? 5 : (ob == 2 ? 3 : -1));   // two-flag code of the obtuse corner's region
-    const int k_ob = ob == 0 ? 2 : (ob == 1 ? 0 : 1);                     // the edge its override selects
-    int kout = (int)((KOUT_LUT >> (2 * m)) & 3u) - 1;
-    kout = ((m == m_ob) & ovr) ? k_ob : kout;
-    const int ksel = inside ? kin : kout;
+    const v2f w01 = (v2f){w0, w1};
+    int ksel;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    if (REGION != 2) {
+        // inside: nearest edge LINE, first minimum in the reference's order k = 0,1,2 (:78-107); edge k is opposite
+        // corner k+2 and its squared distance is w_c^2 K_c
+        const v2f m12 = (w01 * w01) * fc.template g2<R_K0>();
+        m0 = w2 * w2 * fc.template g<R_K2>(); m1 = m12.x; m2 = m12.y;
+        const bool c1 = m1 < m0;
+        const float best = c1 ? m1 : m0;
+        ksel = (m2 < best) ? 2 : (c1 ? 1 : 0);
+    }
+    if (REGION != 1) {
+        // outside: region selection (:112-126) through the face's table (k_face_setup): index = region code m = n0 | n1 << 1 |
+        // n2 << 2 with n_k = (w_k <= 0), + 8 when the pixel lies beyond the obtuse corner's far edge (the override test)
+        const v2f pr = ((v2f){xp, yp} - fc.template g2<R_CX>()) * fc.template g2<R_OX>();   // (xp - cx) ox, (yp - cy) oy
+        const bool ovr = pr.x + pr.y > 0;
+        const int m = ((w0 <= 0 ? 1 : 0) | (w1 <= 0 ? 2 : 0)) | ((w2 <= 0 ? 4 : 0) | (ovr ? 8 : 0));
+        const int kout = (int)((fc.region_lut() >> (2 * m)) & 3u) - 1;
+        ksel = REGION == 2 ? kout : (inside ? ksel : kout);
+    }
     const bool kvalid = ksel >= 0;  // k = -1: reference UB (index -1); defined here and in the oracle as "skip"
     // t[v0] = (w . a - a[v1]) / (a[v0] - a[v1]) in the reference's operation order (:86,:137); IEEE-exact
     // quotient through Markstein's correction.  Far from the silhouette the soft-max renormalises weights
@@ -362,7 +452,7 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
         // den = 0 (see below): the IEEE quotient is +-inf (NaN for 0 / 0); Markstein's correction would turn inf into NaN
         return fabsf(eb.y) <= 3.0e38f ? div_r(num, eb.x, eb.y) : num * eb.y;
     };
-    int k = max(ksel, 0);
+    int k = REGION == 1 ? ksel : max(ksel, 0);
     float tv = edge_param(k);
     // An edge whose screen-space length is below ~3e-4 (an edge seen end-on) loses its squared length in the cancellation of
     // :82-84 -- den comes out as exactly 0 about every second time, as noise otherwise -- and t[v0] is inf, NaN or garbage.
@@ -379,7 +469,7 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
     // the next one beyond 20 sigma leaves a gap of 2.6 sigma ~ 0.1 px at the band's edge, two orders above the noise of the
     // computed distances of faces that are not flagged thin.
     bool no_edge = false;
-    if (fc.ill_conditioned() | (amb_thr > 0.f)) {          // wave-uniform: the default build pays nothing for unflagged faces
+    if (REGION != 2 && (fc.ill_conditioned() | (amb_thr > 0.f))) {          // wave-uniform: the default build pays nothing for unflagged faces
         const bool doubt = inside & (fc.ill_conditioned() | (fmed3_(m0, m1, m2) < amb_thr));
         if (doubt) {
             float dmin = 100000000.f;
@@ -391,8 +481,8 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
                 const float c0 = kk == 0 ? tk : (kk == 1 ? 0.f : uk), c1 = kk == 0 ? uk : (kk == 1 ? tk : 0.f),
                             c2 = kk == 0 ? 0.f : (kk == 1 ? uk : tk);
                 const float s0 = c0 - w0, s1 = c1 - w1, s2 = c2 - w2;
-                const float ex = (s0 * fc.template xy<0>() + s1 * fc.template xy<2>()) + s2 * fc.template xy<4>();
-                const float ey = (s0 * fc.template xy<1>() + s1 * fc.template xy<3>()) + s2 * fc.template xy<5>();
+                float ex, ey;
+                fc.offset(ex, ey, s0, s1, s2);
                 const float dk = ex * ex + ey * ey;
                 if (dk < dmin) { dmin = dk; kb = kk; tbest = tk; }
             }
@@ -403,24 +493,53 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
     }
     const bool k0 = k == 0, k1 = k == 1;
     const float tb = 1.f - tv;
-    const float ba = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f);  // unclamped inside (:86-88), clamped outside (:142-145)
-    const float bb = inside ? tb : fminf(fmaxf(tb, 0.f), 1.f);
+    float ba, bb;
+    if (REGION == 1) { ba = tv; bb = tb; }                                            // unclamped inside (:86-88)
+    else if (REGION == 2) { ba = fminf(fmaxf(tv, 0.f), 1.f); bb = fminf(fmaxf(tb, 0.f), 1.f); }   // clamped outside (:142-145)
+    else { ba = inside ? tv : fminf(fmaxf(tv, 0.f), 1.f); bb = inside ? tb : fminf(fmaxf(tb, 0.f), 1.f); }
     float b0 = k0 ? ba : (k1 ? 0.f : bb);
     float b1 = k0 ? bb : (k1 ? ba : 0.f);
     float b2 = k0 ? 0.f : (k1 ? bb : ba);
-    if (no_edge) { b0 = w0; b1 = w1; b2 = w2; }   // closest point := the pixel itself -> dis_x = dis_y = 0
+    if (REGION != 2 && wave_any(no_edge)) {   // (degenerate faces only) closest point := the pixel itself -> dis_x = dis_y = 0
+        UMR_KEEP_BRANCH();
+        b0 = no_edge ? w0 : b0; b1 = no_edge ? w1 : b1; b2 = no_edge ? w2 : b2;
+    }
     const float t0 = b0 - w0, t1 = b1 - w1, t2 = b2 - w2;
-    const float dx = (t0 * fc.template xy<0>() + t1 * fc.template xy<2>()) + t2 * fc.template xy<4>();  // :95-96, :148-149
-    const float dy = (t0 * fc.template xy<1>() + t1 * fc.template xy<3>()) + t2 * fc.template xy<5>();
+    float dx, dy;
+    fc.offset(dx, dy, t0, t1, t2);  // :95-96, :148-149
     const float dis = dx * dx + dy * dy;
     // the gradient's barycentrics are the reference's `t[k] + w[k]` (:640) with t[k] = b_k - w_k already rounded: for an
     // ordinary face that is b_k to an ulp, for a degenerate one (|w| ~ 1e9) whatever survives the cancellation -- like there
     p.b0 = t0 + w0; p.b1 = t1 + w1; p.b2 = t2 + w2; p.dx = dx; p.dy = dy;
-    p.sign = inside ? 1.f : -1.f;
+    const bool in_ = REGION == 1 ? true : (REGION == 2 ? false : inside);
+    p.sign = in_ ? 1.f : -1.f;
     // 1 / (1 + exp(-sign * dis / sigma))
-    const float e = __expf((inside ? dis : -dis) * neg_inv_sigma);
+    const float e = __expf((in_ ? dis : -dis) * neg_inv_sigma);
     p.frag = __builtin_amdgcn_rcpf(1.f + e);
-    return inb & kvalid & (inside | !(dis >= threshold));  // rejects of :355, :382
+    if (REGION == 1) return inb;
+    return inb & kvalid & (in_ | !(dis >= threshold));  // rejects of :355, :382
+}
+
+// `active`: the lanes whose result the caller will use (a valid pixel of the tile / sub-tile); the others may hold anything.
+// One wave vote picks the specialised body when all active lanes lie on one side of the face's boundary.
+template <class FaceT>
+__device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, float yp, float threshold,
+                                          float neg_inv_sigma, float amb_thr = 0.f, bool active = true) {
+    // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
+    // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
+    float w0, w1, w2;
+    fc.bary(w0, w1, w2, xp, yp);
+    p.w0 = w0; p.w1 = w1; p.w2 = w2;
+    // 0 < w_k < 1 for all k (:68-69) on the bit patterns: a float in (0, 1) is an integer in [1, 0x3f7fffff]; zeros, negatives
+    // (sign bit), 1.0 and above, infinities and NaNs of either sign all fall outside after the wrapping decrement.  Three
+    // full-rate subtractions, one three-operand max and one compare instead of six compares and five mask ANDs.
+    const unsigned u0 = (unsigned)__float_as_int(w0) - 1u, u1 = (unsigned)__float_as_int(w1) - 1u, u2 = (unsigned)__float_as_int(w2) - 1u;
+    const bool inside = max(max(u0, u1), u2) < 0x3f7fffffu;
+#if UMR_REGION_VOTE
+    if (wave_all(inside | !active)) return eval_pair_region<1>(p, fc, xp, yp, w0, w1, w2, true, threshold, neg_inv_sigma, amb_thr);
+    if (!wave_any(inside & active)) return eval_pair_region<2>(p, fc, xp, yp, w0, w1, w2, false, threshold, neg_inv_sigma, amb_thr);
+#endif
+    return eval_pair_region<0>(p, fc, xp, yp, w0, w1, w2, inside, threshold, neg_inv_sigma, amb_thr);
 }
 
 // barycentric_clip (:54-59) + perspective-correct depth (:403).  The soft-max weights are exp(zn/gamma) with
@@ -455,21 +574,21 @@ __device__ __forceinline__ int texel_index(float c0, float c1, int R) {  // :180
 // point is at least that far), so it is rejected at :382.  w_c is affine in the pixel position, so its maximum
 // over the tile is w_c(centre) + hx |dw_c/dx| + hy |dw_c/dy|; signed distance = w_c * h_c with h_c^2 = K_c.
 // NaN / degenerate faces (K_c = 0) never cull.  1e-3 (in barycentric units) absorbs rounding.
-__device__ __forceinline__ bool tile_may_hit(const float4 i0, const float4 i1, const float4 i2, float cx, float cy,
+__device__ __forceinline__ bool tile_may_hit(const float4 q0, const float4 q1, const float4 q2, float cx, float cy,
                                              float hx, float hy, float thr) {
-    // i0 = inv[0..3], i1 = inv[4..7], i2 = {inv[8], K0, K1, K2}
-    const float w0 = fmaf(i0.x, cx, fmaf(i0.y, cy, i0.z)) + (hx * fabsf(i0.x) + hy * fabsf(i0.y));
-    const float w1 = fmaf(i0.w, cx, fmaf(i1.x, cy, i1.y)) + (hx * fabsf(i0.w) + hy * fabsf(i1.x));
-    const float w2 = fmaf(i1.z, cx, fmaf(i1.w, cy, i2.x)) + (hx * fabsf(i1.z) + hy * fabsf(i1.w));
+    // the record's floats [R_I0, R_I0 + 12): q0 = {inv0, inv3, inv1, inv4}, q1 = {inv2, inv5, inv6, inv7}, q2 = {inv8, K2, K0, K1}
+    const float w0 = fmaf(q0.x, cx, fmaf(q0.z, cy, q1.x)) + (hx * fabsf(q0.x) + hy * fabsf(q0.z));
+    const float w1 = fmaf(q0.y, cx, fmaf(q0.w, cy, q1.y)) + (hx * fabsf(q0.y) + hy * fabsf(q0.w));
+    const float w2 = fmaf(q1.z, cx, fmaf(q1.w, cy, q2.x)) + (hx * fabsf(q1.z) + hy * fabsf(q1.w));
     // `thr` = sqrt(threshold) + the face's R_CULL: the reference decides the threshold reject (:382) on ITS computed distance, so
     // the band has to be wider than the exact one by that distance's rounding noise (k_face_setup).
-    const bool out = w0 < -(thr * __frsqrt_rn(i2.y)) - 1e-3f || w1 < -(thr * __frsqrt_rn(i2.z)) - 1e-3f ||
-                     w2 < -(thr * __frsqrt_rn(i2.w)) - 1e-3f;
+    const bool out = w0 < -(thr * __frsqrt_rn(q2.z)) - 1e-3f || w1 < -(thr * __frsqrt_rn(q2.w)) - 1e-3f ||
+                     w2 < -(thr * __frsqrt_rn(q2.y)) - 1e-3f;
     // A face one of whose heights is below ~3e-5 screen units (a sliver, a needle, a face seen edge-on) is not culled beyond
     // its bounding box: its barycentrics carry rounding noise of the size of this very test, and what the reference's
     // arithmetic makes of such a face (soft fragments up to 0.5 along its line) follows that noise, not the geometry.
     // (Found by fuzzing this source on the host, tests/test_kernel_source_on_host.py.)
-    const bool sliver = !((i2.y >= 1e-9f) & (i2.z >= 1e-9f) & (i2.w >= 1e-9f));
+    const bool sliver = !((q2.z >= 1e-9f) & (q2.w >= 1e-9f) & (q2.y >= 1e-9f));
     return sliver | !out;
 }
 

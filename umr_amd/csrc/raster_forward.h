@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                 const float4 bb = bbox_n[fcand];
                 hit = !(t.wxlo > bb.y || t.wxhi < bb.x || t.wylo > bb.w || t.wyhi < bb.z);
                 if (hit) {  // one lane per candidate face: exact-ish tile/triangle test
-                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_INV);
+                    const float4 *q = (const float4 *)(rec_n + (size_t)fcand * REC + R_I0);
                     hit = tile_may_hit(q[0], q[1], q[2], 0.5f * (t.wxlo + t.wxhi), 0.5f * (t.wylo + t.wyhi),
                                        0.5f * (t.wxhi - t.wxlo), 0.5f * (t.wyhi - t.wylo), A.thr + rec_n[(size_t)fcand * REC + R_CULL]);
                 }
@@ -78,9 +78,8 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     // z-buffer winner only (:408-411): needs the bbox test, the barycentrics, the depth -- no distance.
                     // A pixel inside [0,1]^3 is never rejected by the distance threshold (inside: sign > 0; on the
                     // boundary: d = 0), except the defined-as-skip k = -1 case (no w <= 0 yet some w >= 1).
-                    const float w0 = (fc.g<R_INV + 0>() * t.xp + fc.g<R_INV + 1>() * t.yp) + fc.g<R_INV + 2>();
-                    const float w1 = (fc.g<R_INV + 3>() * t.xp + fc.g<R_INV + 4>() * t.yp) + fc.g<R_INV + 5>();
-                    const float w2 = (fc.g<R_INV + 6>() * t.xp + fc.g<R_INV + 7>() * t.yp) + fc.g<R_INV + 8>();
+                    float w0, w1, w2;
+                    fc.bary(w0, w1, w2, t.xp, t.yp);
                     const bool inb = !((t.xp > fc.g<R_XHI>()) | (t.xp < fc.g<R_XLO>()) | (t.yp > fc.g<R_YHI>()) | (t.yp < fc.g<R_YLO>()));
                     const bool incl = (w0 <= 1) & (w0 >= 0) & (w1 <= 1) & (w1 >= 0) & (w2 <= 1) & (w2 >= 0);
                     const bool strict = (w0 > 0) & (w1 > 0) & (w2 > 0) & (w0 < 1) & (w1 < 1) & (w2 < 1);
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     continue;
                 }
                 Pair p;
-                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr) & t.valid;
+                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr, t.valid) & t.valid;
                 if (RGB == 2) {
                     alpha *= live ? 1.f - p.frag : 1.f;
                     continue;
