@@ -53,6 +53,9 @@ def parse():
                     help="s1 = BASELINE configs[1] (headline); s2 = train_s2 sequence of configs[2]/[3] (8 camera hypotheses)")
     ap.add_argument("--epoch", type=int, default=0, help="train_s1 epoch (gates the symmetry / deformation terms)")
     ap.add_argument("--profile-steps", type=int, default=5, help="untimed steps with kernel events for `roofline`")
+    ap.add_argument("--share-mask-render", type=int, default=1,
+                    help="1: the mask render is the alpha channel of the textured render of the same views (one render where the "
+                         "reference makes two); 0: both renders, for A/B")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
     ap.add_argument("--graph", type=int, default=0,
                     help="capture the step in ONE HIP graph and time graph replays instead of eager launches: with --model 0 the "
@@ -130,7 +133,17 @@ def main():
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(args.master_port or 29511))
+        if "MASTER_PORT" not in os.environ:
+            if args.master_port > 0:
+                os.environ["MASTER_PORT"] = str(args.master_port)
+            elif world == 1:            # --force-ddp outside a launcher: a port that is free right now, not a fixed one
+                import socket
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            else:                       # several ranks cannot agree on a random port by themselves
+                raise SystemExit("bench.py: WORLD_SIZE=%d but no MASTER_PORT in the environment: start the ranks with torchrun / "
+                                 "`python bench.py --gpus N` (which picks a free port), or pass --master-port" % world)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" = RCCL on ROCm
 
     from umr_amd import _lib
@@ -156,7 +169,7 @@ def main():
     else:
         from umr_amd.perceptual import PerceptualTextureLoss
         rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size, texture_loss=PerceptualTextureLoss(dev),
-                             epoch=args.epoch).to(dev)
+                             epoch=args.epoch, share_mask_render=bool(args.share_mask_render)).to(dev)
         leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
 
         last_terms = {}
@@ -419,13 +432,15 @@ def main():
     net_note = ("; MeshNet fwd/bwd + %sAdam" % ("RCCL gradient all-reduce over %d ranks + " % world if world > 1 else "")
                 if use_model else "; network excluded")
     if args.workload == "s1":
-        wl = ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: 4 raster fwd + 3 bwd per image (mask + "
-              "unseen-view silhouettes in one launch, textured soft-max render with p2f carrying the hard visibility render) + IoU / AlexNet-perceptual "
+        wl = ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: the reference's 4 raster fwd + 3 bwd per image as 2 fwd + 3 bwd "
+              "launches (textured soft-max render with p2f whose alpha channel IS the mask render and whose visits carry the hard "
+              "visibility render; unseen-view silhouette) + IoU / AlexNet-perceptual "
               "texture / texture-dt / tex-cycle / Laplacian / flatten / GAN losses, fwd+bwd, epoch %d%s"
               % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], args.epoch, net_note))
     else:
-        wl = ("train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: 20 raster fwd + 19 bwd per "
-              "image (8 mask, 8 texture, 1 visibility, 1 unseen view, 2 part renders carrying the reference's 4) + mask / "
+        wl = ("train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: the reference's 22 raster fwd + 21 bwd per "
+              "image as 12 fwd + 19 bwd (8 textured hypothesis renders whose alpha channels are the 8 mask renders, 1 visibility, 1 unseen "
+              "view, 2 part renders carrying the reference's 4) + mask / "
               "AlexNet-perceptual texture / tex-cycle / part / chamfer losses, fwd+bwd%s"
               % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], net_note))
 

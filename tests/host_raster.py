@@ -97,7 +97,8 @@ class emulated_product:
                 self._by_name.append(mod)
         self._orig_ptr = orig_ptr
         if not emulated_product._ops_registered:
-            for op in (ops.soft_rasterize_op, ops.soft_rasterize_backward_op, ops.silhouette_op, ops.silhouette_backward_op):
+            for op in (ops.soft_rasterize_op, ops.soft_rasterize_backward_op, ops.silhouette_op, ops.silhouette_backward_op,
+                       ops.soft_rasterize_alpha_geometry_op):
                 op.register_kernel("cpu")(op._init_fn)
             emulated_product._ops_registered = True
         return self

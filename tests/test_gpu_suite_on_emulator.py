@@ -98,3 +98,30 @@ def test_gpu_test_on_the_emulated_library(emulated, oracle_built, tmp_path, mod_
         fn(**kw)
     finally:
         mod.DEV = saved
+
+
+def test_shared_mask_render_equals_the_two_renders_on_the_emulator():
+    """RenderCompareS1 / S2 with share_mask_render (the mask render = the alpha channel of the textured render of the same views,
+    SoftRenderer.forward(detach_rgb_geometry=True)) against the two renders the reference makes (train_s1.py:199 + :217,
+    loss_utils.py:265 + :313): the alpha planes are the same bits, each gradient comes from the same kernel on the same
+    inputs -- every loss term is EQUAL, not close; the gradients are sums of the same per-view contributions accumulated in
+    another order (one 2B-view launch against two B-view launches feeding the projection's backward): equal to rounding."""
+    import torch
+    from tests.host_raster import emulated_product
+    from umr_amd.synthetic import make_s1_inputs
+    from umr_amd.train_step import RenderCompareS1
+    B, H = 2, 32
+    with emulated_product():
+        tv, faces, outputs, batch = make_s1_inputs(B, H, 1, seed=5, device="cpu")
+        res = []
+        for share in (True, False):
+            rc = RenderCompareS1(tv, faces, H, share_mask_render=share)
+            leaves = [outputs[k].detach().clone().requires_grad_(True) for k in ("delta_v", "cam", "tex_flow")]
+            out = dict(outputs, delta_v=leaves[0], cam=leaves[1], tex_flow=leaves[2])
+            out["pred_vs"] = outputs["mean_shape"][None] + leaves[0]
+            total, terms = rc(out, batch)
+            total.backward()
+            res.append((float(total), {k: float(v) for k, v in terms.items()}, [l.grad.clone() for l in leaves]))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    for a, b in zip(res[0][2], res[1][2]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())

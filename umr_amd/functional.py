@@ -57,13 +57,17 @@ class SoftRasterizeFunction:
       need_p2f:   False skips the p2f accumulators (returned as zeros)
       want_visibility: a 4th output [N,2,IS,IS] = the aggrs_info of the 'hard' render of the same faces (nearest depth, its
                   face id | -1), produced by the same kernel visits (soft-max colour only)
+      detach_rgb_geometry: the colour channels see face_vertices DETACHED (their gradient reaches the textures only) while the
+                  alpha channel keeps its gradient to face_vertices: ONE render where the reference renders the same views
+                  twice, for the mask and -- with detached vertices -- for the texture term (torch.ops.umr.
+                  soft_rasterize_alpha_geometry)
     """
 
     @staticmethod
     def apply(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
               fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
               gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-              pool=False, need_p2f=True, want_visibility=False):
+              pool=False, need_p2f=True, want_visibility=False, detach_rgb_geometry=False):
         from . import ops  # noqa: F401  (registers torch.ops.umr.*)
         _check_raster_shapes(face_vertices, textures)
         modes = ops.pack_modes(_FUNC_RGB[aggr_func_rgb], _FUNC_DIST[dist_func], _FUNC_ALPHA[aggr_func_alpha],
@@ -77,7 +81,10 @@ class SoftRasterizeFunction:
             raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % face_vertices.device)
         if want_visibility and modes != 1:
             raise RuntimeError("soft_rasterize: want_visibility needs aggr_func_rgb='softmax' with UMR's own modes")
-        image, p2f, aggrs, _, vis = torch.ops.umr.soft_rasterize(
+        if detach_rgb_geometry and modes != 1:
+            raise RuntimeError("soft_rasterize: detach_rgb_geometry needs aggr_func_rgb='softmax' with UMR's own modes")
+        op = torch.ops.umr.soft_rasterize_alpha_geometry if detach_rgb_geometry else torch.ops.umr.soft_rasterize
+        image, p2f, aggrs, _, vis = op(
             face_vertices, textures, int(image_size), [float(c) for c in background_color], float(near), float(far),
             bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), modes, bool(pool), bool(need_p2f),
             bool(want_visibility))
@@ -124,7 +131,7 @@ def visibility(face_vertices, image_size, near=1., far=100., fill_back=True, eps
 def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-                   pool=False, need_p2f=True, want_visibility=False):
+                   pool=False, need_p2f=True, want_visibility=False, detach_rgb_geometry=False):
     """Same signature and return as soft_renderer.functional.soft_rasterize
     (functional/soft_rasterize.py:111-125): (soft_colors [N,4,IS,IS], p2f_info [N,F,2], aggrs_info)."""
     if not _lib.on_device(face_vertices):
@@ -132,7 +139,8 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
         raise TypeError('Rasterize module supports only GPU (ROCm) tensors')
     return SoftRasterizeFunction.apply(face_vertices, textures, image_size, background_color, near, far,
                                        fill_back, eps, sigma_val, dist_func, dist_eps, gamma_val,
-                                       aggr_func_rgb, aggr_func_alpha, texture_type, pool, need_p2f, want_visibility)
+                                       aggr_func_rgb, aggr_func_alpha, texture_type, pool, need_p2f, want_visibility,
+                                       detach_rgb_geometry)
 
 
 class ProjectFacesFunction(Function):

@@ -66,14 +66,19 @@ class MultiMaskLoss(nn.Module):
         self.num_hypo_cams = num_hypo_cams
         self.image_size = image_size
 
-    def forward(self, vs, fs, cams_all_hypo, cam_probs, masks_gt):
+    def forward(self, vs, fs, cams_all_hypo, cam_probs, masks_gt, rendered_masks=None):
+        """rendered_masks [B*K,H,H]: the alpha channel of a render of the same views that keeps its gradient to vs and
+        cams_all_hypo (MultiTextureLoss.render_views) -- the mask render (:265) is then not repeated."""
         bs = vs.size(0)
         K = self.num_hypo_cams
-        # the reference materialises vs / fs K times (:260-262); here the K hypotheses of image b are views
-        # b*K .. b*K+K-1 of mesh b (mesh_group indexing in the projection kernel), gradients summed over them
-        cams_all_hypo_flat = cams_all_hypo.view(-1, 7)
-        pred, _, _ = self.renderer.forward(vs, fs, cams_all_hypo_flat)
-        mask_all_hypo = pred[:, 3, :, :]
+        if rendered_masks is not None:
+            mask_all_hypo = rendered_masks
+        else:
+            # the reference materialises vs / fs K times (:260-262); here the K hypotheses of image b are views
+            # b*K .. b*K+K-1 of mesh b (mesh_group indexing in the projection kernel), gradients summed over them
+            cams_all_hypo_flat = cams_all_hypo.view(-1, 7)
+            pred, _, _ = self.renderer.forward(vs, fs, cams_all_hypo_flat)
+            mask_all_hypo = pred[:, 3, :, :]
         masks = masks_gt.unsqueeze(1).repeat(1, K, 1, 1).view(-1, self.image_size, self.image_size)
         loss = neg_iou_loss(mask_all_hypo, masks, avg=False)
         loss = loss.view(bs, -1) * cam_probs
@@ -203,13 +208,22 @@ class MultiTextureLoss(nn.Module):
         self.num_hypo_cams = num_hypo_cams
         self.image_size = image_size
 
+    def render_views(self, vs, fs, cams_all_hypo, tx):
+        """The textured render of all B*K hypothesis views (:313) as the ONE render of those views in the step: colour
+        channels with the geometry detached, as the reference passes it (vs.detach(), cams.detach()), alpha channel with
+        its gradient to vs and cams_all_hypo -- which makes it MultiMaskLoss's render (:265) as well (same meshes, same
+        cameras, same rasterizer settings; alpha depends on neither textures nor lighting).  -> [B*K,4,H,H]"""
+        return self.renderer.forward(vs, fs, cams_all_hypo.view(-1, 7), tx, detach_rgb_geometry=True)[0]
+
     def forward(self, vs, fs, cams_all_hypo, cam_probs, proj_cam, rgbs, masks_gt, masks_pred, tx, tex_flow,
-                dts_barrier):
+                dts_barrier, texture_rgba=None):
+        """texture_rgba: the result of render_views() when the caller shares that render with the mask term."""
         bs, K = vs.size(0), self.num_hypo_cams
-        # :303-306 repeats vertices, faces and the [B,F,36,3] texels K times (70 MB at B*K = 128); folded into
-        # mesh / texture group indexing of the kernels instead
-        cams_all_hypo_flat = cams_all_hypo.view(-1, 7)
-        texture_rgba, _, _ = self.renderer.forward(vs.detach(), fs, cams_all_hypo_flat, tx)
+        if texture_rgba is None:
+            # :303-306 repeats vertices, faces and the [B,F,36,3] texels K times (70 MB at B*K = 128); folded into
+            # mesh / texture group indexing of the kernels instead
+            cams_all_hypo_flat = cams_all_hypo.view(-1, 7)
+            texture_rgba, _, _ = self.renderer.forward(vs.detach(), fs, cams_all_hypo_flat, tx)
         texture_pred = texture_rgba[:, 0:3, :, :]
         imgs = rgbs.unsqueeze(1).repeat(1, K, 1, 1, 1).view(-1, 3, self.image_size, self.image_size)
         masks_gt = masks_gt.unsqueeze(1).repeat(1, K, 1, 1).view(-1, self.image_size, self.image_size)

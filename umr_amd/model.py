@@ -412,7 +412,8 @@ def build_training_step(tv, faces, args, dev, world):
     # backward per step); random weights offline, frozen (requires_grad False) and therefore not in the optimizer
     from .perceptual import PerceptualTextureLoss
     rc = RenderCompareS1(net.get_mean_shape().detach(), net.faces, args.image_size, discriminator=ddp_disc,
-                         texture_loss=PerceptualTextureLoss(dev), epoch=getattr(args, "epoch", 0)).to(dev)
+                         texture_loss=PerceptualTextureLoss(dev), epoch=getattr(args, "epoch", 0),
+                         share_mask_render=bool(getattr(args, "share_mask_render", 1))).to(dev)
     # same update rule as train_utils.py:186-187; `fused` runs it as one multi-tensor kernel on the GPU
     # capturable: the step is going to be captured into ONE HIP graph (bench.py --graph 1) -- the learning rate and the step
     # counter then live on the device and the schedule below is device arithmetic inside the graph
@@ -469,7 +470,8 @@ def build_training_step_s2(args, dev, world):
     rc = RenderCompareS2(net.get_mean_shape().detach(), net.faces, ex["part_vertex_ids"], ex["uv_img"],
                          net.uv_sampler, args.image_size, opts.num_hypo_cams, texture_loss_type="perceptual",
                          discriminator=ddp_disc, tex_size=opts.tex_size,
-                         num_sym_faces=net.texture_predictor.num_sym_faces).to(dev)      # train_s2.py:154-161
+                         num_sym_faces=net.texture_predictor.num_sym_faces,
+                         share_mask_render=bool(getattr(args, "share_mask_render", 1))).to(dev)      # train_s2.py:154-161
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
                            betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))
     mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)

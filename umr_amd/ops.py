@@ -59,11 +59,9 @@ def _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_v
             float(gamma_val), rgb, alpha, tex, 1 if fill_back else 0)
 
 
-@custom_op("umr::soft_rasterize", mutates_args=(), device_types="cuda")
-def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
-                      near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
-                      gamma_val: float, modes: int, pool: bool, need_p2f: bool, want_visibility: bool
-                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+def _raster_forward(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps,
+                    gamma_val, modes, pool, need_p2f, want_visibility):
+    """Body of umr::soft_rasterize and umr::soft_rasterize_alpha_geometry: one umr_raster_forward_vis call."""
     from .functional import standard_grid
     L = _lib.lib()
     dev = face_vertices.device
@@ -100,15 +98,26 @@ def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image
             (vis if want_visibility else soft_colors.new_empty(0)))
 
 
-@soft_rasterize_op.register_fake
-def _(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes,
-      pool, need_p2f, want_visibility):
+@custom_op("umr::soft_rasterize", mutates_args=(), device_types="cuda")
+def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
+                      near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
+                      gamma_val: float, modes: int, pool: bool, need_p2f: bool, want_visibility: bool
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    return _raster_forward(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps,
+                           gamma_val, modes, pool, need_p2f, want_visibility)
+
+
+def _raster_fake(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes,
+                 pool, need_p2f, want_visibility):
     N, F = face_vertices.shape[:2]
     IS = int(image_size)
     S = IS // 2 if pool else IS
     f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
     return (f(N, 4, S, S), f(N, F, 2), f(N, 2, IS, IS), (f(N, 4, IS, IS) if pool else f(0)),
             (f(N, 2, IS, IS) if want_visibility else f(0)))
+
+
+soft_rasterize_op.register_fake(_raster_fake)
 
 
 @custom_op("umr::soft_rasterize_backward", mutates_args=(), device_types="cuda")
@@ -234,3 +243,41 @@ def _sil_backward(ctx, g_out, g_saved):
 
 
 silhouette_op.register_autograd(_sil_backward, setup_context=_sil_setup)
+
+
+# ------------------------------------------------------------------------- one render for the mask AND the texture term
+# train_s1.py:199 / :217 and loss_utils.py:265 / :313 render the SAME meshes from the SAME cameras twice: once for the mask
+# (only alpha is read; gradients go to vertices and cameras) and once textured with vertices and cameras DETACHED (gradients go
+# to the texels only).  Alpha depends on neither textures nor lighting, and the two kernels compute it with the same arithmetic
+# in the same face order, so the alpha channel of the textured render IS the mask render, bit for bit
+# (tests/test_gpu_round2.py::test_raster_flags_and_fused_pool).  This operator is that one render with the reference's gradient
+# routing: d(alpha) -> face_vertices through the silhouette backward, d(rgb) -> textures through the texel-gradient backward; the
+# colour channels' dependence on the geometry is cut, exactly as `.detach()` cuts it in the reference.
+@custom_op("umr::soft_rasterize_alpha_geometry", mutates_args=(), device_types="cuda")
+def soft_rasterize_alpha_geometry_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
+                                     near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
+                                     gamma_val: float, modes: int, pool: bool, need_p2f: bool, want_visibility: bool
+                                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    if int(modes) != 1:
+        raise RuntimeError("soft_rasterize_alpha_geometry: soft-max colour with UMR's own modes only")
+    return _raster_forward(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps,
+                           gamma_val, modes, pool, need_p2f, want_visibility)
+
+
+soft_rasterize_alpha_geometry_op.register_fake(_raster_fake)
+
+
+def _raster_ag_backward(ctx, g_image, g_p2f, g_aggrs, g_saved, g_vis):
+    fv, tex, soft_colors, aggrs = ctx.saved_tensors
+    image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool = ctx.cfg
+    need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    gf = gt = None
+    if need_gf:      # alpha -> geometry: the mask render's backward on this render's alpha plane
+        gf = torch.ops.umr.silhouette_backward(fv, soft_colors[:, 3].contiguous(), g_image[:, 3].contiguous(), image_size, near, far,
+                                               fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
+    if need_gt:      # rgb -> texels only
+        _, gt = torch.ops.umr.soft_rasterize_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg, False, True)
+    return (gf, gt) + (None,) * 13
+
+
+soft_rasterize_alpha_geometry_op.register_autograd(_raster_ag_backward, setup_context=_raster_setup)

@@ -73,7 +73,7 @@ class SoftRenderer(torch.nn.Module):
         return UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
                                            self.dist_eps, self.gamma_val, self.anti_aliasing)
 
-    def forward(self, vertices, faces, cams, textures=None, with_visibility=False):
+    def forward(self, vertices, faces, cams, textures=None, with_visibility=False, detach_rgb_geometry=False):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
         textures None | [N,F,TS,3].
         K camera hypotheses per mesh without the reference's x K repeats (loss_utils.py:260-262, 303-306): pass
@@ -81,7 +81,11 @@ class SoftRenderer(torch.nn.Module):
         (view n = mesh n // K); outputs are per view, gradients come back summed over the K views.
         with_visibility (soft-max renders): a 4th return value, the aggrs_info [N,2,IS,IS] = (nearest depth, face id | -1) a
         SoftRenderer(img_size, 'hard') would return for the same mesh and cameras -- train_s1.py:217-224 renders both; here
-        the z-buffer falls out of the textured render's own kernel visits."""
+        the z-buffer falls out of the textured render's own kernel visits.
+        detach_rgb_geometry (soft-max renders with ambient-only lighting): gradients of imgs[:, 0:3] reach the textures only,
+        as if vertices and cams had been passed detached, while imgs[:, 3] keeps its gradient to vertices and cams -- the mask
+        render (train_s1.py:199, loss_utils.py:265) and the textured render of the same views with detached geometry (:217,
+        :313) as ONE render."""
         faces = faces.int().contiguous()                                  # smr.py:81
         N = cams.shape[0]
         if self.ids_only and self.render_type == 'hard':
@@ -98,6 +102,9 @@ class SoftRenderer(torch.nn.Module):
             imgs = torch.cat([bg, alpha.unsqueeze(1)], dim=1)
             return imgs, alpha.new_zeros(N, faces.shape[1], 2), None
         directional = self.light_intensity_directional != 0
+        if detach_rgb_geometry and (directional or self.render_type != 'softmax'):
+            raise RuntimeError("detach_rgb_geometry: soft-max renders with ambient-only lighting (the per-face directional "
+                               "light depends on the vertices)")
         # lighting.py:50-57: with a directional term the per-face light comes out of the projection kernel (normals of
         # the projected faces); ambient-only lighting is a constant factor
         light = (self.light_intensity_ambient, self.light_intensity_directional, self.light_color,
@@ -126,4 +133,5 @@ class SoftRenderer(torch.nn.Module):
         return UF.soft_rasterize(face_out, textures, size, self.background_color, self.near, self.far, True,
                                  self.eps, self.sigma_val, 'euclidean', self.dist_eps, self.gamma_val,
                                  self.render_type, 'prod', 'surface', pool=self.anti_aliasing,
-                                 need_p2f=self.need_p2f, want_visibility=with_visibility)
+                                 need_p2f=self.need_p2f, want_visibility=with_visibility,
+                                 detach_rgb_geometry=detach_rgb_geometry)

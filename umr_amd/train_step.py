@@ -80,8 +80,11 @@ class RenderCompareS1(nn.Module):
     """
 
     def __init__(self, template_verts, faces, image_size=256, renderer_type="softmax", weights=None,
-                 texture_loss=None, discriminator=None, epoch=0):
+                 texture_loss=None, discriminator=None, epoch=0, share_mask_render=True):
         super().__init__()
+        # True: the mask render (:199) is the alpha channel of the textured render (:217) of the same meshes and cameras
+        # (SoftRenderer.forward(detach_rgb_geometry=True)) instead of a render of its own; False: two renders, as written there
+        self.share_mask_render = share_mask_render
         self.w = weights or S1Weights()
         self.image_size = image_size
         self.register_buffer("faces", faces.long())
@@ -115,27 +118,34 @@ class RenderCompareS1(nn.Module):
         B = pred_vs.shape[0]
         faces = self.faces[None].expand(B, -1, -1)
         terms = {}
-        # shape losses (:199-206).  The mask render (:199) and the unseen-view render of the adversarial term (:235) draw
-        # the same meshes with the same renderer settings and only their alpha is read (:200, :236, :242): they run as
-        # ONE silhouette launch over 2B views (view 2b = predicted camera, 2b+1 = rotated camera of image b), forward
-        # and backward -- at B = 16 a single N = 16 launch leaves a third of the chip idle in its tail
+        # shape losses (:199-206).  Of the mask render (:199) and the unseen-view render of the adversarial term (:235) only
+        # alpha is read (:200, :236, :242).  share_mask_render = False runs them as ONE silhouette launch over 2B views (view
+        # 2b = predicted camera, 2b+1 = rotated camera of image b), forward and backward
         random_cams = rotate_cam_y(proj_cam.detach(), batch["gan_angles"])                        # :232-233
-        both = self.renderer.silhouettes(pred_vs, faces, torch.stack((proj_cam, random_cams), dim=1).reshape(2 * B, 7))
-        both = both.view(B, 2, both.shape[-2], both.shape[-1])
-        mask_pred_seen, mask_pred_unseen = both[:, 0], both[:, 1]
-        terms["mask"] = loss_utils.neg_iou_loss(mask_pred_seen, masks)
-        terms["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
-        terms["flatten"] = self.flatten_loss_fn(pred_vs).mean()
-        terms["deform"] = loss_utils.deform_l2reg(delta_v)
-        terms["ori"] = loss_utils.sym_reg(pred_vs)
         # texture losses (:209-230)
         tex = geom_utils.sample_textures(tex_flow, imgs)
         bs, fs = tex.shape[:2]
         tex = tex.reshape(bs, fs, -1, 3)
         # :217 textured soft-max render and :223-224 the hard render of the SAME mesh and camera of which only the face-id
         # plane is read: one launch (the z-buffer winner is tracked during the soft-max render's own visits)
-        texture_rgba, p2f_info, _, aggr_info = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex,
-                                                                 with_visibility=True)
+        if self.share_mask_render:
+            # ... and :199, the mask render of the same meshes and cameras again: its alpha channel, with the gradient to
+            # vertices and camera the mask render has; the colour channels see the geometry detached as at :217
+            texture_rgba, p2f_info, _, aggr_info = self.tex_renderer(pred_vs, faces, proj_cam, tex, with_visibility=True,
+                                                                     detach_rgb_geometry=True)
+            mask_pred_seen = texture_rgba[:, 3]
+            mask_pred_unseen = self.dis_renderer.silhouettes(pred_vs, faces, random_cams)
+        else:
+            both = self.renderer.silhouettes(pred_vs, faces, torch.stack((proj_cam, random_cams), dim=1).reshape(2 * B, 7))
+            both = both.view(B, 2, both.shape[-2], both.shape[-1])
+            mask_pred_seen, mask_pred_unseen = both[:, 0], both[:, 1]
+            texture_rgba, p2f_info, _, aggr_info = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex,
+                                                                     with_visibility=True)
+        terms["mask"] = loss_utils.neg_iou_loss(mask_pred_seen, masks)
+        terms["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
+        terms["flatten"] = self.flatten_loss_fn(pred_vs).mean()
+        terms["deform"] = loss_utils.deform_l2reg(delta_v)
+        terms["ori"] = loss_utils.sym_reg(pred_vs)
         texture_pred = texture_rgba[:, 0:3]
         terms["tex"] = self.texture_loss(texture_pred, imgs, masks, mask_pred_seen)
         terms["tex_dt"] = loss_utils.texture_dt_loss(tex_flow, dts)
@@ -189,8 +199,12 @@ class RenderCompareS2(nn.Module):
     """
 
     def __init__(self, template_verts, faces, part_vertex_ids, uv_img, uv_sampler, image_size=256, num_hypo_cams=8,
-                 weights=None, texture_loss_type="perceptual", discriminator=None, num_sym_faces=0, tex_size=6):
+                 weights=None, texture_loss_type="perceptual", discriminator=None, num_sym_faces=0, tex_size=6,
+                 share_mask_render=True):
         super().__init__()
+        # True: MultiMaskLoss's render of the B*K hypothesis views (loss_utils.py:265) is the alpha channel of
+        # MultiTextureLoss's render of the same views (:313); False: two renders, as written there
+        self.share_mask_render = share_mask_render
         self.w = weights or S2Weights()
         self.K = num_hypo_cams
         self.register_buffer("faces", faces.long())
@@ -216,17 +230,19 @@ class RenderCompareS2(nn.Module):
         cams_all_hypo, cam_probs = outputs["cam_hypotheses"], outputs["cam_probs"]
         t = {}
         t["cam_div"] = -1 * (torch.log(cam_probs + 1E-9) * cam_probs).sum(1).mean()                 # :222
-        t["mask"], mask_all_hypo = self.mask_loss_fn(pred_vs, faces, cams_all_hypo, cam_probs, masks)
-        t["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
-        t["flatten"] = self.flatten_loss_fn(pred_vs).mean()
-        t["deform"] = loss_utils.deform_l2reg(delta_v)
         tex_flow = outputs["tex_flow"]
         tex = geom_utils.sample_textures(tex_flow, imgs)
         bs, fs = tex.shape[:2]
         tex = tex.reshape(bs, fs, -1, 3)
+        texture_rgba = self.texture_loss_fn.render_views(pred_vs, faces, cams_all_hypo, tex) if self.share_mask_render else None
+        t["mask"], mask_all_hypo = self.mask_loss_fn(pred_vs, faces, cams_all_hypo, cam_probs, masks,
+                                                     rendered_masks=None if texture_rgba is None else texture_rgba[:, 3])
+        t["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
+        t["flatten"] = self.flatten_loss_fn(pred_vs).mean()
+        t["deform"] = loss_utils.deform_l2reg(delta_v)
         t["tex"], t["tex_dt"], t["tex_cycle"], _ = self.texture_loss_fn(
             pred_vs.detach(), faces, cams_all_hypo.detach(), cam_probs.detach(), proj_cam, imgs, masks, mask_all_hypo,
-            tex, tex_flow, batch["dts_barrier"])
+            tex, tex_flow, batch["dts_barrier"], texture_rgba=texture_rgba)
         random_cams = rotate_cam_y(proj_cam, batch["gan_angles"])                                   # :257-258
         pred_unseen, _, _ = self.dis_renderer(pred_vs, faces, random_cams, tex.detach())            # :260
         if self.discriminator is not None:
