@@ -1,0 +1,46 @@
+"""GPU box: bench.py on the tripwire build of the library (-DUMR_TRAP=1, built by tools/r4/nan_hunt.sh into umr_amd/lib/exp/):
+every kernel of libumr_hip.so reports the first non-finite value it reads or writes (site ids: umr_amd/csrc/umr_common.h) without
+adding a launch or a synchronisation.  After bench's own output one line on stderr names the earliest report of the process.
+The render-and-compare inputs of every step are kept on the device (a ring of the last 6 steps); if a site fired or the loss
+went non-finite, the ring goes to gpurun_out/nan/repro_<pid>.pt for an offline replay of the failing step."""
+import ctypes, math, os, runpy, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from umr_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "exp", "libumr_hip_trap.so")
+import umr_amd.train_step as TS
+ring, seen = [], [0]
+KEYS = ("pred_vs", "delta_v", "cam", "cam_hypotheses", "cam_probs", "tex_flow")
+
+
+def hook(cls):
+    orig = cls.forward
+
+    def fwd(self, outputs, batch):
+        ring.append((seen[0], {k: outputs[k].detach().clone() for k in KEYS if k in outputs}))
+        seen[0] += 1
+        del ring[:-6]
+        total, terms = orig(self, outputs, batch)
+        ring[-1][1]["terms"] = {k: v.detach().clone() for k, v in terms.items()}
+        return total, terms
+    cls.forward = fwd
+
+
+hook(TS.RenderCompareS1); hook(TS.RenderCompareS2)
+try:
+    sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+    runpy.run_path(sys.argv[0], run_name="__main__")
+finally:
+    h = _lib.lib()
+    h.umr_debug_trap.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]
+    h.umr_debug_trap.restype = ctypes.c_int
+    when = ctypes.c_ulonglong(0)
+    site = h.umr_debug_trap(0, ctypes.byref(when))
+    bad_terms = [(s, k) for s, r in ring for k, v in r.get("terms", {}).items() if not math.isfinite(float(v))]
+    sys.stderr.write("bench_trap: earliest non-finite report: site %d (0 = none) at device clock %d; steps seen %d; non-finite terms in the last steps: %s\n"
+                     % (site, when.value, seen[0], bad_terms[:6]))
+    if site or bad_terms:
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "nan"), exist_ok=True)
+        torch.save({"site": site, "ring": [(s, {k: (v.cpu() if torch.is_tensor(v) else {a: b.cpu() for a, b in v.items()}) for k, v in r.items()}) for s, r in ring]},
+                   os.path.join(ROOT, "gpurun_out", "nan", "repro_%d.pt" % os.getpid()))
