@@ -111,7 +111,12 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
 #define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb
                                    gradient is zero, which is what "only alpha is consumed" means; needs need_grad_faces */
 
+/* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins, the backward's
+ * start order).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst
+ * case: 1 MB per mesh at F >= 1024); umr_raster_workspace_bytes_for(N, F, image_size) is the exact amount for that size (64 slots
+ * per mesh up to 512^2: a quarter of it) -- a caller that knows the size it is about to render may allocate this instead. */
 size_t umr_raster_workspace_bytes(int N, int F);
+size_t umr_raster_workspace_bytes_for(int N, int F, int image_size);
 
 int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
                        const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,

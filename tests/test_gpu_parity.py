@@ -172,7 +172,7 @@ def test_full_size_vs_oracle(oracle_built, ts, rgb):
         p2f_ref = o["p2f_info"] / np.maximum(o["p2f_sum"], 1e-12)
         assert_close_frac(t2n(p2f), p2f_ref, atol=3e-5, frac=1.0, name="p2f")                      # measured max 2.7e-6
     else:
-        assert (t2n(aggr)[:, 1] == o["aggrs_info"][:, 1]).mean() >= 0.9995
+        np.testing.assert_array_equal(t2n(aggr)[:, 1], o["aggrs_info"][:, 1])     # the z-buffer's face-id plane: index work, exact
     sf = np.abs(gf).max()
     # measured (round-3 build): all 23 040 vertex-gradient values within 5.5e-7 of scale (rounds 1-2: 99.86-99.98 %, the rest off
     # by up to 1.4 % of scale -- nearest-edge ties and rim fragments the tile cull dropped); texel gradients 2.8e-7 of scale
@@ -328,7 +328,11 @@ def test_train_s1_step_vs_oracle(oracle_built):
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
         s = np.abs(r).max()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=3e-4 * s, rtol=5e-3, frac=0.99, name="grad_" + k)
+        # measured (profiles/r03_parity_measured.jsonl): camera and texture-flow gradients agree in every element (1e-6 of scale);
+        # 4 of the 972 vertex-gradient values differ by up to 1 % of scale -- the adversarial term's rotated camera, float64
+        # numpy in the restatement (as in the reference's script), float32 on the device
+        assert_close_frac(t2n(out_g[k].grad), r, atol=3e-4 * s, rtol=5e-3, frac=(0.995 if k == "delta_v" else 1.0),
+                          max_outlier=3e-2 * s, name="grad_" + k)
 
 
 @pytest.mark.parametrize("name", RASTER)

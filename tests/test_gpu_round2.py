@@ -226,7 +226,11 @@ def test_train_s1_step_with_perceptual_term_and_epoch_gating(oracle_built, epoch
     assert abs(w) > 1e-3
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.995, name="s1_e%d_grad_%s" % (epoch, k))
+        # measured: camera / texture-flow gradients in every element; 2 of 972 vertex-gradient values up to 1 % of scale off
+        # (rotated camera of the adversarial term: float64 numpy in the restatement, float32 on the device)
+        sc_ = np.abs(r).max()
+        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * sc_, rtol=2e-2, frac=(0.997 if k == "delta_v" else 1.0),
+                          max_outlier=3e-2 * sc_, name="s1_e%d_grad_%s" % (epoch, k))
 
 
 def test_train_s1_step_at_bench_shape_vs_oracle(oracle_built):
@@ -238,7 +242,9 @@ def test_train_s1_step_at_bench_shape_vs_oracle(oracle_built):
     assert abs(float(total) - float(ref_total)) <= 3e-4 * max(1.0, abs(float(ref_total)))
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.998, name="s1_bench_grad_" + k)
+        # every element; measured max error 7e-5 (vertices), 7e-8 (camera), 9e-7 (texture flow) of the largest gradient
+        assert_close_frac(t2n(out_g[k].grad), r, atol={"delta_v": 5e-4, "cam": 1e-5, "tex_flow": 1e-5}[k] * np.abs(r).max(), frac=1.0,
+                          name="s1_bench_grad_" + k)
 
 
 def test_train_s2_step_at_bench_shape_vs_oracle(oracle_built):
@@ -264,7 +270,9 @@ def test_train_s2_step_at_bench_shape_vs_oracle(oracle_built):
         assert abs(float(terms[k]) - float(ref_terms[k])) <= 3e-4 * max(1.0, abs(float(ref_terms[k]))), (k, float(terms[k]), float(ref_terms[k]))
     for k in ("delta_v", "cam_hypotheses", "cam_probs", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.998, name="s2_bench_grad_" + k)
+        # every element; measured max error 4.5e-5 (vertices), 3e-7 (cameras, probabilities), 6e-7 (texture flow) of scale
+        assert_close_frac(t2n(out_g[k].grad), r, atol={"delta_v": 5e-4}.get(k, 1e-5) * np.abs(r).max(), frac=1.0,
+                          name="s2_bench_grad_" + k)
 
 
 def test_baseline_config1_shape_single_image(oracle_built):
@@ -284,15 +292,16 @@ def test_baseline_config1_shape_single_image(oracle_built):
     ref.ambient_light_only()
     ri, rp, ra = ref(verts, faces, cams, tex)
     assert img.shape == (1, 4, 256, 256) and aggr.shape == (1, 2, 512, 512)
-    assert_close_frac(t2n(img), ri.numpy(), atol=1e-4, frac=0.9999, max_outlier=1e-3, name="cfg1_image")
-    assert_close_frac(t2n(p2f), rp.numpy(), atol=1e-4, frac=0.995, name="cfg1_p2f")
+    assert_close_frac(t2n(img), ri.numpy(), atol=1e-4, frac=1.0, max_outlier=1e-5, name="cfg1_image")   # measured max 2.4e-7
+    assert_close_frac(t2n(p2f), rp.numpy(), atol=1e-5, frac=1.0, name="cfg1_p2f")                       # measured max 7.2e-7
     pts = torch.rand(1, 300, 2, generator=gen) * 2 - 1
     v2d = r.project_points(verts.to(DEV), cams.to(DEV))
     d1, d2, i1, i2 = distChamfer(v2d, pts.to(DEV))
     rd1, rd2, ri1, ri2 = torch_ref.dist_chamfer(torch_ref.orthographic_proj_withz(verts, cams)[:, :, :2], pts)
     np.testing.assert_allclose(t2n(d1), rd1.numpy(), atol=1e-6)
     np.testing.assert_allclose(t2n(d2), rd2.numpy(), atol=1e-6)
-    assert (t2n(i1) == ri1.numpy()).mean() > 0.995 and (t2n(i2) == ri2.numpy()).mean() > 0.995
+    np.testing.assert_array_equal(t2n(i1), ri1.numpy())       # arg-mins: index work, exact (first minimum, the reference's strict <)
+    np.testing.assert_array_equal(t2n(i2), ri2.numpy())
 
 
 def test_one_rank_rccl_training_step():

@@ -24,15 +24,15 @@ RARGS = ([0.1, 0.2, 0.3], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4)
 
 def test_train_s2_step_at_config4_shape_vs_oracle(oracle_built):
     """BASELINE configs[3]: train_s2 at 512x512 renders (IS = 1024) of the 2562-vertex / 5120-face mesh (subdivide 4,
-    experiments/train_s2.py:62, utils/mesh.py:37-41), K = 8 camera hypotheses, AlexNet perceptual texture term; B = 1 image
-    per step instead of 16 per GPU.  Every term of RenderCompareS2 and every gradient against the CPU restatement of
+    experiments/train_s2.py:62, utils/mesh.py:37-41), K = 8 camera hypotheses, AlexNet perceptual texture term; B = 2
+    images per step instead of 16 per GPU.  Every term of RenderCompareS2 and every gradient against the CPU restatement of
     train_s2.py:201-316 on the host cores: 20 raster forwards + 19 backwards at N = 8 | 1, F = 5120, IS = 1024, the IoU /
     part / chamfer / texture-sampling kernels at H = 512."""
     from oracle import softras, torch_ref
     from oracle.train_step_ref import RenderCompareS2Ref
     from umr_amd.synthetic import make_s2_inputs
     from umr_amd.train_step import RenderCompareS2
-    K, H, B = 8, 512, 1
+    K, H, B = 8, 512, 2
     nt = softras.max_threads()
     tv, faces, out_g, batch_g, ex = make_s2_inputs(B, K, H, 4, seed=41, device=DEV)
     assert tv.shape[0] == 2562 and faces.shape[0] == 5120
@@ -51,7 +51,9 @@ def test_train_s2_step_at_config4_shape_vs_oracle(oracle_built):
     assert abs(float(total) - float(ref_total)) <= 3e-4 * max(1.0, abs(float(ref_total)))
     for k in ("delta_v", "cam_hypotheses", "cam_probs", "tex_flow"):
         r = out_c[k].grad.numpy()
-        assert_close_frac(t2n(out_g[k].grad), r, atol=1e-3 * np.abs(r).max(), rtol=2e-2, frac=0.998, name="s2_cfg4_grad_" + k)   # measured 0.9996 .. 1.0
+        # every element; measured (B = 1, round 3) max error 4.4e-5 (vertices), 4.6e-6 (cameras), 3.5e-4 (texture flow) of scale
+        assert_close_frac(t2n(out_g[k].grad), r, atol={"delta_v": 5e-4, "tex_flow": 3e-3}.get(k, 1e-4) * np.abs(r).max(), frac=1.0,
+                          name="s2_cfg4_grad_" + k)
 
 
 def test_loss_kernels_at_config4_resolution(oracle_built):

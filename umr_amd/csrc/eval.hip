@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void k_kp_pick(const float *__restrict__ score
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const int best = s_i[0];
+        // every score NaN (a diverged model's flow): `better` never picks a NaN, the index stays at its sentinel -- face 0 then
+        // (torch.max of an all-NaN row returns the first index), instead of an out-of-bounds gather
+        const int best = s_i[0] == 0x7fffffff ? 0 : s_i[0];
         face_idx[(size_t)pair * K + k] = best;
         const float x = p2face[((size_t)pair * F + best) * 2], y = p2face[((size_t)pair * F + best) * 2 + 1];
         k2k[((size_t)pair * K + k) * 2] = x; k2k[((size_t)pair * K + k) * 2 + 1] = y;

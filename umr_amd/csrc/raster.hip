@@ -35,9 +35,11 @@ namespace {
 
 size_t ws_bbox_bytes(int N, int F) { return (((size_t)N * F * sizeof(float4)) + 255) & ~(size_t)255; }
 size_t ws_rec_bytes(int N, int F) { return (size_t)N * F * REC * sizeof(float); }
-size_t ws_sbcount_bytes(int N) { return (((size_t)N * SB_SLOTS * sizeof(int)) + 255) & ~(size_t)255; }
+// the coarse bins are laid out for the super-block slots a mesh actually has at this image size (sb_slots_for: 64 up to 512^2, 256
+// at 1024^2 and beyond); umr_raster_workspace_bytes(N, F) -- the size-independent query -- asks for the 256-slot worst case
+size_t ws_sbcount_bytes(int N, int slots) { return (((size_t)N * slots * sizeof(int)) + 255) & ~(size_t)255; }
 int sb_cap_for(int F) { return F < SB_CAP ? F : SB_CAP; }
-size_t ws_sblist_bytes(int N, int F) { return (size_t)N * SB_SLOTS * sb_cap_for(F) * sizeof(int); }
+size_t ws_sblist_bytes(int N, int F, int slots) { return (size_t)N * slots * sb_cap_for(F) * sizeof(int); }
 size_t ws_order_bytes(int N, int F) {   // start order in whole groups of <= 16 meshes + the per-face work estimates
     return (size_t)(N + 15) * F * sizeof(int) + (((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255);
 }
@@ -64,16 +66,25 @@ void superblock_geometry(int IS, int *size, int *nx) {
     *size = sixteenth > 64 ? sixteenth : 64;
     *nx = (IS + *size - 1) / *size;
 }
+int sb_slots_for(int IS) {   // super-block slots per mesh: sb_nx^2 (<= SB_SLOTS)
+    if (IS <= 0) return SB_SLOTS;
+    int size, nx;
+    superblock_geometry(IS, &size, &nx);
+    return nx * nx;
+}
+size_t ws_bins_offset(int N, int F) { return ws_bbox_bytes(N, F) + ws_rec_bytes(N, F); }
+size_t ws_order_offset(int N, int F, int IS) { return ws_bins_offset(N, F) + ws_sbcount_bytes(N, sb_slots_for(IS)) + ws_sblist_bytes(N, F, sb_slots_for(IS)); }
 
 // workspace pointers + the per-mesh coarse binning pass (after k_face_setup on the same stream)
 void setup_bins(RasterArgs &A, void *workspace, int N, int F, int IS, hipStream_t st) {
     A.sb_count = nullptr; A.sb_list = nullptr;
     if (!g_superblocks) return;
-    char *p = (char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F);
-    int *cnt = (int *)p, *lst = (int *)(p + ws_sbcount_bytes(N));
+    char *p = (char *)workspace + ws_bins_offset(N, F);
     superblock_geometry(IS, &A.sb_size, &A.sb_nx);
+    A.sb_slots = A.sb_nx * A.sb_nx;
+    int *cnt = (int *)p, *lst = (int *)(p + ws_sbcount_bytes(N, A.sb_slots));
     A.sb_cap = sb_cap_for(F);
-    UMR_LAUNCH(k_superblock_bin, dim3(A.sb_nx * A.sb_nx, N), 256, 0, st, A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx, A.sb_cap);
+    UMR_LAUNCH(k_superblock_bin, dim3(A.sb_slots, N), 256, 0, st, A.bbox, cnt, lst, F, IS, A.sb_size, A.sb_nx, A.sb_cap);
     A.sb_count = cnt; A.sb_list = lst;
 }
 
@@ -159,10 +170,12 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
     return UMR_OK;
 }
 
-size_t umr_raster_workspace_bytes(int N, int F) {
+size_t umr_raster_workspace_bytes_for(int N, int F, int image_size) {
     if (N <= 0 || F <= 0) return 0;
-    return ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F) + ws_order_bytes(N, F);
+    return ws_order_offset(N, F, image_size) + ws_order_bytes(N, F);
 }
+
+size_t umr_raster_workspace_bytes(int N, int F) { return umr_raster_workspace_bytes_for(N, F, 0); }
 
 int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
                        const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,
@@ -198,7 +211,7 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R, &general)) return UMR_ERR_ARG;
     if (general && (alpha_only || ids_only || pooled_out)) return UMR_ERR_ARG;   // fused variants exist for UMR's modes only
     if (visibility && (general || alpha_only || ids_only || func_id_rgb != 1)) return UMR_ERR_ARG;
-    if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
+    if (workspace_bytes < umr_raster_workspace_bytes_for(N, F, image_size)) return UMR_ERR_ARG;
     const int with_p2f = func_id_rgb == 1 && !alpha_only && !(flags & UMR_RASTER_NO_P2F);
     if (with_p2f && (!grid || !p2f_info || !p2f_sum)) return UMR_ERR_ARG;
     if (pooled_out && (image_size & 1)) return UMR_ERR_ARG;
@@ -285,7 +298,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     bool general = false;
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R, &general)) return UMR_ERR_ARG;
     if (general && (alpha_only || grad_is_pooled)) return UMR_ERR_ARG;
-    if (workspace_bytes < umr_raster_workspace_bytes(N, F)) return UMR_ERR_ARG;
+    if (workspace_bytes < umr_raster_workspace_bytes_for(N, F, image_size)) return UMR_ERR_ARG;
     if (grad_is_pooled && (image_size & 1)) return UMR_ERR_ARG;
     if (!need_grad_faces && !need_grad_textures) return UMR_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -317,7 +330,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     const int order_mode = alpha_only ? 2 : ((!need_grad_faces && func_id_rgb == 1) ? 1 : 0);
     const bool ordered = face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 &&
                          F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
-    int *order = (int *)((char *)workspace + ws_bbox_bytes(N, F) + ws_rec_bytes(N, F) + ws_sbcount_bytes(N) + ws_sblist_bytes(N, F));
+    int *order = (int *)((char *)workspace + ws_order_offset(N, F, image_size));
     unsigned short *cost = (unsigned short *)(order + (size_t)(N + 15) * F);
     UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                    sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size, g_thin_face_h);

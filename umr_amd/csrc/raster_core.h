@@ -77,12 +77,12 @@ struct RasterArgs {
     int double_side, with_p2f, grad_pooled, need_gf, need_gt;
     int tiles_x, tiles_y;
     // per-mesh coarse bins written by k_superblock_bin: the image is cut into <= 16 x 16 super-blocks of sb_size^2 pixels
-    // (sb_size >= 64, a multiple of the 16-pixel workgroup block); sb_list[(n * SB_SLOTS + sb) * sb_cap ...] holds, ascending,
+    // (sb_size >= 64, a multiple of the 16-pixel workgroup block); sb_list[(n * sb_slots + sb) * sb_cap ...] holds, ascending,
     // the first sb_cap faces whose dilated bbox touches super-block sb, sb_count their TRUE number (> sb_cap: the list is
     // incomplete and the workgroup scans all F faces).  NULL = scan all F faces per workgroup.
     const int *sb_count;
     const int *sb_list;
-    int sb_size, sb_nx, sb_cap;
+    int sb_size, sb_nx, sb_cap, sb_slots;   // sb_slots = sb_nx^2: slots per mesh in sb_count / sb_list
     // face-major backward: start order of the faces (k_face_order).  order[((g * 8 + xcd) * order_group * (F / 8)) + i] =
     // (mesh - g * order_group) << 16 | face for the i-th wave XCD `xcd` starts within mesh group g; NULL = index order.
     const int *order;
@@ -699,9 +699,9 @@ __device__ __forceinline__ int build_list(int *s_list, int *s_wcnt, const float4
 __device__ __forceinline__ int superblock_list(const RasterArgs &A, const Tile &t, const int *&ids) {
     if (!A.sb_list) { ids = nullptr; return A.F; }
     const int sb = (t.by0 / A.sb_size) * A.sb_nx + (t.bx0 / A.sb_size);
-    const int cnt = A.sb_count[t.n * SB_SLOTS + sb];
+    const int cnt = A.sb_count[t.n * A.sb_slots + sb];
     if (cnt > A.sb_cap) { ids = nullptr; return A.F; }          // overflowed slot (degenerate scene): full scan
-    ids = A.sb_list + ((size_t)t.n * SB_SLOTS + sb) * A.sb_cap;
+    ids = A.sb_list + ((size_t)t.n * A.sb_slots + sb) * A.sb_cap;
     return cnt;
 }
 
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void k_superblock_bin(const float4 *__restrict
     const int sb = blockIdx.x, n = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sbx = sb % sb_nx, sby = sb / sb_nx;
-    int *out = sb_list + ((size_t)n * SB_SLOTS + sb) * sb_cap;
+    int *out = sb_list + ((size_t)n * gridDim.x + sb) * sb_cap;     // gridDim.x = slots per mesh
     const bool pow2 = (IS & (IS - 1)) == 0;
     const float inv_is = 1.f / (float)IS;
     const int px0 = sbx * sb_size, px1 = min(px0 + sb_size - 1, IS - 1), pr0 = sby * sb_size, pr1 = min(pr0 + sb_size - 1, IS - 1);
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void k_superblock_bin(const float4 *__restrict
         count += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) sb_count[n * SB_SLOTS + sb] = count;
+    if (threadIdx.x == 0) sb_count[n * gridDim.x + sb] = count;
 }
 
 }  // namespace

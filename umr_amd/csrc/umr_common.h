@@ -16,11 +16,13 @@
 #endif
 // Lanes of ONE wave handing data to each other through LDS without a barrier rely on the wave executing in lockstep (its LDS
 // operations complete in order).  The emulation build runs a wave's lanes one after the other between cross-lane operations
-// and needs such a point marked; on the device the marker is nothing.
+// and needs such a point marked; on the device the marker emits no instruction but pins the order for the COMPILER (a
+// wavefront-scope release fence + a scheduling barrier: without it nothing would stop a later compiler from moving the loads
+// of other lanes' slots above the conditional stores that fill them).
 #ifdef UMR_HOST_SHIM
 #define UMR_WAVE_LDS_HANDOVER() umr_host_wave_fence()
 #else
-#define UMR_WAVE_LDS_HANDOVER() ((void)0)
+#define UMR_WAVE_LDS_HANDOVER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
 static inline int umr_launch_status() { return hipGetLastError() == hipSuccess ? UMR_OK : UMR_ERR_LAUNCH; }

@@ -39,6 +39,27 @@ def gaussian_patch(sigma, device):
     return _PATCH_CACHE[key]
 
 
+EVAL_MAX_K = 32      # keypoints per pair the device counters take (csrc/eval.hip)
+
+
+def _check_pck_args(K, kp_gt, vis, counters):
+    given = [a is not None for a in (kp_gt, vis, counters)]
+    if any(given) and not all(given):
+        raise ValueError("keypoint transfer: kp_gt, vis and counters go together (all three for PCK accumulation, or none)")
+    if K > EVAL_MAX_K:
+        raise ValueError("keypoint transfer: %d keypoints per pair; the device path takes at most %d" % (K, EVAL_MAX_K))
+
+
+def pck(kps_pred, kps_gt, kps_vis, padding_frac=0.05, thresholds=(0.1, 0.15)):
+    """test_kp.py:253-258 for one batch of transferred keypoints already on hand: kps_pred / kps_gt [P,K,>=2] in [-1,1],
+    kps_vis [P,K] -> (PCK.1, PCK.15), per-keypoint hit rates averaged as the reference does.  (The batch transfer functions
+    accumulate the same counts on the device; this is the stand-alone form of the reference's helper.)"""
+    err = (kps_pred[..., :2] - kps_gt[..., :2]).norm(dim=-1) * ((1 + 2 * padding_frac) / 2)
+    seen = kps_vis != 0
+    n = seen.sum(0).double()
+    return tuple(float((((err < t) & seen).sum(0).double() / n).mean()) for t in thresholds)
+
+
 class PCKCounters:
     """Device-side accumulators of test_kp.py:253-258, 317-323: int32 [3,K] = (visible, err < 0.1, err < 0.15) per keypoint,
     added into by every transfer call that is given a ground truth; .pck() -> (PCK.1, PCK.15)."""
@@ -63,6 +84,7 @@ def map_kp_flow_batch(kp_src, flow_src, flow_tgt, image_size=256, sigma=3, kp_gt
     kp = kp_src.to(dev, torch.float32).contiguous()
     fs, ft = flow_src.to(torch.float32).contiguous(), flow_tgt.to(torch.float32).contiguous()
     P, K = kp.shape[0], kp.shape[1]
+    _check_pck_args(K, kp_gt, vis, counters)
     F = fs.shape[1]
     TT = fs[0, 0].numel() // 2
     face_idx = torch.empty(P, K, dtype=torch.int32, device=dev)
@@ -93,6 +115,7 @@ def map_kp_cam_batch(kp_src, cam_src, cam_tgt, mask_tgt, mean_shape, image_size=
     L = _lib.lib()
     dev = mean_shape.device
     P, K = kp_src.shape[0], kp_src.shape[1]
+    _check_pck_args(K, kp_gt, vis, counters)
     ms = mean_shape.view(1, -1, 3).expand(P, -1, -1).contiguous()
     V = ms.shape[1]
     v_tgt = UF.ProjectPointsFunction.apply(ms, cam_tgt.view(P, 7).contiguous(), 2, 0.0).contiguous()

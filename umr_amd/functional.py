@@ -118,7 +118,7 @@ def visibility(face_vertices, image_size, near=1., far=100., fill_back=True, eps
     N, F = fv.shape[:2]
     IS = int(image_size)
     aggrs = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
-    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     rc = L.umr_raster_forward(ptr(fv), None, None, ptr(aggrs), None, None, None, None, None, N, F, 1, IS, float(near),
                               float(far), float(eps), float(sigma_val), 2, float(math.log(1. / dist_eps - 1.)),

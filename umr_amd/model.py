@@ -465,8 +465,8 @@ def build_training_step_s2(args, dev, world):
     model = nn.ModuleDict(dict(net=net, disc=disc))
     ddp_net, ddp_disc = wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world)
     rank = torch.distributed.get_rank() if world > 1 else 0
-    _, _, _, batch, ex = make_s2_inputs(args.batch, opts.num_hypo_cams, args.image_size, args.subdivide, seed=100 + rank,
-                                        device=dev)
+    _, _, _, batch, ex = make_s2_inputs(args.batch, opts.num_hypo_cams, args.image_size, args.subdivide,
+                                        seed=getattr(args, "data_seed", 100) + rank, device=dev)
     rc = RenderCompareS2(net.get_mean_shape().detach(), net.faces, ex["part_vertex_ids"], ex["uv_img"],
                          net.uv_sampler, args.image_size, opts.num_hypo_cams, texture_loss_type="perceptual",
                          discriminator=ddp_disc, tex_size=opts.tex_size,

@@ -82,7 +82,7 @@ def _raster_forward(face_vertices, textures, image_size, background, near, far, 
     pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
     with_p2f = need_p2f and (modes & 0xf) == 1
     grid = standard_grid(IS, dev) if with_p2f else None
-    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
     # the hard render's (depth, face id) planes of the same faces, from the same visits (umr_raster_forward_vis)
@@ -135,7 +135,7 @@ def soft_rasterize_backward_op(face_vertices: torch.Tensor, textures: torch.Tens
     grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32) if need_grad_faces else None
     grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32) if need_grad_textures else None   # per view
     g = grad_image.to(torch.float32).contiguous()
-    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
     rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
@@ -187,7 +187,7 @@ def silhouette_op(face_vertices: torch.Tensor, image_size: int, near: float, far
     IS = int(image_size)
     alpha = torch.empty(N, IS, IS, device=dev, dtype=torch.float32)
     pooled = torch.empty(N, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
-    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, 1)
     rc = L.umr_raster_forward(ptr(fv), None, None, None, None, None, None, ptr(alpha), ptr(pooled), N, F, 1, *sc, 2 | 1, None,
@@ -214,7 +214,7 @@ def silhouette_backward_op(face_vertices: torch.Tensor, alpha: torch.Tensor, gra
     N, F = fv.shape[:2]
     grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32)
     g = grad_alpha.to(torch.float32).contiguous()
-    ws_bytes = L.umr_raster_workspace_bytes(N, F)
+    ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, 1)
     rc = L.umr_raster_backward(ptr(fv), None, ptr(alpha), None, None, ptr(grad_faces), None, ptr(g), 2 | (1 if pool else 0),

@@ -52,13 +52,16 @@ def gan_labels(module, B, device):
     return cache[(B, device)]
 
 
-def weighted_total(module, terms, weights):
+def weighted_total(module, terms, weights, skip=()):
     """sum_k weights[k] * terms[k] as ONE stack, ONE multiply and ONE sum (and their backward kernels) instead of a
     multiply and an add per term in each direction: the step's wall time equals its host enqueue time, so every
     elementwise launch on scalars costs ~10 us of it.  `weights`: list of (name, python float); the weight vector is
-    uploaded once per device and cached on `module`."""
-    weights = [(k, v) for k, v in weights if float(v) != 0.0]   # a term with weight 0 is OMITTED, as the reference omits the
-    # epoch-gated regularisers (train_s1.py:250-255): 0 * inf would poison the total, and its zero gradient costs kernels
+    uploaded once per device and cached on `module`.  `skip`: names LEFT OUT of the sum -- the terms the reference's own
+    `if` statements leave out (train_s1.py:250-255: the epoch-gated regularisers); a term with a user-set weight of 0 stays in,
+    as `0 * loss`, exactly like the reference's unconditional additions (its parameters then get zero gradients, not None)."""
+    weights = [(k, v) for k, v in weights if k not in skip]
+    if not weights:
+        return next(iter(terms.values())).new_zeros(())
     vals = torch.stack([terms[k].reshape(()) for k, _ in weights])
     cache = module.__dict__.setdefault("_wvec_cache", {})
     key = (vals.device, tuple((k, float(v)) for k, v in weights))
@@ -164,12 +167,11 @@ class RenderCompareS1(nn.Module):
         # epoch > update_template_freq (:253) -- a gated-off term stays in `terms` for logging, as in the reference, and is
         # left out of the sum (weighted_total).  A HIP graph captured from this module bakes in the epoch's gating:
         # re-capture after set_epoch crosses stop_ori_epoch / update_template_freq (bench.py --graph runs one epoch).
-        ori_wt = w.ori_reg_wt if self.epoch < w.stop_ori_epoch else 0.0
-        deform_wt = w.deform_reg_wt if self.epoch > w.update_template_freq else 0.0
+        gated_off = [k for k, on in (("ori", self.epoch < w.stop_ori_epoch), ("deform", self.epoch > w.update_template_freq)) if not on]
         total = weighted_total(self, terms, [
             ("mask", w.mask_loss_wt), ("triangle", w.triangle_reg_wt), ("flatten", w.flatten_reg_wt),
-            ("ori", ori_wt), ("deform", deform_wt), ("tex", w.tex_loss_wt), ("tex_dt", w.tex_dt_loss_wt),
-            ("tex_cycle", w.tex_cycle_loss_wt), ("gan", w.gan_loss_wt)])
+            ("ori", w.ori_reg_wt), ("deform", w.deform_reg_wt), ("tex", w.tex_loss_wt), ("tex_dt", w.tex_dt_loss_wt),
+            ("tex_cycle", w.tex_cycle_loss_wt), ("gan", w.gan_loss_wt)], skip=gated_off)
         return total, terms
 
 
