@@ -74,11 +74,16 @@ def self_launch(args):
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
+    # the ranks run the script this process was started as (bench.py; the CPU suite starts it through a wrapper that puts the
+    # wave64 emulation of the library under it: tests/bench_rank_on_emulator.py)
+    entry = os.path.abspath(sys.argv[0]) if sys.argv and sys.argv[0].endswith(".py") else os.path.abspath(__file__)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), entry] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # N ranks share the host's cores: OpenMP (MIOpen's host side, the CPU-baseline oracle on rank 0) and torch's intra-op pool
+    # get an N-th each instead of N x all cores
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(1, args.gpus)))))
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -104,7 +109,9 @@ def cpu_baseline(args, n_images):
                       "side" % (n_images, dt)}
 
 
-def main():
+def main(device=None, backend="nccl"):
+    """device / backend: the CPU suite runs this very function on host tensors over gloo with the wave64 emulation of the library
+    (tests/bench_rank_on_emulator.py) to exercise the N > 1 plumbing without GPUs; every real run leaves them at their defaults."""
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,16 +127,20 @@ def main():
         os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    assert device is not None or torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
     if world > 1:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), (os.cpu_count() or 8) // world)))
         # N ranks start at once on a fresh node: each gets its own MIOpen user database / kernel cache, so the first-use solver
         # searches of the ranks do not write the same sqlite files concurrently (set before MIOpen creates its first handle)
         for var, sub_ in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
             d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "umr_miopen_%s_rank%d" % (sub_, local))
             os.makedirs(d, exist_ok=True)
             os.environ.setdefault(var, d)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if device is None:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device(device)
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,7 +155,8 @@ def main():
             else:                       # several ranks cannot agree on a random port by themselves
                 raise SystemExit("bench.py: WORLD_SIZE=%d but no MASTER_PORT in the environment: start the ranks with torchrun / "
                                  "`python bench.py --gpus N` (which picks a free port), or pass --master-port" % world)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" = RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                device_id=(dev if dev.type == "cuda" else None))   # "nccl" = RCCL on ROCm
 
     from umr_amd import _lib
     from umr_amd.synthetic import make_s1_inputs
@@ -370,7 +382,7 @@ def main():
     # the gradient exchange on its own: the model's gradient bytes all-reduced in DDP's bucket size, timed with HIP events
     # on every rank (max over ranks).  With one rank (--force-ddp) this is RCCL's launch + local-copy floor of the path.
     ar_info = {}
-    if world > 1 or args.force_ddp:
+    if (world > 1 or args.force_ddp) and dev.type == "cuda":
         import torch.distributed as dist
         from umr_amd.parallel import BUCKET_MB
         nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad) if model is not None else 337 * 1024 * 1024

@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from umr_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "exp", "libumr_hip_trap.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "exp", "libumr_hip_%s.so" % os.environ.get("TRAP_LIB", "trap"))
+for kv in os.environ.get("UMR_DEBUG_SET", "").split(","):      # e.g. UMR_DEBUG_SET=exact_edges=0
+    if "=" in kv:
+        _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 import umr_amd.train_step as TS
 ring, seen = [], [0]
 KEYS = ("pred_vs", "delta_v", "cam", "cam_hypotheses", "cam_probs", "tex_flow")
