@@ -100,6 +100,9 @@ class emulated_product:
             for op in (ops.soft_rasterize_op, ops.soft_rasterize_backward_op, ops.silhouette_op, ops.silhouette_backward_op,
                        ops.soft_rasterize_alpha_geometry_op):
                 op.register_kernel("cpu")(op._init_fn)
+            from umr_amd import ops_losses          # the geometry / loss operators: the same implementations for host tensors
+            for name, impl in ops_losses.IMPLS:
+                ops_losses._LIB.impl(name, impl, "CPU")
             emulated_product._ops_registered = True
         return self
 

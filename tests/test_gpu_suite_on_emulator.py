@@ -107,7 +107,7 @@ def test_shared_mask_render_equals_the_two_renders_on_the_emulator():
     inputs -- every loss term is EQUAL, not close; the gradients are sums of the same per-view contributions accumulated in
     another order (one 2B-view launch against two B-view launches feeding the projection's backward): equal to rounding."""
     import torch
-    from tests.host_raster import emulated_product
+    from host_raster import emulated_product
     from umr_amd.synthetic import make_s1_inputs
     from umr_amd.train_step import RenderCompareS1
     B, H = 2, 32

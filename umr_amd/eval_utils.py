@@ -118,8 +118,8 @@ def map_kp_cam_batch(kp_src, cam_src, cam_tgt, mask_tgt, mean_shape, image_size=
     _check_pck_args(K, kp_gt, vis, counters)
     ms = mean_shape.view(1, -1, 3).expand(P, -1, -1).contiguous()
     V = ms.shape[1]
-    v_tgt = UF.ProjectPointsFunction.apply(ms, cam_tgt.view(P, 7).contiguous(), 2, 0.0).contiguous()
-    v_src = UF.ProjectPointsFunction.apply(ms, cam_src.view(P, 7).contiguous(), 2, 0.0).contiguous()
+    v_tgt = UF.project_points(ms, cam_tgt.view(P, 7).contiguous(), 2, 0.0).contiguous()
+    v_src = UF.project_points(ms, cam_src.view(P, 7).contiguous(), 2, 0.0).contiguous()
     kp = kp_src.to(dev, torch.float32).contiguous()
     mask = mask_tgt.to(dev, torch.float32).contiguous()
     vert_idx = torch.empty(P, K, dtype=torch.int32, device=dev)

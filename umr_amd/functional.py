@@ -7,7 +7,6 @@ import ctypes
 import math
 
 import torch
-from torch.autograd import Function
 
 from . import _lib
 from ._lib import ptr
@@ -35,6 +34,24 @@ def standard_grid(image_size, device):
 
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
+
+
+class KernelCtx:
+    """What the *Kernel classes below hand from forward() to backward(): the tensors to keep, which inputs want a gradient,
+    and a few plain attributes.  The registered operators (umr_amd/ops_losses.py) build one per call -- forward of
+    torch.ops.umr.<name>, backward of torch.ops.umr.<name>_backward -- from their own saved tensors; this is an ordinary class of
+    this package, not torch's autograd context."""
+
+    def __init__(self, needs=(), saved=(), **attrs):
+        self.needs_input_grad = tuple(needs)
+        self.saved_tensors = tuple(saved)
+        self.__dict__.update(attrs)
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
 
 
 def _check_raster_shapes(face_vertices, textures):
@@ -128,6 +145,11 @@ def visibility(face_vertices, image_size, near=1., far=100., fill_back=True, eps
     return aggrs
 
 
+def silhouette(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool):
+    """Alpha channel of the soft render only -> [N,S,S]; see SilhouetteFunction."""
+    return SilhouetteFunction.apply(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
+
+
 def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
@@ -143,7 +165,7 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
                                        detach_rgb_geometry)
 
 
-class ProjectFacesFunction(Function):
+class ProjectFacesKernel:
     """verts [N/G,V,3], cams [N,7], faces [N/G,F,3] int32 -> (face_pre [N,F,3,3], face_out [N,F,3,3], light [N,F,3]).
     Fuses geom_utils.orthographic_proj_withz + smr.Render's y flip + face_vertices + LookAt/orthogonal and, when
     `light` = (ambient, directional, color3, direction3) is given, sr.Lighting's per-face surface light
@@ -208,7 +230,7 @@ class ProjectFacesFunction(Function):
         return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None, None, None, None
 
 
-class ProjectPointsFunction(Function):
+class ProjectPointsKernel:
     """verts [N,V,3], cams [N,7] -> [N,V,out_dim] (2: xy; 3: xy + z with offset_z).  No y flip."""
 
     @staticmethod
@@ -237,7 +259,7 @@ class ProjectPointsFunction(Function):
         return grad_verts, (grad_cams if ctx.needs_input_grad[1] else None), None, None
 
 
-class NegIoUFunction(Function):
+class NegIoUKernel:
     """loss[n] = 1 - sum(p t) / (sum(p + t - p t) + 1e-6)   (nnutils/loss_utils.py:41-48, avg=False)."""
 
     @staticmethod
@@ -266,7 +288,7 @@ class NegIoUFunction(Function):
         return gp.view(ctx.shape), None
 
 
-class ChamferFunction(Function):
+class ChamferKernel:
     @staticmethod
     def forward(ctx, a, b):
         L = _lib.lib()
@@ -298,7 +320,7 @@ class ChamferFunction(Function):
         return ga, gb
 
 
-class GridSampleCLFunction(Function):
+class GridSampleCLKernel:
     """image [B,C,H,W], grid [B,P,2] -> out [B,P,C]; bilinear / zeros / align_corners=True."""
 
     @staticmethod
@@ -327,7 +349,7 @@ class GridSampleCLFunction(Function):
         return gi, gg
 
 
-class LaplacianFunction(Function):
+class LaplacianKernel:
     @staticmethod
     def forward(ctx, x, nbr_off, nbr_idx):
         L = _lib.lib()
@@ -352,7 +374,7 @@ class LaplacianFunction(Function):
         return gx, None, None
 
 
-class FlattenFunction(Function):
+class FlattenKernel:
     @staticmethod
     def forward(ctx, x, quads):
         L = _lib.lib()
@@ -388,7 +410,7 @@ def visible_face_mask(face_ids, num_faces):
     return mask
 
 
-class Upsample2xBilinearFunction(Function):
+class Upsample2xBilinearKernel:
     """[B,C,H,W] -> [B,C,2H,2W], == F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)."""
 
     @staticmethod
@@ -413,7 +435,7 @@ class Upsample2xBilinearFunction(Function):
         return gi
 
 
-class PerceptualPrologueFunction(Function):
+class PerceptualPrologueKernel:
     """img [B,C<=3,H,W], mask [B,H,W] -> ((2 (img * mask) - 1) - shift_c) / scale_c: the input side of the perceptual texture
     term (loss_utils.py:141-146, perceptual_loss.py:52-54, networks_basic.py:45-46) in one launch each way instead of
     five element-wise kernels forward and as many backward.  shift / scale: 3 python floats each."""
@@ -448,7 +470,7 @@ class PerceptualPrologueFunction(Function):
         return gi, gm, None, None
 
 
-class CosSimDistanceFunction(Function):
+class CosSimDistanceKernel:
     """PNet head (networks_basic.py:42-64 + util/util.py:71-83): apply(eps, *feats0, *feats1) with 2 T feature maps
     [N,C_t,X_t,Y_t] -> val [N] = sum_t (1 - mean_xy cos(f0_t, f1_t)).  One launch for all taps each way."""
 
@@ -498,7 +520,7 @@ class CosSimDistanceFunction(Function):
         return (None,) + tuple(g0) + tuple(g1)
 
 
-class PartMatchFunction(Function):
+class PartMatchKernel:
     """Reductions of part_matching_loss (nnutils/loss_utils.py:399-440, scops_utils.py:12-54):
     apply(render_a [B,4,H,W], render_b [B,4,H,W], part_segs [B,5,H,W], weights5 (python floats), background, eps)
     -> (l_eqv [B], l_lm [B]); see include/umr_hip.h for the exact definition.  Gradients flow to the two renders."""
@@ -538,7 +560,7 @@ class PartMatchFunction(Function):
         return ga, gb, None, None, None, None
 
 
-class RowNormMeanFunction(Function):
+class RowNormMeanKernel:
     """mean over rows of ||x_row||_2 (deform_l2reg, nnutils/loss_utils.py:118-123): x [..., W] -> scalar."""
 
     @staticmethod
@@ -565,7 +587,7 @@ class RowNormMeanFunction(Function):
         return gx.view(ctx.shape)
 
 
-class AbsColumnMeanFunction(Function):
+class AbsColumnMeanKernel:
     """mean |x[..., column]| (sym_reg, nnutils/loss_utils.py:125-126: column 1 of verts [B,V,3]) -> scalar."""
 
     @staticmethod
@@ -592,7 +614,7 @@ class AbsColumnMeanFunction(Function):
         return gx.view(ctx.shape), None
 
 
-class MaskedL1Function(Function):
+class MaskedL1Kernel:
     """per_sample[b] = mean_{c,p} |img_pred mask_pred - img_gt mask_gt| (texture_loss_masks, nnutils/loss_utils.py:103-116).
     img_* [B,C,H,W], mask_* [B,H,W]; gradients to img_pred and mask_pred."""
 
@@ -623,3 +645,103 @@ class MaskedL1Function(Function):
         _lib.check(L.umr_masked_l1_backward(ptr(ip), ptr(ig), ptr(mg), ptr(mp), ptr(g), ptr(gip), ptr(gmp), B, C, H * W,
                                             _lib.stream_ptr(ip.device)), "umr_masked_l1_backward")
         return gip, None, None, (gmp.view(ctx.mp_shape) if gmp is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The ONE route into the kernels above: the registered operators torch.ops.umr.* (umr_amd/ops_losses.py; the rasterizer's are in
+# umr_amd/ops.py).  The functions below are what the loss / geometry modules call; the *Function classes keep the
+# `Function.apply(...)` call form of rounds 1-3 for tests and tools and are thin forwards to the same operators.
+def _ops(*tensors):
+    """torch.ops.umr, after refusing host tensors with this package's own message (the dispatcher's "no kernel for the CPU
+    backend" says the same less readably): there is no CPU path."""
+    from . import ops_losses  # noqa: F401  (registers torch.ops.umr.*)
+    for t in tensors:
+        if torch.is_tensor(t) and not _lib.on_device(t):
+            raise RuntimeError("umr_amd: expected a GPU tensor, got %s (no CPU path exists)" % t.device)
+    return torch.ops.umr
+
+
+def _light_list(light):
+    if light is None:
+        return []
+    amb, dirn, col, dvec = light
+    return [float(amb), float(dirn)] + [float(x) for x in col] + [float(x) for x in dvec]
+
+
+def project_faces(verts, cams, faces_idx, offset_z, eye_z, want_pre=False, light=None):
+    """-> (face_pre [N,F,3,3] | empty, face_out [N,F,3,3], light [N,F,3] | empty); see ProjectFacesKernel."""
+    return _ops(verts, cams).project_faces_lit(verts, cams, faces_idx, float(offset_z), float(eye_z), bool(want_pre), _light_list(light))
+
+
+def project_points(verts, cams, out_dim=2, offset_z=0.0):
+    return _ops(verts, cams).project_points(verts, cams, int(out_dim), float(offset_z))
+
+
+def neg_iou(predict, target):
+    return _ops(predict, target).neg_iou(predict, target)[0]
+
+
+def chamfer(a, b):
+    return _ops(a, b).chamfer(a, b)
+
+
+def grid_sample_cl(image, grid):
+    return _ops(image, grid).grid_sample_cl(image, grid)
+
+
+def laplacian(x, nbr_off, nbr_idx):
+    return _ops(x).laplacian(x, nbr_off, nbr_idx)[0]
+
+
+def flatten(x, quads):
+    return _ops(x).flatten(x, quads)
+
+
+def upsample2x_bilinear(x):
+    return _ops(x).upsample2x_bilinear(x)
+
+
+def perceptual_prologue(img, mask, shift, scale):
+    return _ops(img, mask).perceptual_prologue(img, mask, [float(v) for v in shift], [float(v) for v in scale])
+
+
+def cos_sim_distance(eps, feats0, feats1):
+    return _ops(*feats0, *feats1).cos_sim(list(feats0), list(feats1), float(eps))[0]
+
+
+def part_match(render_a, render_b, part_segs, weights5, background, center_eps):
+    e, l, _ = _ops(render_a, render_b, part_segs).part_match(render_a, render_b, part_segs, [float(w) for w in weights5], float(background), float(center_eps))
+    return e, l
+
+
+def row_norm_mean(x):
+    return _ops(x).row_norm_mean(x)
+
+
+def abs_column_mean(x, column):
+    return _ops(x).abs_column_mean(x, int(column))
+
+
+def masked_l1(img_pred, img_gt, mask_gt, mask_pred):
+    return _ops(img_pred, img_gt, mask_gt, mask_pred).masked_l1(img_pred, img_gt, mask_gt, mask_pred)
+
+
+class _Apply:
+    def __init__(self, fn):
+        self.apply = fn
+
+
+ProjectFacesFunction = _Apply(project_faces)
+ProjectPointsFunction = _Apply(project_points)
+NegIoUFunction = _Apply(neg_iou)
+ChamferFunction = _Apply(chamfer)
+GridSampleCLFunction = _Apply(grid_sample_cl)
+LaplacianFunction = _Apply(laplacian)
+FlattenFunction = _Apply(flatten)
+Upsample2xBilinearFunction = _Apply(upsample2x_bilinear)
+PerceptualPrologueFunction = _Apply(perceptual_prologue)
+CosSimDistanceFunction = _Apply(lambda eps, *feats: cos_sim_distance(eps, feats[:len(feats) // 2], feats[len(feats) // 2:]))
+PartMatchFunction = _Apply(part_match)
+RowNormMeanFunction = _Apply(row_norm_mean)
+AbsColumnMeanFunction = _Apply(abs_column_mean)
+MaskedL1Function = _Apply(masked_l1)

@@ -11,7 +11,7 @@ from .smr import SoftRenderer
 
 def neg_iou_loss(predict, target, avg=True):
     """nnutils/loss_utils.py:41-48."""
-    per = UF.NegIoUFunction.apply(predict, target)
+    per = UF.neg_iou(predict, target)
     if avg:
         return per.sum() / per.nelement()   # == 1 - (I/U).sum()/n
     return per
@@ -20,24 +20,24 @@ def neg_iou_loss(predict, target, avg=True):
 def texture_dt_loss(texture_flow, dist_transf, vis_rend=None, cams=None, verts=None, tex_pred=None):
     """nnutils/loss_utils.py:50-90 (the interactive visualisation branch is not carried over)."""
     B, F, T = texture_flow.shape[0], texture_flow.shape[1], texture_flow.shape[-2]
-    s = UF.GridSampleCLFunction.apply(dist_transf, texture_flow.reshape(B, F * T * T, 2))
+    s = UF.grid_sample_cl(dist_transf, texture_flow.reshape(B, F * T * T, 2))
     return s.mean()
 
 
 def texture_loss_masks(img_pred, img_gt, mask_gt, mask_pred, avg=True):
     """nnutils/loss_utils.py:103-116: L1(img_pred * mask_pred, img_gt * mask_gt); one kernel pair (umr_masked_l1_*)."""
-    per = UF.MaskedL1Function.apply(img_pred, img_gt, mask_gt, mask_pred)     # [B]: mean over (C, H, W) per sample
+    per = UF.masked_l1(img_pred, img_gt, mask_gt, mask_pred)     # [B]: mean over (C, H, W) per sample
     return per.mean() if avg else per
 
 
 def deform_l2reg(V):
     """nnutils/loss_utils.py:118-123: mean row norm of V [B,N,3] (umr_row_norm_mean_*)."""
-    return UF.RowNormMeanFunction.apply(V)
+    return UF.row_norm_mean(V)
 
 
 def sym_reg(verts):
     """nnutils/loss_utils.py:125-126: mean |y| of verts [B,V,3] (umr_abs_mean_*)."""
-    return UF.AbsColumnMeanFunction.apply(verts, 1)
+    return UF.abs_column_mean(verts, 1)
 
 
 class TexCycle(nn.Module):
@@ -148,7 +148,7 @@ class LaplacianLoss(nn.Module):
         self.register_buffer('nbr_idx', torch.from_numpy(idx))
 
     def forward(self, x):
-        loss = UF.LaplacianFunction.apply(x, self.nbr_off, self.nbr_idx)
+        loss = UF.laplacian(x, self.nbr_off, self.nbr_idx)
         if self.average:
             return loss.sum() / x.size(0)
         return loss
@@ -179,7 +179,7 @@ class FlattenLoss(nn.Module):
         self.register_buffer('quads', torch.tensor(quads, dtype=torch.int32))
 
     def forward(self, vertices, eps=1e-6):
-        loss = UF.FlattenFunction.apply(vertices, self.quads)
+        loss = UF.flatten(vertices, self.quads)
         if self.average:
             return loss.sum() / vertices.size(0)
         return loss
@@ -286,7 +286,7 @@ class part_matching_loss(nn.Module):
         projs = [proj_a[:, 0:1], proj_a[:, 1:2], proj_a[:, 2:3], proj_b[:, 0:1]]
         # everything after the renders (:399-440: background plane, soft-max over the 5 planes, SCOPS soft centroids of
         # both stacks, per-plane max normalisation, weighted MSE) is one fused op: 4 launches forward, 1 backward
-        l_eqv, l_lm = UF.PartMatchFunction.apply(proj_a, proj_b, part_segs, self._w5, 0.1, 1e-3)
+        l_eqv, l_lm = UF.part_match(proj_a, proj_b, part_segs, self._w5, 0.1, 1e-3)
         H, W = proj_a.shape[2], proj_a.shape[3]
         if avg:
             loss_eqv = l_eqv.sum() / (bs * 5 * H * W)

@@ -75,8 +75,8 @@ class Upsample2x(nn.Module):
 
     def forward(self, x):
         if x.is_cuda:
-            from .functional import Upsample2xBilinearFunction
-            return Upsample2xBilinearFunction.apply(x)
+            from .functional import upsample2x_bilinear
+            return upsample2x_bilinear(x)
         return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
 
 

@@ -4,8 +4,8 @@ umr_amd/ops.py registers the rasterizer (the reference's own extension module, s
 north_star asks for ALL kernels of the path as custom ops; this module registers the geometry and loss kernels the same way:
 a schema, a device implementation, a fake (meta) kernel for FakeTensor tracing / torch.library.opcheck, and an autograd
 formula whose backward is itself a registered operator.  The implementations are the ctypes calls of umr_amd/functional.py
-(the autograd.Function classes there stay the Python-level entry points the loss modules use; both routes enqueue the same
-libumr_hip.so kernels on the current stream).
+(the *Kernel classes there; these operators are the ONE route from the loss / geometry modules into them -- umr_amd.functional's
+call wrappers, and the `XFunction.apply` forms kept for tests, forward here).
 
   umr::project_points(verts[N,V,3], cams[N,7], int out_dim, float offset_z) -> [N,V,out_dim]     geom_utils.py:60-91
   umr::neg_iou(predict[N,...], target[N,...]) -> (loss[N], sums)                                  loss_utils.py:41-48
@@ -19,6 +19,11 @@ libumr_hip.so kernels on the current stream).
   umr::row_norm_mean(x[...,W]) -> scalar, umr::abs_column_mean(x[...,W], int column) -> scalar    loss_utils.py:118-126
   umr::masked_l1(img_pred, img_gt, mask_gt, mask_pred) -> per_sample[B]                           loss_utils.py:103-116
   umr::project_faces(verts, cams, faces int32, float offset_z, float eye_z) -> face_vertices[N,F,3,3]   smr.py:36-44 fused
+  umr::project_faces_lit(verts, cams, faces, offset_z, eye_z, bool want_pre, float[] light) -> (face_pre, face_vertices, light[N,F,3])
+        the same with the pre-look_at faces and / or sr.Lighting's per-face surface light (lighting.py:50-57); light = [] or
+        [ambient, directional, colour x 3, direction x 3]
+  umr::upsample2x_bilinear(x[B,C,H,W]) -> [B,C,2H,2W]                                             cub_mesh.py:150-157 (texture decoder)
+  umr::perceptual_prologue(img, mask, float[] shift, float[] scale) -> Tensor                     loss_utils.py:141-146 input side
 each with umr::<name>_backward.
 """
 from typing import List
@@ -31,41 +36,33 @@ from . import functional as UF
 _LIB = Library("umr", "FRAGMENT")
 
 
-class _Ctx:
-    """Minimal stand-in for an autograd context: the Function classes of functional.py are driven through it."""
-
-    def __init__(self, needs=(), **attrs):
-        self.needs_input_grad = needs
-        self.saved_tensors = ()
-        self.__dict__.update(attrs)
-
-    def save_for_backward(self, *t):
-        self.saved_tensors = t
-
-    def mark_non_differentiable(self, *t):
-        pass
+_Ctx = UF.KernelCtx     # the kernels' own forward -> backward context (umr_amd/functional.py)
 
 
 def _f32(t, *shape):
     return t.new_empty(shape, dtype=torch.float32)
 
 
+IMPLS = []      # (name, implementation): tests/host_raster.py::emulated_product registers them for host tensors as well
+
+
 def _define(name, schema, impl, fake):
     _LIB.define(name + schema)
     _LIB.impl(name, impl, "CUDA")
+    IMPLS.append((name, impl))
     register_fake("umr::" + name)(fake)
 
 
 # ---------------------------------------------------------------------------------------------- project_points
 _define("project_points", "(Tensor verts, Tensor cams, int out_dim, float offset_z) -> Tensor",
-        lambda verts, cams, out_dim, offset_z: UF.ProjectPointsFunction.forward(_Ctx(), verts, cams, out_dim, offset_z),
+        lambda verts, cams, out_dim, offset_z: UF.ProjectPointsKernel.forward(_Ctx(), verts, cams, out_dim, offset_z),
         lambda verts, cams, out_dim, offset_z: _f32(verts, verts.shape[0], verts.shape[1], out_dim))
 
 
 def _pp_bwd(grad, verts, cams, out_dim, need_verts):
     ctx = _Ctx((need_verts, True), out_dim=out_dim)
     ctx.saved_tensors = (UF._f32c(verts), UF._f32c(cams))
-    gv, gc, _, _ = UF.ProjectPointsFunction.backward(ctx, grad)
+    gv, gc, _, _ = UF.ProjectPointsKernel.backward(ctx, grad)
     return (gv if gv is not None else verts.new_empty(0)), gc
 
 
@@ -90,7 +87,7 @@ register_autograd("umr::project_points", _pp_autograd, setup_context=_pp_setup)
 # ---------------------------------------------------------------------------------------------- neg_iou
 def _iou_fwd(predict, target):
     ctx = _Ctx()
-    loss = UF.NegIoUFunction.forward(ctx, predict, target)
+    loss = UF.NegIoUKernel.forward(ctx, predict, target)
     return loss, ctx.saved_tensors[2]
 
 
@@ -106,7 +103,7 @@ _define("neg_iou", "(Tensor predict, Tensor target) -> (Tensor, Tensor)", _iou_f
 def _iou_bwd(grad, predict, target, sums):
     ctx = _Ctx(shape=predict.shape)
     ctx.saved_tensors = (UF._f32c(predict).view(predict.shape[0], -1), UF._f32c(target).view(target.shape[0], -1), sums)
-    return UF.NegIoUFunction.backward(ctx, grad)[0]
+    return UF.NegIoUKernel.backward(ctx, grad)[0]
 
 
 _define("neg_iou_backward", "(Tensor grad, Tensor predict, Tensor target, Tensor sums) -> Tensor", _iou_bwd,
@@ -117,7 +114,7 @@ register_autograd("umr::neg_iou", lambda ctx, g, _gs: (torch.ops.umr.neg_iou_bac
 
 # ---------------------------------------------------------------------------------------------- chamfer
 _define("chamfer", "(Tensor a, Tensor b) -> (Tensor, Tensor, Tensor, Tensor)",
-        lambda a, b: UF.ChamferFunction.forward(_Ctx(), a, b),
+        lambda a, b: UF.ChamferKernel.forward(_Ctx(), a, b),
         lambda a, b: (_f32(a, a.shape[0], a.shape[1]), _f32(a, b.shape[0], b.shape[1]),
                       a.new_empty((a.shape[0], a.shape[1]), dtype=torch.int32), a.new_empty((b.shape[0], b.shape[1]), dtype=torch.int32)))
 
@@ -125,7 +122,7 @@ _define("chamfer", "(Tensor a, Tensor b) -> (Tensor, Tensor, Tensor, Tensor)",
 def _ch_bwd(g1, g2, a, b, i1, i2):
     ctx = _Ctx()
     ctx.saved_tensors = (UF._f32c(a), UF._f32c(b), i1, i2)
-    return UF.ChamferFunction.backward(ctx, g1, g2, None, None)
+    return UF.ChamferKernel.backward(ctx, g1, g2, None, None)
 
 
 _define("chamfer_backward", "(Tensor g1, Tensor g2, Tensor a, Tensor b, Tensor i1, Tensor i2) -> (Tensor, Tensor)", _ch_bwd,
@@ -145,14 +142,14 @@ register_autograd("umr::chamfer", _ch_autograd,
 
 # ---------------------------------------------------------------------------------------------- grid_sample (channels last)
 _define("grid_sample_cl", "(Tensor image, Tensor grid) -> Tensor",
-        lambda image, grid: UF.GridSampleCLFunction.forward(_Ctx(), image, grid),
+        lambda image, grid: UF.GridSampleCLKernel.forward(_Ctx(), image, grid),
         lambda image, grid: _f32(image, image.shape[0], grid.shape[1], image.shape[1]))
 
 
 def _gs_bwd(grad, image, grid, need_image, need_grid):
     ctx = _Ctx((need_image, need_grid))
     ctx.saved_tensors = (UF._f32c(image), UF._f32c(grid))
-    gi, gg = UF.GridSampleCLFunction.backward(ctx, grad)
+    gi, gg = UF.GridSampleCLKernel.backward(ctx, grad)
     return (gi if gi is not None else image.new_empty(0)), (gg if gg is not None else image.new_empty(0))
 
 
@@ -174,7 +171,7 @@ register_autograd("umr::grid_sample_cl", _gs_autograd, setup_context=lambda ctx,
 # ---------------------------------------------------------------------------------------------- laplacian / flatten
 def _lap_fwd(x, nbr_off, nbr_idx):
     ctx = _Ctx()
-    loss = UF.LaplacianFunction.forward(ctx, x, nbr_off, nbr_idx)
+    loss = UF.LaplacianKernel.forward(ctx, x, nbr_off, nbr_idx)
     return loss, ctx.saved_tensors[0]
 
 
@@ -185,7 +182,7 @@ _define("laplacian", "(Tensor x, Tensor nbr_off, Tensor nbr_idx) -> (Tensor, Ten
 def _lap_bwd(grad, lap, nbr_off, nbr_idx):
     ctx = _Ctx()
     ctx.saved_tensors = (lap, nbr_off, nbr_idx)
-    return UF.LaplacianFunction.backward(ctx, grad)[0]
+    return UF.LaplacianKernel.backward(ctx, grad)[0]
 
 
 _define("laplacian_backward", "(Tensor grad, Tensor lap, Tensor nbr_off, Tensor nbr_idx) -> Tensor", _lap_bwd,
@@ -194,13 +191,13 @@ register_autograd("umr::laplacian", lambda ctx, g, _gl: (torch.ops.umr.laplacian
                   setup_context=lambda ctx, inputs, output: ctx.save_for_backward(output[1], inputs[1], inputs[2]))
 
 _define("flatten", "(Tensor x, Tensor quads) -> Tensor",
-        lambda x, quads: UF.FlattenFunction.forward(_Ctx(), x, quads), lambda x, quads: _f32(x, x.shape[0]))
+        lambda x, quads: UF.FlattenKernel.forward(_Ctx(), x, quads), lambda x, quads: _f32(x, x.shape[0]))
 
 
 def _fl_bwd(grad, x, quads):
     ctx = _Ctx()
     ctx.saved_tensors = (UF._f32c(x), quads)
-    return UF.FlattenFunction.backward(ctx, grad)[0]
+    return UF.FlattenKernel.backward(ctx, grad)[0]
 
 
 _define("flatten_backward", "(Tensor grad, Tensor x, Tensor quads) -> Tensor", _fl_bwd, lambda grad, x, quads: _f32(x, *x.shape))
@@ -211,7 +208,7 @@ register_autograd("umr::flatten", lambda ctx, g: (torch.ops.umr.flatten_backward
 # ---------------------------------------------------------------------------------------------- PNet head (cos_sim)
 def _cos_fwd(feats0: List[torch.Tensor], feats1: List[torch.Tensor], eps: float):
     ctx = _Ctx()
-    val = UF.CosSimDistanceFunction.forward(ctx, eps, *feats0, *feats1)
+    val = UF.CosSimDistanceKernel.forward(ctx, eps, *feats0, *feats1)
     return val, ctx.saved_tensors[0]
 
 
@@ -234,7 +231,7 @@ def _cos_bwd(grad, feats0: List[torch.Tensor], feats1: List[torch.Tensor], ws, e
     T = len(feats0)
     ctx = _Ctx((False,) + tuple(need), eps=float(eps), T=T)
     ctx.saved_tensors = (ws,) + tuple(UF._f32c(f) for f in feats0) + tuple(UF._f32c(f) for f in feats1)
-    out = UF.CosSimDistanceFunction.backward(ctx, grad)[1:]
+    out = UF.CosSimDistanceKernel.backward(ctx, grad)[1:]
     return [g if g is not None else grad.new_empty(0) for g in out]
 
 
@@ -266,7 +263,7 @@ register_autograd("umr::cos_sim", _cos_autograd, setup_context=_cos_setup)
 # ---------------------------------------------------------------------------------------------- part_match
 def _pm_fwd(render_a, render_b, part_segs, weights5: List[float], background: float, center_eps: float):
     ctx = _Ctx()
-    e, l = UF.PartMatchFunction.forward(ctx, render_a, render_b, part_segs, weights5, background, center_eps)
+    e, l = UF.PartMatchKernel.forward(ctx, render_a, render_b, part_segs, weights5, background, center_eps)
     return e.clone(), l.clone(), ctx.saved_tensors[3]     # (the two results are rows of one buffer: outputs may not alias)
 
 
@@ -282,7 +279,7 @@ _define("part_match", "(Tensor render_a, Tensor render_b, Tensor part_segs, floa
 def _pm_bwd(g_eqv, g_lm, render_a, render_b, part_segs, ws, weights5: List[float], background: float, center_eps: float):
     ctx = _Ctx(cfg=([float(x) for x in weights5], float(background), float(center_eps)))
     ctx.saved_tensors = (UF._f32c(render_a), UF._f32c(render_b), UF._f32c(part_segs), ws)
-    ga, gb = UF.PartMatchFunction.backward(ctx, g_eqv, g_lm)[:2]
+    ga, gb = UF.PartMatchKernel.backward(ctx, g_eqv, g_lm)[:2]
     return ga, gb
 
 
@@ -317,27 +314,27 @@ _define("dt_barrier", "(Tensor mask, float k) -> Tensor", _dt_fwd, lambda mask, 
 
 
 # ---------------------------------------------------------------------------------------------- small regularisers, masked L1
-_define("row_norm_mean", "(Tensor x) -> Tensor", lambda x: UF.RowNormMeanFunction.forward(_Ctx(), x), lambda x: _f32(x))
+_define("row_norm_mean", "(Tensor x) -> Tensor", lambda x: UF.RowNormMeanKernel.forward(_Ctx(), x), lambda x: _f32(x))
 
 
 def _rn_bwd(grad, x):
     ctx = _Ctx(shape=x.shape)
     ctx.saved_tensors = (UF._f32c(x).view(-1, x.shape[-1]),)
-    return UF.RowNormMeanFunction.backward(ctx, grad)
+    return UF.RowNormMeanKernel.backward(ctx, grad)
 
 
 _define("row_norm_mean_backward", "(Tensor grad, Tensor x) -> Tensor", _rn_bwd, lambda grad, x: _f32(x, *x.shape))
 register_autograd("umr::row_norm_mean", lambda ctx, g: torch.ops.umr.row_norm_mean_backward(g, *ctx.saved_tensors),
                   setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0]))
 
-_define("abs_column_mean", "(Tensor x, int column) -> Tensor", lambda x, column: UF.AbsColumnMeanFunction.forward(_Ctx(), x, column),
+_define("abs_column_mean", "(Tensor x, int column) -> Tensor", lambda x, column: UF.AbsColumnMeanKernel.forward(_Ctx(), x, column),
         lambda x, column: _f32(x))
 
 
 def _ac_bwd(grad, x, column):
     ctx = _Ctx(shape=x.shape, column=int(column))
     ctx.saved_tensors = (UF._f32c(x).view(-1, x.shape[-1]),)
-    return UF.AbsColumnMeanFunction.backward(ctx, grad)[0]
+    return UF.AbsColumnMeanKernel.backward(ctx, grad)[0]
 
 
 _define("abs_column_mean_backward", "(Tensor grad, Tensor x, int column) -> Tensor", _ac_bwd, lambda grad, x, column: _f32(x, *x.shape))
@@ -352,13 +349,13 @@ register_autograd("umr::abs_column_mean", lambda ctx, g: (torch.ops.umr.abs_colu
                   setup_context=_ac_setup)
 
 _define("masked_l1", "(Tensor img_pred, Tensor img_gt, Tensor mask_gt, Tensor mask_pred) -> Tensor",
-        lambda ip, ig, mg, mp: UF.MaskedL1Function.forward(_Ctx(), ip, ig, mg, mp), lambda ip, ig, mg, mp: _f32(ip, ip.shape[0]))
+        lambda ip, ig, mg, mp: UF.MaskedL1Kernel.forward(_Ctx(), ip, ig, mg, mp), lambda ip, ig, mg, mp: _f32(ip, ip.shape[0]))
 
 
 def _ml_bwd(grad, ip, ig, mg, mp, need_img, need_mask):
     ctx = _Ctx((need_img, False, False, need_mask), mp_shape=mp.shape)
     ctx.saved_tensors = (UF._f32c(ip), UF._f32c(ig), UF._f32c(mg), UF._f32c(mp))
-    gi, _, _, gm = UF.MaskedL1Function.backward(ctx, grad)
+    gi, _, _, gm = UF.MaskedL1Kernel.backward(ctx, grad)
     return (gi if gi is not None else ip.new_empty(0)), (gm if gm is not None else ip.new_empty(0))
 
 
@@ -378,7 +375,7 @@ register_autograd("umr::masked_l1", _ml_autograd, setup_context=lambda ctx, inpu
 
 # ---------------------------------------------------------------------------------------------- project_faces (ambient light)
 def _pf_fwd(verts, cams, faces_idx, offset_z: float, eye_z: float):
-    return UF.ProjectFacesFunction.forward(_Ctx(), verts, cams, faces_idx, offset_z, eye_z, False, None)[1]
+    return UF.ProjectFacesKernel.forward(_Ctx(), verts, cams, faces_idx, offset_z, eye_z, False, None)[1]
 
 
 _define("project_faces", "(Tensor verts, Tensor cams, Tensor faces_idx, float offset_z, float eye_z) -> Tensor", _pf_fwd,
@@ -388,7 +385,7 @@ _define("project_faces", "(Tensor verts, Tensor cams, Tensor faces_idx, float of
 def _pf_bwd(grad, verts, cams, faces_idx, need_verts):
     ctx = _Ctx((need_verts, True), light=None, want_pre=False)
     ctx.saved_tensors = (UF._f32c(verts), UF._f32c(cams), faces_idx)
-    gv, gc = UF.ProjectFacesFunction.backward(ctx, None, grad, None)[:2]
+    gv, gc = UF.ProjectFacesKernel.backward(ctx, None, grad, None)[:2]
     return (gv if gv is not None else verts.new_empty(0)), gc
 
 
@@ -404,5 +401,104 @@ def _pf_autograd(ctx, g):
 
 register_autograd("umr::project_faces", _pf_autograd, setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1], inputs[2]))
 
+
+# ---------------------------------------------------------------------------------------------- project_faces_lit (full form)
+def _light_tuple(light):
+    return None if len(light) == 0 else (light[0], light[1], tuple(light[2:5]), tuple(light[5:8]))
+
+
+def _pfl_fwd(verts, cams, faces_idx, offset_z: float, eye_z: float, want_pre: bool, light: List[float]):
+    return UF.ProjectFacesKernel.forward(_Ctx(), verts, cams, faces_idx, offset_z, eye_z, want_pre, _light_tuple(light))
+
+
+def _pfl_fake(verts, cams, faces_idx, offset_z, eye_z, want_pre, light):
+    N, F = cams.shape[0], faces_idx.shape[1]
+    return ((_f32(verts, N, F, 3, 3) if want_pre else _f32(verts, 0)), _f32(verts, N, F, 3, 3),
+            (_f32(verts, N, F, 3) if len(light) else _f32(verts, 0)))
+
+
+_define("project_faces_lit", "(Tensor verts, Tensor cams, Tensor faces_idx, float offset_z, float eye_z, bool want_pre, float[] light) "
+        "-> (Tensor, Tensor, Tensor)", _pfl_fwd, _pfl_fake)
+
+
+def _pfl_bwd(g_pre, g_out, g_light, face_out, verts, cams, faces_idx, want_pre: bool, light: List[float], need_verts: bool):
+    import ctypes
+    lt = _light_tuple(light)
+    ctx = _Ctx((need_verts, True), want_pre=want_pre,
+               light=((float(lt[1]), (ctypes.c_float * 3)(*[float(x) for x in lt[2]]), (ctypes.c_float * 3)(*[float(x) for x in lt[3]]))
+                      if lt is not None else None))
+    ctx.saved_tensors = (UF._f32c(verts), UF._f32c(cams), faces_idx) + ((face_out,) if lt is not None else ())
+    gv, gc = UF.ProjectFacesKernel.backward(ctx, (g_pre if want_pre else None), g_out, (g_light if lt is not None else None))[:2]
+    return (gv if gv is not None else verts.new_empty(0)), gc
+
+
+_define("project_faces_lit_backward", "(Tensor g_pre, Tensor g_out, Tensor g_light, Tensor face_out, Tensor verts, Tensor cams, Tensor faces_idx, "
+        "bool want_pre, float[] light, bool need_verts) -> (Tensor, Tensor)", _pfl_bwd,
+        lambda g_pre, g_out, g_light, face_out, verts, cams, faces_idx, want_pre, light, need_verts:
+        ((_f32(verts, *verts.shape) if need_verts else _f32(verts, 0)), _f32(cams, *cams.shape)))
+
+
+def _pfl_setup(ctx, inputs, output):
+    verts, cams, faces_idx, _, _, want_pre, light = inputs
+    ctx.want_pre, ctx.light = want_pre, list(light)
+    ctx.save_for_backward(verts, cams, faces_idx, output[1])
+
+
+def _pfl_autograd(ctx, g_pre, g_out, g_light):
+    v, c, f, face_out = ctx.saved_tensors
+    N, F = c.shape[0], f.shape[1]
+    z = lambda g, *shape: g if g is not None else face_out.new_zeros(shape)
+    gv, gc = torch.ops.umr.project_faces_lit_backward(z(g_pre, N, F, 3, 3) if ctx.want_pre else face_out.new_empty(0), z(g_out, N, F, 3, 3),
+                                                       z(g_light, N, F, 3) if ctx.light else face_out.new_empty(0), face_out, v, c, f,
+                                                       ctx.want_pre, ctx.light, ctx.needs_input_grad[0])
+    return (gv if ctx.needs_input_grad[0] else None), (gc if ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
+register_autograd("umr::project_faces_lit", _pfl_autograd, setup_context=_pfl_setup)
+
+
+# ---------------------------------------------------------------------------------------------- upsample2x_bilinear
+_define("upsample2x_bilinear", "(Tensor x) -> Tensor", lambda x: UF.Upsample2xBilinearKernel.forward(_Ctx(), x),
+        lambda x: _f32(x, x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3]))
+_define("upsample2x_bilinear_backward", "(Tensor grad) -> Tensor",
+        lambda grad: UF.Upsample2xBilinearKernel.backward(_Ctx(shape=(grad.shape[0], grad.shape[1], grad.shape[2] // 2, grad.shape[3] // 2)), grad),
+        lambda grad: _f32(grad, grad.shape[0], grad.shape[1], grad.shape[2] // 2, grad.shape[3] // 2))
+register_autograd("umr::upsample2x_bilinear", lambda ctx, g: torch.ops.umr.upsample2x_bilinear_backward(g),
+                  setup_context=lambda ctx, inputs, output: None)
+
+
+# ---------------------------------------------------------------------------------------------- perceptual_prologue
+_define("perceptual_prologue", "(Tensor img, Tensor mask, float[] shift, float[] scale) -> Tensor",
+        lambda img, mask, shift, scale: UF.PerceptualPrologueKernel.forward(_Ctx(), img, mask, shift, scale),
+        lambda img, mask, shift, scale: _f32(img, *img.shape))
+
+
+def _ppl_bwd(grad, img, mask, scale: List[float], need_img: bool, need_mask: bool):
+    ctx = _Ctx((need_img, need_mask), scale=[float(v) for v in scale])
+    ctx.saved_tensors = (UF._f32c(img), UF._f32c(mask))
+    gi, gm = UF.PerceptualPrologueKernel.backward(ctx, grad)[:2]
+    return (gi if gi is not None else img.new_empty(0)), (gm if gm is not None else img.new_empty(0))
+
+
+_define("perceptual_prologue_backward", "(Tensor grad, Tensor img, Tensor mask, float[] scale, bool need_img, bool need_mask) -> (Tensor, Tensor)",
+        _ppl_bwd, lambda grad, img, mask, scale, need_img, need_mask: ((_f32(img, *img.shape) if need_img else _f32(img, 0)),
+                                                                      (_f32(mask, *mask.shape) if need_mask else _f32(img, 0))))
+
+
+def _ppl_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+    ctx.scale = list(inputs[3])
+
+
+def _ppl_autograd(ctx, g):
+    img, mask = ctx.saved_tensors
+    ni, nm = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    gi, gm = torch.ops.umr.perceptual_prologue_backward(g, img, mask, ctx.scale, ni, nm)
+    return (gi if ni else None), (gm.view(mask.shape) if nm else None), None, None
+
+
+register_autograd("umr::perceptual_prologue", _ppl_autograd, setup_context=_ppl_setup)
+
 ALL_OPS = ("project_points", "neg_iou", "chamfer", "grid_sample_cl", "laplacian", "flatten", "cos_sim", "part_match", "dt_barrier",
-           "row_norm_mean", "abs_column_mean", "masked_l1", "project_faces")
+           "row_norm_mean", "abs_column_mean", "masked_l1", "project_faces", "project_faces_lit", "upsample2x_bilinear",
+           "perceptual_prologue")

@@ -36,7 +36,7 @@ class AlexNetFeatures(nn.Module):
 def cos_sim_distance(feats0, feats1, eps=1e-10):
     """sum over the feature pairs of 1 - util.cos_sim(f0, f1) (networks_basic.py:50-58, util/util.py:71-83) -> [N].
     GPU tensors only (umr_cos_sim_forward / _backward); there is no eager fallback."""
-    return UF.CosSimDistanceFunction.apply(eps, *feats0, *feats1)
+    return UF.cos_sim_distance(eps, feats0, feats1)
 
 
 class PNet(nn.Module):
@@ -96,9 +96,9 @@ class PerceptualTextureLoss(object):
             if getattr(net, "_host_consts", None) is None:     # read the two buffers back once, not once per step
                 net._host_consts = (net.shift.flatten().tolist(), net.scale.flatten().tolist())
             sh, sc = net._host_consts
-            x_pred = UF.PerceptualPrologueFunction.apply(img_pred, m_pred, sh, sc)
+            x_pred = UF.perceptual_prologue(img_pred, m_pred, sh, sc)
             with torch.no_grad():
-                x_gt = UF.PerceptualPrologueFunction.apply(img_gt, mask_gt, sh, sc)
+                x_gt = UF.perceptual_prologue(img_gt, mask_gt, sh, sc)
             dist = net.forward_scaled(x_gt, x_pred)          # forward_pair(target, pred)
         else:
             dist = self.perceptual_loss(img_pred * m_pred.unsqueeze(1), img_gt * mask_gt.unsqueeze(1))

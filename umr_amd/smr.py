@@ -50,7 +50,7 @@ class SoftRenderer(torch.nn.Module):
 
     def project_points(self, verts, cams):
         """smr.py:76-78 -> [N,V,2]."""
-        return UF.ProjectPointsFunction.apply(verts, cams, 2, 0.0)
+        return UF.project_points(verts, cams, 2, 0.0)
 
     def _const(self, ref, values):
         """Small device constant (light colour / direction, background), uploaded once per (device, value): building
@@ -68,9 +68,9 @@ class SoftRenderer(torch.nn.Module):
         views per mesh (view n renders mesh n // (N / M)), e.g. the seen and the rotated camera of each image interleaved,
         so both silhouettes of a training step come out of ONE launch per direction."""
         faces = faces.int().contiguous()
-        _, face_out, _ = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
+        _, face_out, _ = UF.project_faces(vertices, cams, faces, self.offset_z, self.eye_z, False)
         size = self.img_size * (2 if self.anti_aliasing else 1)
-        return UF.SilhouetteFunction.apply(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
+        return UF.silhouette(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
                                            self.dist_eps, self.gamma_val, self.anti_aliasing)
 
     def forward(self, vertices, faces, cams, textures=None, with_visibility=False, detach_rgb_geometry=False):
@@ -90,7 +90,7 @@ class SoftRenderer(torch.nn.Module):
         N = cams.shape[0]
         if self.ids_only and self.render_type == 'hard':
             with torch.no_grad():
-                _, face_out, _ = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False)
+                _, face_out, _ = UF.project_faces(vertices, cams, faces, self.offset_z, self.eye_z, False)
                 size = self.img_size * (2 if self.anti_aliasing else 1)
                 aggr = UF.visibility(face_out, size, self.near, self.far, True, self.eps, self.sigma_val, self.dist_eps,
                                      self.gamma_val)
@@ -109,7 +109,7 @@ class SoftRenderer(torch.nn.Module):
         # the projected faces); ambient-only lighting is a constant factor
         light = (self.light_intensity_ambient, self.light_intensity_directional, self.light_color,
                  self.light_direction) if directional else None
-        _, face_out, face_light = UF.ProjectFacesFunction.apply(vertices, cams, faces, self.offset_z, self.eye_z, False,
+        _, face_out, face_light = UF.project_faces(vertices, cams, faces, self.offset_z, self.eye_z, False,
                                                                 light)
         F = faces.shape[1]
         if directional:
