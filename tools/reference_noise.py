@@ -8,7 +8,7 @@ for bit the reference's arithmetic, tests/test_kernel_source_on_host.py).
   cull    outside pixels the reference still includes (computed distance below the threshold) although their exact distance is
           beyond it: the largest exact excess, and the slack the tile cull needs in its own units, by the face's smallest height
 
-    python tools/r3/reference_noise.py edge|cull [faces]
+    python tools/reference_noise.py edge|cull [faces]
 """
 import ctypes
 import math
@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HK = os.path.join(ROOT, "tests", "host_kernel")
 f32 = np.float32
 P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float

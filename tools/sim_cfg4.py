@@ -3,7 +3,7 @@ configs[3] (1024^2 render, 5120 faces) -- (pixel, face) pairs under the sigma-di
 least one contributing pixel of a face (= the visits a perfect cull would make)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_ref as TR
 from umr_amd.synthetic import make_s1_inputs
 

@@ -1,7 +1,7 @@
 """CPU simulation behind DESIGN.md section 4.1: how tight is the conservative tile-vs-dilated-triangle test?  bbox-only
 candidates, the current test, the current test + vertex-axis separating tests, and the exact need, per mesh."""
 import numpy as np, torch, sys
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_ref as TR
 from umr_amd.synthetic import make_s1_inputs
 B=2; H=256; IS=512

@@ -5,7 +5,7 @@ ideal sub-tile cull).  usage: sim_subtile.py [scale_lo scale_hi] [subdiv IS]"""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_ref as TR
 from tests.helpers import scene
 

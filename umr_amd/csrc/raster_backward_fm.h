@@ -124,7 +124,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const float lxf = (float)(2 * lx) * inv_is, lyf = (float)(2 * ly) * inv_is;
             const unsigned lo_pn = (unsigned)(ly * IS + lx) * 4u, lo_gp = pooled ? (unsigned)((ly >> 1) * H2 + (lx >> 1)) * 4u : lo_pn;
 #endif
-#ifdef FM_NO_CULL            // time-split experiment (tools/r3/split.sh): per-face set-up and reductions only
+#ifdef FM_NO_CULL            // time-split experiment (-DFM_NO_CULL, HISTORY.md 4.2): per-face set-up and reductions only
             for (int tb = ntiles; tb < ntiles; tb += 64) {
 #else
             for (int tb = 0; tb < ntiles; tb += 64) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                 }
                 unsigned long long tm = __ballot(want);
                 visited |= tm != 0;
-#ifdef FM_NO_VISIT          // time-split experiment (tools/r3/split.sh): per-face set-up + culling pass only
+#ifdef FM_NO_VISIT          // time-split experiment (-DFM_NO_VISIT, HISTORY.md 4.2): per-face set-up + culling pass only
                 tm = 0;
 #endif
 #if FM_BODY_SLOTS
