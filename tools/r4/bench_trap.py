@@ -14,7 +14,7 @@ for kv in os.environ.get("UMR_DEBUG_SET", "").split(","):      # e.g. UMR_DEBUG_
         _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 import umr_amd.train_step as TS
 ring, seen = [], [0]
-KEYS = ("pred_vs", "delta_v", "cam", "cam_hypotheses", "cam_probs", "tex_flow")
+KEYS = ("pred_vs", "delta_v", "cam", "cam_hypotheses", "cam_probs")      # small tensors only: the ring has to fit gpurun_out (64 MiB)
 
 
 def hook(cls):
@@ -40,10 +40,16 @@ finally:
     h.umr_debug_trap.restype = ctypes.c_int
     when = ctypes.c_ulonglong(0)
     site = h.umr_debug_trap(0, ctypes.byref(when))
+    h.umr_debug_trap_where.restype = ctypes.c_ulonglong
+    where = h.umr_debug_trap_where()
+    info = int(where & 0xffffff) if where != 2 ** 64 - 1 else None
+    if info is not None:
+        sys.stderr.write("bench_trap: first raster-backward offender: launch with N %s 32, mesh-of-launch %d, face %d\n"
+                         % (">" if info >> 20 else "<=", (info >> 13) & 127, info & 0x1fff))
     bad_terms = [(s, k) for s, r in ring for k, v in r.get("terms", {}).items() if not math.isfinite(float(v))]
     sys.stderr.write("bench_trap: earliest non-finite report: site %d (0 = none) at device clock %d; steps seen %d; non-finite terms in the last steps: %s\n"
                      % (site, when.value, seen[0], bad_terms[:6]))
     if site or bad_terms:
         os.makedirs(os.path.join(ROOT, "gpurun_out", "nan"), exist_ok=True)
-        torch.save({"site": site, "ring": [(s, {k: (v.cpu() if torch.is_tensor(v) else {a: b.cpu() for a, b in v.items()}) for k, v in r.items()}) for s, r in ring]},
+        torch.save({"site": site, "where": info, "ring": [(s, {k: (v.cpu() if torch.is_tensor(v) else {a: b.cpu() for a, b in v.items()}) for k, v in r.items()}) for s, r in ring]},
                    os.path.join(ROOT, "gpurun_out", "nan", "repro_%d.pt" % os.getpid()))

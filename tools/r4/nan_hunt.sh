@@ -4,7 +4,7 @@
 # usage: nan_hunt.sh [N=20] [steps=60]
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/nan; mkdir -p $O
+O=gpurun_out/nan; rm -rf $O; mkdir -p $O
 N=${1:-20}; STEPS=${2:-60}
 # OLD=1: the tripwire build with round 3's EARLY settings -- tile cull band without the reference-noise widening, no thin-face
 # route, nearest edge by true distance everywhere (exact_edges off): the configuration the non-finite runs were seen on
@@ -19,7 +19,7 @@ for i in $(seq 1 $N); do
   timeout 600 python tools/r4/bench_trap.py --workload s2 --image-size 512 --subdivide 4 --steps $STEPS --warmup 2 --profile-steps 1 --cpu-baseline 0 > $O/run_$i.json 2> $O/run_$i.err
   rc=$?
   d=$(grep -o '"discarded_nonfinite_runs": [0-9]*' $O/run_$i.json | head -1)
-  s=$(grep -h "bench_trap: earliest" $O/run_$i.err | tail -1)
+  s=$(grep -h "bench_trap: earliest\|bench_trap: first raster" $O/run_$i.err | tr '\n' ' ')
   echo "run $i rc $rc $d | $s" | tee -a $O/summary.log
   if [ $rc -eq 0 ] && ! grep -q "site [1-9]" $O/run_$i.err && echo "$d" | grep -q ": 0"; then rm -f $O/run_$i.json $O/run_$i.err; fi
 done

@@ -112,6 +112,7 @@ struct ProfScope {  // brackets exactly one kernel launch on `st`
 }  // namespace
 
 UMR_TRAP_ACCESSOR(umr_trap_read_raster)
+UMR_TRAP_INFO_ACCESSOR(umr_debug_trap_where)
 #if UMR_TRAP
 extern "C" unsigned long long umr_trap_read_geometry(int), umr_trap_read_losses(int), umr_trap_read_perceptual(int), umr_trap_read_edt(int);
 // earliest non-finite report of the whole library: site id (0 = none), *when = its device wall-clock stamp

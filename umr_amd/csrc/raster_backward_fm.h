@@ -355,7 +355,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const float sv = wave_sum_full(gv[k]);
             if (lane == k) mine = sv;
         }
-        UMR_TRAP_IF(umr_bad(mine), 4);
+        UMR_TRAP_AT(umr_bad(mine), 4 | (RGB == 2 ? 0x40 : (RGB == 0 ? 0x80 : 0)), ((unsigned)(A.N > 32) << 20) | ((unsigned)(n & 127) << 13) | (unsigned)f);
         if (live && lane < 9) A.grad_faces[((size_t)n * F + f) * 9 + lane] += mine;
     }
     if (NEED_GT) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     float acc = wave_tex[j];
 #pragma unroll
                     for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
-                    UMR_TRAP_IF(umr_bad(acc), 4);
+                    UMR_TRAP_AT(umr_bad(acc), 5 | (RGB == 0 ? 0x80 : 0), ((unsigned)(A.N > 32) << 20) | ((unsigned)(n & 127) << 13) | (unsigned)f);
                     dst[j] += acc;
                 }
             }

@@ -370,23 +370,6 @@ __device__ __forceinline__ void load_face(Face &fc, const float *rg) {
     fc.edges = (const char *)(rg + R_EDGE);
 }
 
-// Warm the scalar cache with the NEXT face's record while this visit computes: two dword loads (one per 64-byte line of the 32
-// wave-uniform floats) whose result is never read.  gfx950 has no scalar prefetch instruction; scalar loads return out of order
-// and are waited for with lgkmcnt(0), so this is issued AFTER the current record has arrived (eval_pair calls it behind the
-// barycentrics) -- by the next visit's own wait the lines are in the cache (hit rate of the record loads without it: 76-82 %,
-// profiles/r04_pmc_r3_build_counters.json; a miss goes to L2, 250-800 cycles under load).
-#ifndef UMR_PREFETCH_REC
-#define UMR_PREFETCH_REC 1
-#endif
-__device__ __forceinline__ void scalar_touch(const float *rg, float after_v, float after_s) {   // after_*: values of BOTH halves of the
-#if UMR_PREFETCH_REC && !defined(UMR_HOST_SHIM)                 // CURRENT record -- inputs of the asm, so it cannot be scheduled before they arrived
-    unsigned t0_, t1_;
-    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40" : "=s"(t0_), "=s"(t1_) : "s"(rg), "v"(after_v), "s"(after_s));
-#else
-    (void)rg; (void)after_v; (void)after_s;
-#endif
-}
-
 // the 32 wave-uniform floats again (face-major backward: keeps them loop-VARIANT, see FM_RELOAD_PER_TILE)
 __device__ __forceinline__ void reload_face(Face &fc, const float *rg) {
     cv16f_t *r = (cv16f_t *)rg;
@@ -541,13 +524,12 @@ __device__ __forceinline__ bool eval_pair_region(Pair &p, const FaceT &fc, float
 // One wave vote picks the specialised body when all active lanes lie on one side of the face's boundary.
 template <class FaceT>
 __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, float yp, float threshold,
-                                          float neg_inv_sigma, float amb_thr = 0.f, bool active = true, const float *next_rec = nullptr) {
+                                          float neg_inv_sigma, float amb_thr = 0.f, bool active = true) {
     // barycentrics in the reference's operation order (no FMA): they decide inside/outside, feed the depth
     // chain and -- through cancellation -- carry ~1e-6 of rounding noise that has to match the reference's
     float w0, w1, w2;
     fc.bary(w0, w1, w2, xp, yp);
     p.w0 = w0; p.w1 = w1; p.w2 = w2;
-    if (next_rec) scalar_touch(next_rec, w2, fc.template g<R_FLAGS>());  // (wave-uniform) the record of the face this wave visits next
     // 0 < w_k < 1 for all k (:68-69) on the bit patterns: a float in (0, 1) is an integer in [1, 0x3f7fffff]; zeros, negatives
     // (sign bit), 1.0 and above, infinities and NaNs of either sign all fall outside after the wrapping decrement.  Three
     // full-rate subtractions, one three-operand max and one compare instead of six compares and five mask ANDs.

@@ -94,11 +94,7 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                     continue;
                 }
                 Pair p;
-                // (the next face of this tile's list, if any: its record is touched while this visit computes)
-                // (branch-free: the last face of a list touches its own record again -- a merge point would put a scalar-load wait,
-                // which waits for ALL scalar loads in flight, right behind the touch)
-                const float *next_rec = rec_n + (size_t)__builtin_amdgcn_readlane(fcand, m ? __builtin_ctzll(m) : b) * REC;
-                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr, t.valid, next_rec) & t.valid;
+                const bool live = eval_pair(p, fc, t.xp, t.yp, A.threshold, A.nis, A.amb_thr, t.valid) & t.valid;
                 if (RGB == 2) {
                     alpha *= live ? 1.f - p.frag : 1.f;
                     continue;

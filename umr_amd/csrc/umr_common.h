@@ -106,6 +106,23 @@ __device__ __forceinline__ void umr_trap(bool nonfinite, unsigned site) {
     if (nonfinite) atomicMin(&g_umr_trap, ((unsigned long long)wall_clock64() << 8) | (unsigned long long)(site & 0xffu));
 }
 #define UMR_TRAP_IF(cond, site) umr_trap((cond), (site))
+// ... and WHERE: a second word, min over reports of (device clock << 24 | 24 bits the site packs -- the raster backward:
+// launch size class << 20 | mesh of the launch << 13 | face), so the offending (view, face) can be replayed on the CPU
+static __device__ unsigned long long g_umr_trap_info = ~0ull;
+__device__ __forceinline__ void umr_trap_at(bool nonfinite, unsigned site, unsigned info) {
+    if (nonfinite) {
+        const unsigned long long c = (unsigned long long)wall_clock64();
+        atomicMin(&g_umr_trap, (c << 8) | (unsigned long long)(site & 0xffu));
+        atomicMin(&g_umr_trap_info, (c << 24) | (unsigned long long)(info & 0xffffffu));
+    }
+}
+#define UMR_TRAP_AT(cond, site, info) umr_trap_at((cond), (site), (info))
+#define UMR_TRAP_INFO_ACCESSOR(name)                                                                         \
+    extern "C" unsigned long long name(void) {                                                               \
+        unsigned long long v = ~0ull;                                                                        \
+        (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_umr_trap_info), sizeof(v), 0, hipMemcpyDeviceToHost);     \
+        return v;                                                                                            \
+    }
 #define UMR_TRAP_ACCESSOR(name)                                                                              \
     extern "C" unsigned long long name(int reset) {                                                          \
         unsigned long long v = ~0ull;                                                                        \
@@ -116,11 +133,13 @@ __device__ __forceinline__ void umr_trap(bool nonfinite, unsigned site) {
     }
 #else
 #define UMR_TRAP_IF(cond, site) ((void)0)
+#define UMR_TRAP_AT(cond, site, info) ((void)0)
+#define UMR_TRAP_INFO_ACCESSOR(name)
 #define UMR_TRAP_ACCESSOR(name)
 __device__ __forceinline__ bool umr_bad(float) { return false; }
 #endif
 // site ids: 1 raster face setup: non-finite vertex in | 2 raster forward: non-finite pixel out | 3 raster backward: non-finite
-// incoming gradient | 4 raster backward: non-finite gradient out | 10 projection: vertex / camera in | 11 projection backward:
+// incoming gradient | 4 raster backward: non-finite vertex gradient out, 5: texel gradient out (+ 0x40 silhouette variant, + 0x80 hard) | 10 projection: vertex / camera in | 11 projection backward:
 // incoming gradient | 12 projection backward: gradient out | 20 IoU loss out | 21 IoU backward incoming | 22 grid-sample out |
 // 23 grid-sample backward incoming | 24 grid-sample backward out | 25 Laplacian in | 26 flatten in | 27 up-sampling in |
 // 28 up-sampling backward incoming | 30 PNet head: feature in | 31 PNet head: value out | 32 PNet backward: gradient out |
