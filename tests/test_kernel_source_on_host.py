@@ -71,7 +71,7 @@ def _alpha_from_kernel_source(h, fv, IS, sigma, dist_eps_log):
 
 
 def test_kernel_pair_geometry_on_host_vs_oracle(host_lib, oracle_built):
-    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eval_pair_model import fuzz_cases
     from oracle import softras
     IS, n = 48, 160
@@ -110,7 +110,7 @@ def test_tile_culling_of_the_kernel_source_is_conservative(host_lib):
     reference's COMPUTED distance can be ~30 % short of the geometric one -- its arithmetic is ill conditioned there -- so a
     pixel 1.2 thresholds away from the needle still gets D ~ 1e-7 from the reference while the geometric cull, rightly,
     drops its tile; parity is unaffected at the 1e-4 the renders are held to.)"""
-    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eval_pair_model import fuzz_cases
     IS, n = 48, 120
     sigma, del_ = 1e-5, float(np.log(1. / 1e-10 - 1.))
@@ -138,7 +138,7 @@ def test_texel_lookup_of_the_kernel_source_vs_oracle(host_lib, oracle_built):
     """clip_depth + texel_index of the kernel source: with a 'hard' render of ONE face whose 36 texels carry their own index
     as colour, the oracle's image names the texel every covered pixel samples (soft_rasterize_cuda_kernel.cu:54-59,
     :180-189, :408-414) -- the host-compiled kernel source must name the same one."""
-    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eval_pair_model import fuzz_cases
     from oracle import softras
     IS, n, R = 48, 200, 6
@@ -166,7 +166,7 @@ def test_texel_lookup_of_the_kernel_source_vs_oracle(host_lib, oracle_built):
 def test_general_mode_fragments_of_the_kernel_source_vs_oracle(host_lib, oracle_built, dist_mode):
     """gen_fragment of raster_general.h (hard / barycentric distance, :154-157, :365-372) on the host against the oracle's
     alpha plane of one-face meshes."""
-    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eval_pair_model import fuzz_cases
     from oracle import softras
     IS, n = 48, 200
@@ -228,7 +228,7 @@ def test_depth_in_range_flag_of_the_kernel_source_is_sound(host_lib):
     perspective-correct depth and its range test (:592).  Sound only if the interpolated depth of such a face can never
     leave [near, far]: for faces the flag covers (vertex depths inside (near * 1.0001, far * 0.9999)), every live pixel's
     clip_depth of the kernel source must lie in range -- needles and slivers included."""
-    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from eval_pair_model import fuzz_cases
     IS, n = 48, 150
     sigma, del_ = 1e-5, float(np.log(1. / 1e-10 - 1.))
