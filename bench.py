@@ -303,7 +303,7 @@ def main(device=None, backend="nccl"):
     # together; config.discarded_nonfinite_runs counts them, the per-step loss history goes to stderr): after a NaN every
     # render degenerates (NaN geometry) and the timing means nothing.  Round 2 saw one such process in ~20; the cause -- a face
     # edge seen end-on makes the reference's own `den` exactly 0, and the inside branch of eval_pair did not skip that edge the
-    # way the reference's min-over-edges does -- is fixed (tests/test_gpu_zz_collapsed_edges.py); the
+    # way the reference's min-over-edges does -- is fixed (HISTORY.md section 5, tests/test_gpu_zz_collapsed_edges.py); the
     # guard stays.
     discarded = 0
     while True:
@@ -474,9 +474,9 @@ def main(device=None, backend="nccl"):
                                             ("render-and-compare step" if (args.graph and not use_model and world == 1) else None)),
                         "hot_path_loss_spread": loss_spread}, **rccl),
         # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
-        # `achieved` = algorithmic bytes of THAT variant (SURVEY 8d's rule -- each op-boundary buffer the
+        # `achieved` = algorithmic bytes of THAT variant (HISTORY.md 4.6: SURVEY 8d's rule -- each op-boundary buffer the
         # variant touches, once) / its mean HIP-event duration over the profile pass.
-        # `valu`: the resource that actually binds these kernels -- issued wave64 VALU instructions per launch,
+        # `valu`: the resource that actually binds these kernels (HISTORY.md 4.6) -- issued wave64 VALU instructions per launch,
         # the share of their lanes that was active, and the issue rate against the fp32 vector peak (1228.9 G wave-instr/s),
         # from SQ PMC passes of this command on this build (profiles/traffic.json; absent when that file is stale).
         "roofline": dict({"bound": "hbm", "kernel": "k_raster_backward_fm (textured render)", "peak": HBM_PEAK_GBS,

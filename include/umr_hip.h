@@ -44,7 +44,7 @@ int umr_profile_enable(int on);
 /* A/B switches for benchmarking kernel variants ("bwd_pixel_major": 1 selects the tile-binned
  * pixel-major backward with global atomics instead of the default face-major one; "superblock_bins",
  * "xcd_remap", "face_order", "face_order_group": see raster.hip), and two switches that trade time for
- * exactness.  Inside a triangle the reference keeps the edge line with the smallest COMPUTED
+ * exactness (HISTORY.md 4.4).  Inside a triangle the reference keeps the edge line with the smallest COMPUTED
  * distance (:78-107); the kernels pick it by its true distance unless the face is thin.
  *   "exact_edges" (default 1): inside pixels whose SECOND nearest edge line is closer than sqrt(20 sigma) evaluate
  *       all three lines the reference's way -- the nearest-edge choice then never differs from the reference's

@@ -6,7 +6,7 @@
 
 namespace {
 // ---- a well-conditioned closest-point evaluation (TEST INSTRUMENT, not product code) -------------------------------------
-// Round 3 built this as a 'lean' geometry for the face-major backward and measured it on the MI355X: rejected,
+// Round 3 built this as a 'lean' geometry for the face-major backward and measured it on the MI355X (HISTORY.md 4.7): rejected,
 // because what it differs by from eval_pair -- the reference formulation's own rounding noise -- decides which rim pixels
 // contribute.  It stays here to MEASURE that noise on the kernel source (test_reference_order_geometry_carries_rounding_noise).
 // The reference obtains the closest boundary point through barycentrics of O(1) homogeneous products (:63-152): region
@@ -204,6 +204,69 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
             if (hit) hit = tile_may_hit(q[0], q[1], q[2], cx, cy, hx, hy, thr + rec[(size_t)i * REC + R_CULL]);   // as the kernels call it
             out[(size_t)i * ntiles + t] = hit ? 1 : 0;
         }
+    }
+    delete[] rec; delete[] bbox;
+    return 0;
+}
+
+// The two raster directions cull at different granularity -- the forward per 8x8 wave tile, the face-major backward per 4x4
+// sub-tile -- and then decide per pixel with eval_pair.  For every face: all pixels under its dilated bbox (+ 2 pixels); counts
+//   out[0] pixels eval_pair includes                     out[1] ... whose 8x8 tile the cull drops (the forward never sees them)
+//   out[2] ... whose 4x4 sub-tile the cull drops         out[3] ... dropped at 8x8 but KEPT at 4x4: the backward includes a pair
+// the forward did not -- where no nearer face covers the pixel the saved soft-max maximum is then far below the pair's depth and
+// exp((zn - max) / gamma) overflows (round 3's non-finite training runs at configs[3], HISTORY.md 10).
+// noise_scale multiplies the per-face widening R_CULL of the band: 0 = the band at the exact threshold (round 3's early builds).
+// first[0..3]: (face, xi, row, -) of the first out[3] case.
+int host_cull_granularity(const float *faces, int n, int IS, float thr, float threshold, float nis, float noise_scale, long *out, int *first) {
+    float *rec = new float[(size_t)n * REC];
+    float4 *bbox = new float4[n];
+    blockDim.x = 1;
+    for (int i = 0; i < n; ++i) {
+        blockIdx.x = (unsigned)i; threadIdx.x = 0;
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
+    }
+    const bool pow2 = (IS & (IS - 1)) == 0;
+    const float inv_is = 1.f / (float)IS, h = 0.5f * IS;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    first[0] = -1;
+    auto hit = [&](const float4 *q, const float4 bb, float band, int px0, int pr0, int T) {
+        const int px1 = min(px0 + T - 1, IS - 1), pr1 = min(pr0 + T - 1, IS - 1);
+        const float xl = ndc_coord_fast(px0, IS, inv_is, pow2), xh = ndc_coord_fast(px1, IS, inv_is, pow2);
+        const float yh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), yl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
+        if (xl > bb.y || xh < bb.x || yl > bb.w || yh < bb.z) return false;                      // the kernels' bbox test first
+        return tile_may_hit(q[0], q[1], q[2], 0.5f * (xl + xh), 0.5f * (yl + yh), 0.5f * (xh - xl), 0.5f * (yh - yl), band);
+    };
+    for (int i = 0; i < n; ++i) {
+        Face fc;
+        load_face(fc, rec + (size_t)i * REC);
+        const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_I0);
+        const float4 bb = bbox[i];
+        if (!(bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w)) continue;
+        const float band = thr + noise_scale * rec[(size_t)i * REC + R_CULL];
+        const int x0 = max((int)floorf(bb.x * h + h - 0.5f) - 2, 0), x1 = min((int)ceilf(bb.y * h + h - 0.5f) + 2, IS - 1);
+        const int yi0 = max((int)floorf(bb.z * h + h - 0.5f) - 2, 0), yi1 = min((int)ceilf(bb.w * h + h - 0.5f) + 2, IS - 1);
+        const int r0 = IS - 1 - yi1, r1 = IS - 1 - yi0;
+        for (int ty = r0 / 8; ty <= r1 / 8; ++ty)
+            for (int tx = x0 / 8; tx <= x1 / 8; ++tx) {
+                const bool h8 = hit(q, bb, band, tx * 8, ty * 8, 8);
+                for (int sy = 0; sy < 2; ++sy)
+                    for (int sx = 0; sx < 2; ++sx) {
+                        const int px0 = tx * 8 + sx * 4, pr0 = ty * 8 + sy * 4;
+                        if (px0 >= IS || pr0 >= IS) continue;
+                        const bool h4 = hit(q, bb, band, px0, pr0, 4);
+                        for (int row = pr0; row < min(pr0 + 4, IS); ++row)
+                            for (int xi = px0; xi < min(px0 + 4, IS); ++xi) {
+                                Pair pr;
+                                if (!eval_pair(pr, fc, ndc_coord_fast(xi, IS, inv_is, pow2), ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2), threshold, nis)) continue;
+                                ++out[0];
+                                out[1] += !h8; out[2] += !h4;
+                                if (!h8 && h4) {
+                                    if (!out[3]) { first[0] = i; first[1] = xi; first[2] = row; }
+                                    ++out[3];
+                                }
+                            }
+                    }
+            }
     }
     delete[] rec; delete[] bbox;
     return 0;

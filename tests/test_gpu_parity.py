@@ -165,7 +165,7 @@ def test_full_size_vs_oracle(oracle_built, ts, rgb):
                                       rgb, 'prod', 'surface')
     sc.backward(gsc.to(DEV))
     # north_star: 1e-4.  Measured at this size (2.1 M values) on the round-3 build, which takes the reference's nearest-edge
-    # and threshold decisions everywhere: EVERY value within 1e-4, max |err| 6.6e-7 .. 8.0e-7
+    # and threshold decisions everywhere (HISTORY.md 4.1, 4.4): EVERY value within 1e-4, max |err| 6.6e-7 .. 8.0e-7
     # (rounds 1-2: 99.9997 % and 1.6e-4 .. 2.7e-4).  With umr_debug_set("exact_edges", 0) the old figures return.
     assert_close_frac(t2n(sc), o["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="soft_colors")
     if rgb == "softmax":

@@ -101,7 +101,7 @@ def test_product_vs_reference_device_code_full_size(ts, rgb):
     fvd, texd = fv.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True)
     sc, p2f, aggr = UF.soft_rasterize(fvd, texd, 512, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, rgb)
     sc.backward(gsc.to(DEV))
-    # round-3 build (reference's nearest-edge and threshold decisions everywhere), measured: every value,
+    # round-3 build (reference's nearest-edge and threshold decisions everywhere, HISTORY.md 4.1 / 4.4), measured: every value,
     # max 7.7e-7; vertex gradients 7e-7 .. 1.2e-6 of scale, texel gradients 8.7e-7, every element
     assert_close_frac(t2n(sc), t2n(ref["soft_colors"]), atol=1e-4, frac=1.0, max_outlier=1e-5, name="vs_refgpu_soft_colors")
     rp = ref["p2f_info"] / ref["p2f_sum"].clamp_min(1e-12)          # functional/soft_rasterize.py:73

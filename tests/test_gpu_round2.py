@@ -277,7 +277,7 @@ def test_train_s2_step_at_bench_shape_vs_oracle(oracle_built):
 
 def test_baseline_config1_shape_single_image(oracle_built):
     """BASELINE configs[0] (demo.py): ONE 256x256 image, 642-vertex icosphere, soft render + chamfer.  The reference runs it
-    on its CPU plumbing path; there is deliberately no CPU backend in the product, so the shape is
+    on its CPU plumbing path; there is deliberately no CPU backend in the product (HISTORY.md section 7), so the shape is
     covered here on the HIP path against the oracle: image, p2f, and distChamfer of the projected vertices."""
     from oracle import torch_ref
     from umr_amd.chamfer_python import distChamfer

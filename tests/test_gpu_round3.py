@@ -255,7 +255,7 @@ def test_loss_and_geometry_operators_opcheck_and_match_the_function_path():
 def test_nearest_edge_choice_is_the_references_at_full_size(oracle_built):
     """Inside a triangle the reference keeps the edge line with the smallest COMPUTED distance (:78-107).  The default build
     (umr_debug_set("exact_edges", 1)) evaluates all three lines the reference's way wherever the choice can matter and be in doubt
-    (DESIGN.md 4.4), so at BASELINE size (2 x 1280 faces x 512^2) the render and its gradients agree with the oracle in EVERY
+    (HISTORY.md 4.4), so at BASELINE size (2 x 1280 faces x 512^2) the render and its gradients agree with the oracle in EVERY
     element; so does the brute-force switch "thin_face_h_1e6" = 1e9 (every inside lane); "exact_edges" = 0 (the fast pick, 8-15 %
     less kernel time) holds the same bounds with isolated outliers."""
     import math

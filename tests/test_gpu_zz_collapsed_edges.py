@@ -2,7 +2,7 @@
 soft_rasterize_cuda_kernel.cu:82-84 (den = a0[v0] - a0[v1] comes out as exactly 0 about every second time), so the edge
 parameter of :86 is inf or NaN.  The reference's inside branch is immune (it keeps the smallest distance over the three edge
 lines with `dis < dis_min`, false for NaN / inf); a kernel that picks the edge first and evaluates only that one is not --
-this is what turned one training run in twenty into NaN (tripwire build).  Here: 64 such faces, each
+this is what turned one training run in twenty into NaN (tripwire build, HISTORY.md section 5).  Here: 64 such faces, each
 built around a pixel centre so that the pixel lies (up to rounding) inside the triangle and nearest to the collapsed edge."""
 import numpy as np
 import pytest

@@ -256,7 +256,7 @@ def test_reference_order_geometry_carries_rounding_noise(host_lib):
     faces of the BASELINE meshes' size.  Round 3 measured that formulation as a faster backward on the MI355X: 1e-3 of D noise
     decides which pixels at the rim of the distance band contribute, and outside the silhouette those pixels carry soft-max
     weights of O(1) -- gradients off by more than their scale on ~1 % of the faces, inf where the forward had rejected the
-    only face of a pixel.  This test pins the size of that noise on the kernel source: if it ever vanished
+    only face of a pixel (HISTORY.md 4.7).  This test pins the size of that noise on the kernel source: if it ever vanished
     (e.g. a reformulated eval_pair), the 1e-4 parity with the reference's render would have vanished with it."""
     host_lib.host_accurate_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 3

@@ -236,7 +236,7 @@ def test_argument_checks_of_the_entry_points(L):
 def test_default_build_takes_the_references_decisions_on_fuzzed_scenes(L, oracle_built):
     """tools/fuzz_host_raster.py's six scene classes (spheres, dense three-pixel meshes, triangle soups, sub-pixel faces, needles,
     degenerate faces), a few scenes each: with the default switches ("exact_edges" = 1, thin faces and the noise-widened cull,
-    DESIGN.md 4.1 / 4.4) the emulated kernels take every discrete decision as the reference does -- no pixel with a missing or
+    HISTORY.md 4.1 / 4.4) the emulated kernels take every discrete decision as the reference does -- no pixel with a missing or
     extra face, alpha within a few ulp of the oracle's (1e-6), no colour value off by 1e-4, every gradient (full, texel-only,
     silhouette backward) within 1e-5 of the scene's largest.  (3 600 scenes of the same generator: profiles/r03_emulator_fuzz.json.)"""
     import os
@@ -265,7 +265,7 @@ def test_emulated_library_exports_the_whole_c_abi(L):
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.umr_version() == b"umr_hip 0.3 gfx950" and L.umr_build_id() == b"host-emulation"
+    assert L.umr_version() == b"umr_hip 0.4 gfx950" and L.umr_build_id() == b"host-emulation"
 
 
 def test_exactness_switches_change_what_they_say(L, oracle_built):
@@ -292,4 +292,4 @@ def test_exactness_switches_change_what_they_say(L, oracle_built):
     assert max(default["gf_err_max"], default["gfa_err_max"]) <= 1e-5 and default["alpha_err_max"] <= 1e-6
     assert max(brute["gf_err_max"], brute["gfa_err_max"]) <= 1e-5 and brute["alpha_err_max"] <= 1e-6
     assert max(fast["gf_err_max"], fast["gfa_err_max"]) > 1e-3          # the fast pick is measurably not the reference's choice (1.3 - 5.4 % here) ...
-    assert fast["alpha_err_max"] <= 2e-2 and fast["membership_pixels"] == 0   # ... within the bounds DESIGN.md 4.4 states
+    assert fast["alpha_err_max"] <= 2e-2 and fast["membership_pixels"] == 0   # ... within the bounds HISTORY.md 4.4 states

@@ -1,4 +1,4 @@
-"""CPU measurements behind DESIGN.md 4.4 (thin faces) and 4.1 (tile cull): the rounding noise of the reference's closest-point
+"""CPU measurements behind HISTORY.md 4.4 (thin faces) and 4.1 (tile cull): the rounding noise of the reference's closest-point
 formulation, measured on the product's own eval_pair (tests/host_kernel/pair_host.cpp = raster_core.h compiled for the host; bit
 for bit the reference's arithmetic, tests/test_kernel_source_on_host.py).
 

@@ -21,7 +21,7 @@ python bench.py --model 0 --cpu-baseline 0 --graph 1 > "$O/bench_hotpath_graph.j
 python bench.py --workload s2 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
 # the SAME command as the bench line above (default warm-up / steps / profile pass, CPU leg off): the library's HIP events
 # bracket the raster kernels of the last 5 steps (the profile pass), so rocprofv3's last 5 dispatches are the same steps
-# (should bench.py ever discard a diverged measurement -- DESIGN.md section 5 -- and repeat it on a fresh model, a profile
+# (should bench.py ever discard a diverged measurement -- HISTORY.md section 5 -- and repeat it on a fresh model, a profile
 # that contains the discarded run is thrown away and taken again)
 for attempt in 1 2 3; do
   rm -rf "$O/stats"

@@ -1,4 +1,4 @@
-"""CPU count behind DESIGN.md section 4.1 (r3): raster work per mesh at BASELINE configs[1] (512^2 render, 1280 faces) and
+"""CPU count behind HISTORY.md section 4.1 (r3): raster work per mesh at BASELINE configs[1] (512^2 render, 1280 faces) and
 configs[3] (1024^2 render, 5120 faces) -- (pixel, face) pairs under the sigma-dilated bounding boxes and 8x8 tiles that hold at
 least one contributing pixel of a face (= the visits a perfect cull would make)."""
 import sys

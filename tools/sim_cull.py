@@ -1,4 +1,4 @@
-"""CPU simulation behind DESIGN.md section 4.1: how tight is the conservative tile-vs-dilated-triangle test?  bbox-only
+"""CPU simulation behind HISTORY.md section 4.1: how tight is the conservative tile-vs-dilated-triangle test?  bbox-only
 candidates, the current test, the current test + vertex-axis separating tests, and the exact need, per mesh."""
 import numpy as np, torch, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -54,7 +54,7 @@ float g_thin_face_h = THIN_FACE_H;   // umr_debug_set("thin_face_h_1e6", h * 1e6
                                      // inside pixels the reference's way (k_face_setup, bit 4 of the record's flags)
 bool g_exact_edges = true;           // umr_debug_set("exact_edges", 0 | 1): eval_pair's amb_thr = 20 sigma (see there).  On by default:
                                      // the nearest-edge choice inside a face is then the reference's in every pixel; 0 trades that
-                                     // for 8-15 % of the raster kernels' time
+                                     // for 8-15 % of the raster kernels' time (HISTORY.md 4.4)
 bool g_superblocks = true;       // umr_debug_set("superblock_bins", 0): every workgroup scans all F faces (A/B)
 
 // super-block edge: 64 pixels, or a sixteenth of the image rounded up to whole 16-pixel workgroup blocks when that is larger
@@ -129,7 +129,7 @@ extern "C" int umr_debug_trap(int reset, unsigned long long *when) {
 
 extern "C" {
 
-const char *umr_version(void) { return "umr_hip 0.3 gfx950"; }
+const char *umr_version(void) { return "umr_hip 0.4 gfx950"; }
 
 #ifndef UMR_SRC_HASH
 #define UMR_SRC_HASH "unknown"
