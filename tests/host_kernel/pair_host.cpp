@@ -272,6 +272,82 @@ int host_cull_granularity(const float *faces, int n, int IS, float thr, float th
     return 0;
 }
 
+// Replay of ONE face of a soft-max render through the arithmetic of both raster directions (tools/r4/replay_nan.py): for every pixel
+// of face `f`'s window the forward state (running soft-max maximum and sum, :417-437) over ALL faces in ascending order -- a face
+// contributes at a pixel when its 8x8 wave tile passes the forward's cull AND eval_pair includes the pixel AND the depth is in
+// range --, then the backward's weight of face f at that pixel, ps = D exp((zn - max) / gamma) / sum (:608), where its 4x4 sub-tile
+// passes the backward's cull.  noise_scale as in host_cull_granularity.  out[p * 8 ...] = (xi, row, D_f, zn_f, max, sum, ps,
+// code) with code = 1 forward included f here | 2 backward includes f here; returns the number of window pixels (<= cap).
+int host_replay_face(const float *faces, int n, int f, int IS, float thr, float threshold, float nis, float gamma, float near_, float far_,
+                     float eps, float noise_scale, float amb_thr, float *out, int cap) {
+    float *rec = new float[(size_t)n * REC];
+    float4 *bbox = new float4[n];
+    blockDim.x = 1;
+    for (int i = 0; i < n; ++i) {
+        blockIdx.x = (unsigned)i; threadIdx.x = 0;
+        k_face_setup(faces, nullptr, bbox, rec, n, thr, near_, far_, nullptr, 0, g_thin_h);
+    }
+    const bool pow2 = (IS & (IS - 1)) == 0;
+    const float inv_is = 1.f / (float)IS, h = 0.5f * IS, ig = 1.f / gamma, rr = 1.f / (far_ - near_);
+    auto hit = [&](int i, int px0, int pr0, int T) {
+        const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_I0);
+        const float4 bb = bbox[i];
+        const float band = thr + noise_scale * rec[(size_t)i * REC + R_CULL];
+        const int px1 = min(px0 + T - 1, IS - 1), pr1 = min(pr0 + T - 1, IS - 1);
+        const float xl = ndc_coord_fast(px0, IS, inv_is, pow2), xh = ndc_coord_fast(px1, IS, inv_is, pow2);
+        const float yh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), yl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
+        if (xl > bb.y || xh < bb.x || yl > bb.w || yh < bb.z) return false;
+        return tile_may_hit(q[0], q[1], q[2], 0.5f * (xl + xh), 0.5f * (yl + yh), 0.5f * (xh - xl), 0.5f * (yh - yl), band);
+    };
+    const float4 bf = bbox[f];
+    const int x0 = max((int)floorf(bf.x * h + h - 0.5f) - 2, 0), x1 = min((int)ceilf(bf.y * h + h - 0.5f) + 2, IS - 1);
+    const int yi0 = max((int)floorf(bf.z * h + h - 0.5f) - 2, 0), yi1 = min((int)ceilf(bf.w * h + h - 0.5f) + 2, IS - 1);
+    int np = 0;
+    for (int row = IS - 1 - yi1; row <= IS - 1 - yi0 && np < cap; ++row)
+        for (int xi = x0; xi <= x1 && np < cap; ++xi) {
+            const float xp = ndc_coord_fast(xi, IS, inv_is, pow2), yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
+            float ssum = expf(eps / gamma), smax = eps, Df = 0.f, znf = 0.f;
+            int code = 0;
+            for (int i = 0; i < n; ++i) {
+                const float4 bb = bbox[i];
+                if (xp > bb.y || xp < bb.x || yp > bb.w || yp < bb.z) continue;          // (block / tile bbox filters: implied by this one)
+                if (!hit(i, xi & ~7, row & ~7, 8)) continue;                              // the forward's 8x8 wave tile
+                Face fc;
+                load_face(fc, rec + (size_t)i * REC);
+                Pair pr;
+                if (!eval_pair(pr, fc, xp, yp, threshold, nis, amb_thr)) continue;
+                float q0, q1, q2;
+                const float zp = clip_depth(q0, q1, q2, pr, fc);
+                if (zp < near_ || zp > far_) continue;
+                const float zn = div_r(far_ - zp, far_ - near_, rr);
+                float rescale = 1.f;
+                if (zn > smax) { rescale = expf((smax - zn) * ig); smax = zn; }
+                ssum = rescale * ssum + expf((zn - smax) * ig) * pr.frag;
+                if (i == f) code |= 1;
+            }
+            float ps = 0.f;
+            {
+                Face fc;
+                load_face(fc, rec + (size_t)f * REC);
+                Pair pr;
+                if (hit(f, xi & ~3, row & ~3, 4) && eval_pair(pr, fc, xp, yp, threshold, nis, amb_thr)) {
+                    float q0, q1, q2;
+                    const float zp = clip_depth(q0, q1, q2, pr, fc);
+                    if (!(zp < near_ || zp > far_)) {
+                        znf = div_r(far_ - zp, far_ - near_, rr); Df = pr.frag;
+                        ps = pr.frag * expf((znf - smax) * ig) * (1.0f / ssum);
+                        code |= 2;
+                    }
+                }
+            }
+            float *o = out + (size_t)np * 8;
+            o[0] = (float)xi; o[1] = (float)row; o[2] = Df; o[3] = znf; o[4] = smax; o[5] = ssum; o[6] = ps; o[7] = (float)code;
+            ++np;
+        }
+    delete[] rec; delete[] bbox;
+    return np;
+}
+
 // per (face, pixel): the closest boundary point by three clamped edge projections on operands relative to the face's own
 // vertices (agrees with a float64 evaluation to ~1e-9): live (inside | d2 < threshold), soft fragment, P - Q
 int host_accurate_pairs(const float *faces, int n, const float *xp, const float *yp, int npix, float thr, float threshold, float nis,

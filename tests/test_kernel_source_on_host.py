@@ -45,6 +45,10 @@ def host_lib():
     h.host_tile_setup.restype = I
     h.host_fm_owned_face.argtypes = [I, I, I, I]
     h.host_fm_owned_face.restype = I
+    h.host_replay_face.argtypes = [P, I, I, I, F, F, F, F, F, F, F, F, F, P, I]
+    h.host_replay_face.restype = I
+    h.host_cull_granularity.argtypes = [P, I, I, F, F, F, F, P, P]
+    h.host_cull_granularity.restype = I
     return h
 
 
@@ -299,3 +303,52 @@ def test_reference_order_geometry_carries_rounding_noise(host_lib):
     on_boundary = d2a < 1e-13
     w = np.where(live != 0, frag, 0).astype(np.float64); wa = np.where(alive != 0, afrag, 0).astype(np.float64)
     assert ((w < 2e-10) & (wa < 2e-10) | on_boundary)[only].all()
+
+
+def test_tile_culls_of_both_directions_agree_where_a_pixel_is_included(host_lib):
+    """The cause of round 3's non-finite training runs at BASELINE configs[3] (HISTORY.md 10), on the geometry two tripwire runs
+    on the MI355X captured (tests/golden/nan_cfg4_faces.npz: the faces around the offender of the blamed view, written by
+    tools/r4/make_nan_fixture.py).  The forward culls per 8x8 wave tile, the face-major backward per 4x4 sub-tile, then both decide
+    per pixel with eval_pair.  With the cull band at the EXACT threshold (round 3's early builds: noise_scale 0) a thin face's
+    corner pixel of a tile -- included by the reference's own noisy distance with the smallest possible fragment, 1.03e-10 -- was
+    dropped by the 8x8 test and kept by the 4x4 test (the two evaluate the same maximum through different tile centres and round
+    differently): the backward then weighs a pair the forward never saw, the pixel's saved soft-max maximum is the background's
+    eps, and exp((zn - max) / gamma) = exp(9300) overflows -- an infinite texel / vertex gradient, NaN parameters one step later.
+    With the band widened by the reference's distance noise (R_CULL, the shipped library) such pixels lie far inside the band:
+    both directions include the same pairs and every weight is a soft-max weight <= 1."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nan_cfg4_faces.npz"))
+    sigma, gamma = 1e-5, 1e-4
+    threshold = float(np.log(1e10 - 1.0) * sigma)
+    thr = float(np.sqrt(f32(threshold)))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for c in range(2):
+        fv, off, IS = np.ascontiguousarray(g["faces_%d" % c], f32), int(g["offender_%d" % c]), int(g["meta_%d" % c][5])
+        res = {}
+        for noise in (0.0, 1.0):
+            out = np.zeros((20000, 8), f32)
+            n = host_lib.host_replay_face(p(fv), fv.shape[0], off, IS, thr, threshold, -1.0 / sigma, gamma, 1.0, 100.0, 1e-3, noise,
+                                          20.0 * sigma, p(out), out.shape[0])
+            o = out[:n]
+            code = o[:, 7].astype(int)
+            fwd, bwd = (code & 1) > 0, (code & 2) > 0
+            res[noise] = (int((bwd & ~fwd).sum()), int((fwd & ~bwd).sum()), o[bwd, 6], o[bwd & ~fwd])
+        only_b, only_f, ps, rows = res[0.0]
+        assert only_b == 1 and not np.isfinite(ps).all(), "the captured mechanism no longer reproduces with the exact band"
+        assert abs(rows[0][2] - 1.03e-10) < 3e-12 and rows[0][4] == f32(1e-3) and int(rows[0][0]) % 8 in (0, 7) and int(rows[0][1]) % 8 in (0, 7)
+        only_b, only_f, ps, _ = res[1.0]
+        assert only_b == 0 and only_f == 0 and np.isfinite(ps).all() and ps.max() <= 1.0 + 1e-6 and len(ps) > 500
+    # and as a count over random thin faces: with the shipped band no included pixel is dropped by either cull
+    rng = np.random.default_rng(7)
+    n = 4000
+    c = rng.uniform(-0.95, 0.95, (n, 2)); L = rng.uniform(0.01, 0.12, n); hh = 10 ** rng.uniform(-5.0, -1.5, n); a = rng.uniform(0, np.pi, n)
+    u, v = np.stack([np.cos(a), np.sin(a)], 1), np.stack([-np.sin(a), np.cos(a)], 1)
+    fv = np.zeros((n, 3, 3), f32)
+    fv[:, 0, :2] = c - 0.5 * L[:, None] * u; fv[:, 1, :2] = c + 0.5 * L[:, None] * u
+    fv[:, 2, :2] = c + ((rng.uniform(0.05, 0.95, n) - 0.5) * L)[:, None] * u + hh[:, None] * v
+    fv[:, :, 2] = rng.uniform(3, 6, (n, 3))
+    fv = np.ascontiguousarray(fv.reshape(n, 9))
+    cnt, first = (ctypes.c_long * 4)(), (ctypes.c_int * 4)()
+    host_lib.host_cull_granularity(p(fv), n, 1024, thr, threshold, -1.0 / sigma, 1.0, cnt, first)
+    assert cnt[0] > 1000000 and cnt[1] == 0 and cnt[2] == 0 and cnt[3] == 0, list(cnt)
+    host_lib.host_cull_granularity(p(fv), n, 1024, thr, threshold, -1.0 / sigma, 0.0, cnt, first)
+    assert cnt[1] > 0 and cnt[2] > 0      # with the exact band both culls DO drop pixels the reference's arithmetic includes
