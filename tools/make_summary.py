@@ -21,7 +21,8 @@ cp("bench_hotpath_only.json", tag + "_bench_hotpath_only.json")
 cp("bench_s2.json", tag + "_bench_s2.json")
 if os.path.exists(os.path.join(SRC, "bench_hotpath_graph.json")):
     cp("bench_hotpath_graph.json", tag + "_bench_hotpath_graph.json")
-for extra in ("bench_full_graph.json", "bench_s2_cfg4.json", "bench_ddp1.json", "eval_bench.json"):
+for extra in ("bench_full_graph.json", "bench_s2_cfg4.json", "bench_ddp1.json", "eval_bench.json", "bench_full_two_renders.json",
+              "bench_s2_two_renders.json", "step_kernels.jsonl"):
     if os.path.exists(os.path.join(SRC, extra)) and os.path.getsize(os.path.join(SRC, extra)) > 0:
         cp(extra, tag + "_" + extra)
 if os.path.exists(os.path.join(SRC, "valu_ubench.log")):
@@ -29,17 +30,12 @@ if os.path.exists(os.path.join(SRC, "valu_ubench.log")):
 cp("stats/t_kernel_stats.csv", tag + "_bench_kernel_stats.csv")
 cp("traffic/traffic.json", tag + "_traffic.json")
 cp("traffic/traffic.json", "traffic.json")
-pm = os.path.join(P, tag + "_pmc")
-shutil.rmtree(pm, ignore_errors=True)
-os.makedirs(pm)
-for shape in ("ts1", "ts36"):
-    for p in ("p1", "p2"):
-        shutil.copyfile(os.path.join(SRC, "pmc_" + shape, p, "t_counter_collection.csv"),
-                        os.path.join(pm, "%s_%s_counters.csv" % (shape, p)))
-    shutil.copyfile(os.path.join(SRC, "pmc_%s.log" % shape), os.path.join(pm, "%s_report.jsonl" % shape))
+if os.path.exists(os.path.join(SRC, "pmc", "pmc_summary.json")):      # tools/r4/pmc_passes.py: SQ / SQC / TCC / TCP counters per raster kernel
+    cp("pmc/pmc_summary.json", tag + "_pmc_step_kernels.json")
 with open(os.path.join(P, tag + "_microbench.log"), "w") as f:
     for name in ("microbench.log", "kernel_only.log"):
-        f.write("".join(l for l in open(os.path.join(SRC, name)) if "amdgpu.ids" not in l))
+        if os.path.exists(os.path.join(SRC, name)):
+            f.write("".join(l for l in open(os.path.join(SRC, name)) if "amdgpu.ids" not in l))
 
 full = json.load(open(os.path.join(SRC, "bench_full.json")))
 hot = json.load(open(os.path.join(SRC, "bench_hotpath_only.json")))

@@ -15,9 +15,7 @@ python bench.py > "$O/bench_full.json" 2> "$O/bench_full.err"
 python bench.py --graph 1 --cpu-baseline 0 > "$O/bench_full_graph.json" 2> "$O/bench_full_graph.err"      # whole step from ONE HIP graph
 python bench.py --workload s2 --image-size 512 --subdivide 4 --steps 5 --warmup 2 --cpu-baseline 0 > "$O/bench_s2_cfg4.json" 2> "$O/bench_s2_cfg4.err"
 python bench.py --force-ddp 1 --cpu-baseline 0 --steps 10 --warmup 5 > "$O/bench_ddp1.json" 2> "$O/bench_ddp1.err"   # 1-rank RCCL: all-reduce path timed
-python tools/r3/eval_bench.py > "$O/eval_bench.json" 2> "$O/eval_bench.err"
 python bench.py --model 0 --cpu-baseline 0 > "$O/bench_hotpath_only.json" 2> "$O/bench_hot.err"
-python bench.py --model 0 --cpu-baseline 0 --graph 1 > "$O/bench_hotpath_graph.json" 2> "$O/bench_hot_graph.err"
 python bench.py --workload s2 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
 # the SAME command as the bench line above (default warm-up / steps / profile pass, CPU leg off): the library's HIP events
 # bracket the raster kernels of the last 5 steps (the profile pass), so rocprofv3's last 5 dispatches are the same steps
@@ -33,11 +31,12 @@ done
 # average and rocprofv3's kernel average must agree (in the full step they sit ~25 % apart: different trajectories and a
 # GPU that the fp32 MIOpen network keeps at a lower clock when nothing slows the host down)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_hot" -o t -- python "$R/bench.py" --model 0 --cpu-baseline 0 > "$O/stats_hot.log" 2>&1)
-python tools/microbench.py > "$O/microbench.log" 2>&1
-python tools/microbench.py --alpha >> "$O/microbench.log" 2>&1
-python tools/sweep_fm.py kernel_only > "$O/kernel_only.log" 2>&1
-tools/pmc_raster.sh "$O/pmc_ts36" 64 3 512 36 > "$O/pmc_ts36.log" 2>&1
-tools/pmc_raster.sh "$O/pmc_ts1" 64 3 512 1 > "$O/pmc_ts1.log" 2>&1
+python bench.py --share-mask-render 0 --cpu-baseline 0 > "$O/bench_full_two_renders.json" 2> "$O/bench_two.err"   # A/B of DESIGN 4.5
+python bench.py --workload s2 --share-mask-render 0 --cpu-baseline 0 --steps 10 --warmup 3 > "$O/bench_s2_two_renders.json" 2> "$O/bench_s2_two.err"
+UMR_CFG4=1 python tools/sweep_fm.py kernel_only > "$O/kernel_only.log" 2>&1
+python tools/r4/step_kernels.py 20 0.6 0.9 > "$O/step_kernels.jsonl" 2> /dev/null
+python tools/r4/step_kernels.py 20 0.95 1.05 >> "$O/step_kernels.jsonl" 2> /dev/null
+PMC_GROUPS=sq1,sq2,tcc1,tcp,sqc python tools/r4/pmc_passes.py "$O/pmc" 3 0.6 0.9 > "$O/pmc.log" 2>&1
 python - "$O" <<'PY'
 import csv, glob, json, sys, collections
 # per raster kernel: rocprofv3 duration averaged over the dispatches of the LAST 5 steps (= bench.py's profile pass)
