@@ -166,13 +166,33 @@ for k, v in tr["kernels"].items():
                     u.get("lane_use") or 0, 100 * u["frac_of_peak"], u.get("wave_wait_frac") or 0, u.get("wave_issue_stall_frac") or 0,
                     u.get("wave_active_frac") or 0))
 L.append("\n## Kernel timings and SQ counters\n")
-L.append("`profiles/%s_microbench.log`: torch-event timings per autograd call (incl. face setup and allocation) and, last "
-         "line, kernel-only HIP-event averages in us per launch [forward, backward] at N=16 / N=128.\n" % tag)
-L.append("`profiles/%s_pmc/`: two SQ PMC passes (N=64, TS=1 and TS=36) and the derived per-kernel report:\n\n```" % tag)
-for shape in ("ts1", "ts36"):
-    for l in open(os.path.join(SRC, "pmc_%s.log" % shape)):
-        if l.startswith("{"):
-            L.append(shape + ": " + l.strip())
-L.append("```")
+L.append("`profiles/%s_microbench.log`: kernel-only HIP-event averages in us per launch [forward, backward] at N=16 / N=128 and at the "
+         "configs[3] raster shape (`tools/sweep_fm.py`).\n" % tag)
+pj = os.path.join(SRC, "pmc", "pmc_summary.json")
+if os.path.exists(pj):
+    pm = json.load(open(pj))
+    L.append("`profiles/%s_pmc_step_kernels.json` (`tools/r4/pmc_passes.py`: one counter group per run over the four raster launches of a "
+             "train_s1 step, N = 16 / 32, kernel-only driver):\n" % tag)
+    L.append("| kernel | VALU M | SALU M | VALU busy (ACTIVE_INST_VALU x 4 / SIMD-cycles) | quad-cycles per VALU instr | wait | issue stall | TCC hit | scalar-cache hit | L1->L2 read latency (cycles) |\n|---|---|---|---|---|---|---|---|---|---|")
+    for k, c in pm["kernels"].items():
+        if "k_raster" not in k:
+            continue
+        dur = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        L.append("| `%s` | %.1f | %.1f | %.2f | %.3f | %.2f | %.2f | %s | %s | %s |" % (
+            short(k)[:56], c.get("SQ_INSTS_VALU", 0) / 1e6, c.get("SQ_INSTS_SALU", 0) / 1e6,
+            c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(dur * 1024, 1), c.get("SQ_ACTIVE_INST_VALU", 0) / max(c.get("SQ_INSTS_VALU", 1), 1),
+            c.get("SQ_WAIT_ANY/WAVE_CYCLES", 0), c.get("SQ_WAIT_INST_ANY/WAVE_CYCLES", 0), c.get("tcc_hit_rate"), c.get("scalar_cache_hit_rate"),
+            c.get("avg_l1_to_l2_read_latency_cycles")))
+sk = os.path.join(SRC, "step_kernels.jsonl")
+if os.path.exists(sk):
+    L.append("\nKernel-only timings of those launches (`tools/r4/step_kernels.py`, library-owned HIP events, us per launch):\n\n```")
+    L.extend(l.strip() for l in open(sk) if l.startswith("{"))
+    L.append("```")
+for nm, label in (("bench_full_two_renders.json", "train_s1"), ("bench_s2_two_renders.json", "train_s2")):
+    t = _load(nm)
+    o = full if label == "train_s1" else s2
+    if t:
+        L.append("\n%s, mask render as the alpha channel of the textured render (default) vs the reference's two renders (`--share-mask-render 0`, "
+                 "`profiles/%s_%s`): %.1f vs %.1f images/s.\n" % (label, tag, nm, o["value"], t["value"]))
 open(os.path.join(P, tag + "_SUMMARY.md"), "w").write("\n".join(L) + "\n")
 print("wrote", os.path.join(P, tag + "_SUMMARY.md"))

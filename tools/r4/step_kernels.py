@@ -2,8 +2,8 @@
 HIP-event timing (library-owned events, umr_profile_*):
   textured soft-max forward with visibility planes + fused pool (N = 16, TS = 36), its texel-gradient-only backward,
   silhouette forward / backward over 2 x 16 views.
-usage: step_kernels.py [iters] [scale_lo scale_hi] [N]      (scale = camera scale range of tests.helpers.scene; bench.py's
-networks start near 1.0: the mesh fills the frame)"""
+usage: step_kernels.py [iters] [scale_lo scale_hi] [N] [IS subdiv]      (scale = camera scale range of tests.helpers.scene; bench.py's
+networks start near 1.0: the mesh fills the frame; IS 1024 subdiv 4 = BASELINE configs[3]'s raster shape)"""
 import json
 import os
 import sys
@@ -56,7 +56,8 @@ if __name__ == "__main__":
     it = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     sc = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.6, 0.9)
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+    IS_, sub_ = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (512, 3)
     for kv in os.environ.get("UMR_DEBUG_SET", "").split(","):      # e.g. UMR_DEBUG_SET=exact_edges=0,face_order=0
         if "=" in kv:
             _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
-    print(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "set": os.environ.get("UMR_DEBUG_SET", ""), "scale": sc, "N": n, "us_per_launch": run(it, sc, n)}), flush=True)
+    print(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "set": os.environ.get("UMR_DEBUG_SET", ""), "scale": sc, "N": n, "IS": IS_, "subdiv": sub_, "us_per_launch": run(it, sc, n, IS_, sub_)}), flush=True)
