@@ -109,6 +109,51 @@ def cpu_baseline(args, n_images):
                       "side" % (n_images, dt)}
 
 
+def fixed_scene_kernel_times(dev, iters=20):
+    """The four raster launches of one train_s1 step (bs 16) on a FIXED synthetic scene -- SURVEY.md 8d's: 1280-face icospheres with
+    0.05 vertex noise, camera scale U(0.6, 0.9), translation U(-0.1, 0.1), random rotation, seed 0 -- timed with the library's HIP
+    events: the per-kernel figures of `roofline` come from the live training state (meshes of steps 41-45 of THIS run's
+    trajectory, which float-atomic summation order makes differ from run to run by +-20 % in raster work); these do not move
+    and are comparable across builds and rounds.  us per launch."""
+    from umr_amd import _lib, functional as UF
+    from umr_amd.mesh import create_sphere
+    g = torch.Generator().manual_seed(0)
+    N, IS, TS = 16, 512, 36
+    v, f = create_sphere(3)
+    verts = torch.from_numpy(v).float()[None].repeat(2 * N, 1, 1)
+    verts = verts + 0.05 * torch.randn(verts.shape, generator=g)
+    faces = torch.from_numpy(f).long()[None].repeat(2 * N, 1, 1)
+    sc_ = 0.6 + 0.3 * torch.rand(2 * N, 1, generator=g)          # (drawn in the order of tests/helpers.py:scene -- the geometry
+    tr_ = -0.1 + 0.2 * torch.rand(2 * N, 2, generator=g)         # tools/r4/step_kernels.py times)
+    q = torch.randn(2 * N, 4, generator=g)
+    cams = torch.cat([sc_, tr_, q / q.norm(dim=1, keepdim=True)], 1)
+    _, fv, _ = UF.project_faces(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732)
+    fv = fv.detach()
+    tex = torch.rand(N, faces.shape[1], TS, 3, generator=g).to(dev).requires_grad_(True)
+    fv_sil = fv.clone().requires_grad_(True)
+    g_tex, g_sil = torch.randn(N, 4, IS // 2, IS // 2, generator=g).to(dev), torch.randn(2 * N, IS // 2, IS // 2, generator=g).to(dev)
+    out = {}
+    for phase in range(2):
+        if phase:
+            _lib.profile_enable(True)
+            for k in range(4):
+                _lib.profile_collect(k)
+        for _ in range(iters if phase else 2):
+            tex.grad = None; fv_sil.grad = None
+            sc = UF.soft_rasterize(fv[:N], tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
+                                   pool=True, need_p2f=True, want_visibility=True)[0]
+            a = UF.silhouette(fv_sil, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, True)
+            sc.backward(g_tex)
+            a.backward(g_sil)
+        torch.cuda.synchronize()
+    for name, k in (("textured_forward_p2f_vis_pool_N16", 0), ("texel_gradient_backward_N16", 1), ("silhouette_forward_N32", 2),
+                    ("silhouette_backward_N32", 3)):
+        ms, n, _ = _lib.profile_collect(k)
+        out[name] = round(1e3 * ms / max(n, 1), 1)
+    _lib.profile_enable(False)
+    return out
+
+
 def main(device=None, backend="nccl"):
     """device / backend: the CPU suite runs this very function on host tensors over gloo with the wave64 emulation of the library
     (tests/bench_rank_on_emulator.py) to exercise the N > 1 plumbing without GPUs; every real run leaves them at their defaults."""
@@ -486,6 +531,9 @@ def main(device=None, backend="nccl"):
                          silhouette_forward=dict(kernel_line(2), valu=valu.get("silhouette_forward")),
                          silhouette_backward=dict(kernel_line(3), valu=valu.get("silhouette_backward"))),
     }
+    if dev.type == "cuda":
+        out["roofline"]["fixed_scene_us"] = dict(fixed_scene_kernel_times(dev),
+                                                 scene="SURVEY 8d: 16 (32) x 1280-face icospheres, IS 512, TS 36, seed 0 -- identical every run")
     want_cpu = (world == 1 and args.workload == "s1") if args.cpu_baseline < 0 else bool(args.cpu_baseline)
     if want_cpu:
         from oracle import softras
