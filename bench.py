@@ -53,6 +53,8 @@ def parse():
                     help="s1 = BASELINE configs[1] (headline); s2 = train_s2 sequence of configs[2]/[3] (8 camera hypotheses)")
     ap.add_argument("--epoch", type=int, default=0, help="train_s1 epoch (gates the symmetry / deformation terms)")
     ap.add_argument("--profile-steps", type=int, default=5, help="untimed steps with kernel events for `roofline`")
+    ap.add_argument("--fixed-scene", type=int, default=1, help="0: skip roofline.fixed_scene_us (the PMC passes of tools/collect_traffic.sh: "
+                    "their per-launch averages are over the step's own launches only)")
     ap.add_argument("--share-mask-render", type=int, default=1,
                     help="1: the mask render is the alpha channel of the textured render of the same views (one render where the "
                          "reference makes two); 0: both renders, for A/B")
@@ -150,6 +152,19 @@ def fixed_scene_kernel_times(dev, iters=20):
                     ("silhouette_backward_N32", 3)):
         ms, n, _ = _lib.profile_collect(k)
         out[name] = round(1e3 * ms / max(n, 1), 1)
+    # the shared mask / texture render of the same 16 views: its ONE backward pass (alpha gradient -> vertices, rgb -> texels),
+    # which replaces a texel-gradient backward + a 16-view silhouette backward
+    fv_sh = fv[:N].clone().requires_grad_(True)
+    for phase in range(2):
+        if phase:
+            _lib.profile_collect(1)
+        for _ in range(iters if phase else 2):
+            tex.grad = None; fv_sh.grad = None
+            UF.soft_rasterize(fv_sh, tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
+                              pool=True, need_p2f=True, want_visibility=True, detach_rgb_geometry=True)[0].backward(g_tex)
+        torch.cuda.synchronize()
+    ms, n, _ = _lib.profile_collect(1)
+    out["shared_render_backward_one_pass_N16"] = round(1e3 * ms / max(n, 1), 1)
     _lib.profile_enable(False)
     return out
 
@@ -471,9 +486,9 @@ def main(device=None, backend="nccl"):
             traffic = tj.get("raster_backward_bytes_per_launch")
             traffic_note = "PMC FETCH_SIZE (x%.2f calibrated) + WRITE_SIZE per launch, tools/collect_traffic.sh on build %s" % (
                 tj.get("calibration", {}).get("fetch_correction_factor", 2.0), tj.get("build_id"))
-            for kname, key in (("k_raster_backward_fm<1", "backward"), ("k_raster_forward<1", "forward_kernel"),
-                               ("k_raster_forward<2", "silhouette_forward"), ("k_raster_backward_fm<2", "silhouette_backward"),
-                               ("k_raster_backward_fm_slots<2", "silhouette_backward")):
+            for kname, key in (("k_raster_backward_fm<1", "backward"), ("k_raster_backward_fm_ag<1", "backward"),
+                               ("k_raster_forward<1", "forward_kernel"), ("k_raster_forward<2", "silhouette_forward"),
+                               ("k_raster_backward_fm<2", "silhouette_backward"), ("k_raster_backward_fm_quads<2", "silhouette_backward")):
                 for kn, e in tj.get("kernels", {}).items():
                     if kname in kn and e.get("valu"):
                         v = e["valu"]
@@ -489,17 +504,19 @@ def main(device=None, backend="nccl"):
     net_note = ("; MeshNet fwd/bwd + %sAdam" % ("RCCL gradient all-reduce over %d ranks + " % world if world > 1 else "")
                 if use_model else "; network excluded")
     if args.workload == "s1":
-        wl = ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: the reference's 4 raster fwd + 3 bwd per image as 2 fwd + 3 bwd "
+        wl = ("train_s1 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere: the reference's 4 raster fwd + 3 bwd per image as %s "
               "launches (textured soft-max render with p2f whose alpha channel IS the mask render and whose visits carry the hard "
               "visibility render; unseen-view silhouette) + IoU / AlexNet-perceptual "
               "texture / texture-dt / tex-cycle / Laplacian / flatten / GAN losses, fwd+bwd, epoch %d%s"
-              % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], args.epoch, net_note))
+              % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
+                 "2 fwd + 2 bwd (ONE backward pass for the shared render's two gradients)" if args.share_mask_render else "4 fwd + 3 bwd", args.epoch, net_note))
     else:
         wl = ("train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: the reference's 22 raster fwd + 21 bwd per "
-              "image as 12 fwd + 19 bwd (8 textured hypothesis renders whose alpha channels are the 8 mask renders, 1 visibility, 1 unseen "
+              "image as %s (8 textured hypothesis renders whose alpha channels are the 8 mask renders, 1 visibility, 1 unseen "
               "view, 2 part renders carrying the reference's 4) + mask / "
               "AlexNet-perceptual texture / tex-cycle / part / chamfer losses, fwd+bwd%s"
-              % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0], net_note))
+              % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
+                 "12 fwd + 11 bwd" if args.share_mask_render else "20 fwd + 19 bwd", net_note))
 
     def kernel_line(k):
         ms, n, nbytes = prof[k]
@@ -518,20 +535,22 @@ def main(device=None, backend="nccl"):
                         "hip_graph_scope": ("whole training step (network + losses + Adam)" if whole_graph is not None else
                                             ("render-and-compare step" if (args.graph and not use_model and world == 1) else None)),
                         "hot_path_loss_spread": loss_spread}, **rccl),
-        # dominant raster-backward kernel of the step (textured render: texel gradients only, pooled gradient in).
+        # dominant raster-backward kernel of the step: the ONE backward pass of the shared mask / texture render (alpha gradient ->
+        # vertices, rgb gradient -> texels, pooled gradient in; with --share-mask-render 0 the texel-gradient-only backward).
         # `achieved` = algorithmic bytes of THAT variant (HISTORY.md 4.6: SURVEY 8d's rule -- each op-boundary buffer the
         # variant touches, once) / its mean HIP-event duration over the profile pass.
         # `valu`: the resource that actually binds these kernels (HISTORY.md 4.6) -- issued wave64 VALU instructions per launch,
         # the share of their lanes that was active, and the issue rate against the fp32 vector peak (1228.9 G wave-instr/s),
         # from SQ PMC passes of this command on this build (profiles/traffic.json; absent when that file is stale).
-        "roofline": dict({"bound": "hbm", "kernel": "k_raster_backward_fm (textured render)", "peak": HBM_PEAK_GBS,
+        "roofline": dict({"bound": "hbm", "kernel": ("k_raster_backward_fm_ag (shared render: d alpha -> vertices, d rgb -> texels)" if args.share_mask_render else
+                                     "k_raster_backward_fm (textured render, texel gradients only)"), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_note, "valu": valu.get("backward")},
                          **kernel_line(1),
                          forward_kernel=dict(kernel_line(0), valu=valu.get("forward_kernel")),
                          silhouette_forward=dict(kernel_line(2), valu=valu.get("silhouette_forward")),
                          silhouette_backward=dict(kernel_line(3), valu=valu.get("silhouette_backward"))),
     }
-    if dev.type == "cuda":
+    if dev.type == "cuda" and args.fixed_scene:
         out["roofline"]["fixed_scene_us"] = dict(fixed_scene_kernel_times(dev),
                                                  scene="SURVEY 8d: 16 (32) x 1280-face icospheres, IS 512, TS 36, seed 0 -- identical every run")
     want_cpu = (world == 1 and args.workload == "s1") if args.cpu_baseline < 0 else bool(args.cpu_baseline)

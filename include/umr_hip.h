@@ -110,6 +110,11 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
 #define UMR_BWD_GRAD_POOLED 1   /* gradient arrives at the 2x2-pooled resolution */
 #define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb
                                    gradient is zero, which is what "only alpha is consumed" means; needs need_grad_faces */
+#define UMR_BWD_ALPHA_GEOMETRY 4 /* soft-max render whose rgb channels were rendered from DETACHED geometry (train_s1.py:217,
+                                   loss_utils.py:313) and whose alpha channel is the mask render of the same views (:199, :265):
+                                   grad_faces receives the alpha term only, grad_textures the rgb term -- what
+                                   UMR_BWD_ALPHA_ONLY on the alpha plane plus a texel-only call return, from one pass over the
+                                   (pixel, face) pairs; needs need_grad_faces and need_grad_textures, func_id_rgb 1 */
 
 /* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins, the backward's
  * start order).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst

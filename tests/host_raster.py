@@ -16,7 +16,7 @@ SO = os.path.join(SRC_DIR, "libumr_host.so")
 TUS = ["raster", "geometry", "losses", "perceptual", "edt", "atlas", "regs", "eval"]     # umr_amd/build.py SOURCES
 
 NO_P2F, ALPHA_ONLY, FACE_ID_ONLY = 1, 2, 4      # UMR_RASTER_* (include/umr_hip.h)
-BWD_GRAD_POOLED, BWD_ALPHA_ONLY = 1, 2          # UMR_BWD_*
+BWD_GRAD_POOLED, BWD_ALPHA_ONLY, BWD_ALPHA_GEOMETRY = 1, 2, 4          # UMR_BWD_*
 
 
 def available():
@@ -98,7 +98,7 @@ class emulated_product:
         self._orig_ptr = orig_ptr
         if not emulated_product._ops_registered:
             for op in (ops.soft_rasterize_op, ops.soft_rasterize_backward_op, ops.silhouette_op, ops.silhouette_backward_op,
-                       ops.soft_rasterize_alpha_geometry_op):
+                       ops.soft_rasterize_alpha_geometry_op, ops.soft_rasterize_alpha_geometry_backward_op):
                 op.register_kernel("cpu")(op._init_fn)
             from umr_amd import ops_losses          # the geometry / loss operators: the same implementations for host tensors
             for name, impl in ops_losses.IMPLS:

@@ -273,7 +273,8 @@ def test_every_kernel_of_the_path_is_a_registered_operator_with_a_fake_kernel():
     import torch
     from torch._subclasses.fake_tensor import FakeTensorMode
     from umr_amd import ops, ops_losses  # noqa: F401
-    names = ["soft_rasterize", "soft_rasterize_backward", "silhouette", "silhouette_backward"] + list(ops_losses.ALL_OPS) + \
+    names = ["soft_rasterize", "soft_rasterize_backward", "silhouette", "silhouette_backward", "soft_rasterize_alpha_geometry",
+             "soft_rasterize_alpha_geometry_backward"] + list(ops_losses.ALL_OPS) + \
         [n + "_backward" for n in ops_losses.ALL_OPS if n != "dt_barrier"]
     for n in names:
         assert hasattr(torch.ops.umr, n), n

@@ -19,7 +19,7 @@ def test_alpha_geometry_render_routes_gradients_like_the_two_renders():
     """umr::soft_rasterize_alpha_geometry = ONE textured render whose alpha channel keeps its gradient to the geometry while the
     colour channels see it detached -- against the two renders the reference makes of the same views (mask render with gradients
     to the vertices, train_s1.py:199; textured render of detached vertices, :217): same image bits, the vertex gradient of the
-    silhouette render, the texel gradient of the textured one.  opcheck: schema, fake kernel, autograd registration."""
+    silhouette render and the texel gradient of the textured one to rounding.  opcheck: schema, fake kernel, autograd registration."""
     from torch.library import opcheck
     from umr_amd import ops  # noqa: F401
     from umr_amd import functional as UF
@@ -42,8 +42,10 @@ def test_alpha_geometry_render_routes_gradients_like_the_two_renders():
                                                 'softmax', 'prod', 'surface', pool=True, need_p2f=True, want_visibility=True)
     ((alpha * g[:, 3]).sum() + (img2[:, :3] * g[:, :3]).sum()).backward()
     assert torch.equal(img[:, 3], alpha) and torch.equal(img[:, :3], img2[:, :3]) and torch.equal(vis, vis2)
-    assert torch.equal(fv1.grad, fv2.grad), float((fv1.grad - fv2.grad).abs().max())
-    assert torch.equal(tex1.grad, tex2.grad)
+    # gradients: ONE backward pass over the pairs (UMR_BWD_ALPHA_GEOMETRY) against the silhouette backward + the texel-only
+    # backward of the two renders -- the same per-pair terms summed in another order (measured 8e-8 / 1.5e-7 of the largest)
+    assert float((fv1.grad - fv2.grad).abs().max()) <= 2e-6 * float(fv2.grad.abs().max())
+    assert float((tex1.grad - tex2.grad).abs().max()) <= 2e-6 * float(tex2.grad.abs().max())
     # and nothing of the colour gradient reaches the geometry
     fv3 = fv.detach().clone().requires_grad_(True)
     img3 = torch.ops.umr.soft_rasterize_alpha_geometry(fv3, tex, *cfg)[0]

@@ -175,7 +175,7 @@ def test_every_production_variant_vs_oracle(L, oracle_built, IS, subdiv, TS):
                 assert_close_frac(a, rgf_p, atol=1.5e-5 * np.abs(rgf_p).max(), rtol=1e-4, frac=1.0, name="host bwd pooled gf %s" % (need,))
             if need[1]:
                 assert_close_frac(b, rgt_p, atol=3e-6 * np.abs(rgt_p).max(), rtol=1e-4, frac=1.0, name="host bwd pooled gt %s" % (need,))
-    # silhouette backward (k_raster_backward_fm_slots): the full backward with a zero rgb gradient
+    # silhouette backward (k_raster_backward_fm_quads): the full backward with a zero rgb gradient
     ga = gsc.copy()
     ga[:, :3] = 0
     rgf_a, _ = softras.raster_backward(faces, tex, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], ga, IS, n_threads=4, **cfg)
@@ -213,6 +213,41 @@ def test_front_face_culling_hard_render_and_camera_groups(L, oracle_built):
         gf, gt = HR.backward(faces, tex4, o["soft_colors"], o["aggrs_info"], gsc, IS, L=L, **cfg)
         assert_close_frac(gf, rgf, atol=1.5e-5 * np.abs(rgf).max(), rtol=1e-4, frac=1.0, name="host one-sided gf rgb%d" % rgb)
         assert_close_frac(gt, rgt, atol=3e-6 * max(np.abs(rgt).max(), 1e-12), rtol=1e-4, frac=1.0, name="host one-sided gt rgb%d" % rgb)
+
+
+@pytest.mark.parametrize("IS,pooled,two_sided,K", [(64, True, True, 1), (64, False, True, 2), (50, False, True, 1), (30, True, False, 1),
+                                                   (128, True, True, 1)])
+def test_one_pass_backward_of_the_shared_render_equals_its_two_launches(L, IS, pooled, two_sided, K):
+    """UMR_BWD_ALPHA_GEOMETRY: d alpha -> vertices and d rgb -> texels from ONE pass over the pairs, against the two launches it
+    replaces (UMR_BWD_ALPHA_ONLY on the render's alpha plane; the texel-only backward) on the same saved state -- equal up to the
+    order of summation; power-of-two and ragged image sizes, pooled and full-resolution gradients, front faces only, K views per
+    texture set."""
+    import torch
+    faces, gen = _scene_faces(4, 2, seed=31 + IS)
+    F = faces.shape[1]
+    tex = torch.rand(4 // K, F, 9, 3, generator=gen).numpy()
+    cfg = dict(CFG, func_id_rgb=1, double_side=two_sided)
+    o = HR.forward(faces, tex, IS, tex_group=K, L=L, **cfg)
+    H = IS // 2 if pooled else IS
+    g = torch.randn(4, 4, H, H, generator=gen).numpy()
+    fl = HR.BWD_GRAD_POOLED if pooled else 0
+    _, gt_ref = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], g, IS, need_gf=False, need_gt=True, grad_flags=fl, tex_group=K, L=L, **cfg)
+    gf_ref, _ = HR.backward(faces, None, np.ascontiguousarray(o["soft_colors"][:, 3]), None, np.ascontiguousarray(g[:, 3]), IS, need_gf=True,
+                            need_gt=False, grad_flags=fl | HR.BWD_ALPHA_ONLY, L=L, **cfg)
+    gf, gt = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], g, IS, need_gf=True, need_gt=True,
+                         grad_flags=fl | HR.BWD_ALPHA_GEOMETRY, tex_group=K, L=L, **cfg)
+    assert np.abs(gf_ref).max() > 0 and np.abs(gt_ref).max() > 0
+    assert np.abs(gf - gf_ref).max() <= 2e-6 * np.abs(gf_ref).max()
+    assert np.abs(gt - gt_ref).max() <= 2e-6 * np.abs(gt_ref).max()
+    # the full backward of the same render differs (it also sends the rgb gradient to the geometry): the flag is not a no-op
+    gf_full, _ = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], g, IS, need_gf=True, need_gt=True, grad_flags=fl, tex_group=K, L=L, **cfg)
+    assert np.abs(gf_full - gf_ref).max() > 1e-3 * np.abs(gf_ref).max()
+    # refusals: hard colour mode, a missing gradient target, the silhouette flag on top
+    for bad in (dict(func_id_rgb=0), dict(need_gf=False), dict(need_gt=False)):
+        kw = dict(need_gf=True, need_gt=True, grad_flags=fl | HR.BWD_ALPHA_GEOMETRY, tex_group=K, L=L, **cfg)
+        kw.update(bad)
+        with pytest.raises(RuntimeError):
+            HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], g, IS, **kw)
 
 
 def test_argument_checks_of_the_entry_points(L):
@@ -265,7 +300,7 @@ def test_emulated_library_exports_the_whole_c_abi(L):
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.umr_version() == b"umr_hip 0.4 gfx950" and L.umr_build_id() == b"host-emulation"
+    assert L.umr_version() == b"umr_hip 0.5 gfx950" and L.umr_build_id() == b"host-emulation"
 
 
 def test_exactness_switches_change_what_they_say(L, oracle_built):

@@ -119,12 +119,12 @@ if ev:
              "directions x %d keypoints -- flow mode %.0f pairs/s (%.1f us/pair), cam mode %.0f pairs/s (%.1f us/pair), PCK counters on "
              "the device.\n" % (tag, ev["pairs"], ev["keypoints"], ev["flow"]["pairs_per_s"], ev["flow"]["us_per_pair"],
                                  ev["cam"]["pairs_per_s"], ev["cam"]["us_per_pair"]))
-bk = [r for r in ours if "k_raster_backward_fm<1, false, true" in r["Name"]]
+bk = [r for r in ours if ("k_raster_backward_fm_ag<1" in r["Name"] or "k_raster_backward_fm<1, false, true" in r["Name"])]
 tsum = os.path.join(SRC, "raster_trace_summary.json")
 if os.path.exists(tsum):
     shutil.copyfile(tsum, os.path.join(P, tag + "_raster_trace_summary.json"))
     tj = json.load(open(tsum))
-    kk = [k for k in tj if "k_raster_backward_fm<1, false, true" in k]
+    kk = [k for k in tj if "k_raster_backward_fm_ag<1" in k] or [k for k in tj if "k_raster_backward_fm<1, false, true" in k]
     if kk:
         L.append("HIP-event average (profile pass = steps 41-45 of the un-profiled bench run) vs rocprofv3 over the same five "
                  "steps of the profiled run of the same command for `%s`: %.1f us vs %.1f us (%.1f us over all 45 steps); "
@@ -137,7 +137,7 @@ if os.path.exists(tsum):
         if os.path.exists(hs):
             shutil.copyfile(hs, os.path.join(P, tag + "_raster_hot_stats.json"))
             hj = json.load(open(hs))
-            hk = [k for k in hj if "k_raster_backward_fm<1, false, true" in k]
+            hk = [k for k in hj if "k_raster_backward_fm_ag<1" in k] or [k for k in hj if "k_raster_backward_fm<1, false, true" in k]
             if hk:
                 L.append("Where both see the same work -- the hot path alone (`--model 0`: the same scene every step) -- they "
                          "agree: HIP events %.1f us (`profiles/%s_bench_hotpath_only.json`) vs rocprofv3 %.1f us over %d "

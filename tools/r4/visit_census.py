@@ -26,8 +26,8 @@ INJECT = [
     ("                                        0.5f * (cyh - cyl), thr_cull);\n", "                                        0.5f * (cyh - cyl), thr_cull); if (want) CNT(3);\n"),
     ("                unsigned long long tm = __ballot(want);\n", "                unsigned long long tm = __ballot(want); if (want) CNT(4); if (lane == 0) CNT(13);\n"),
     ("                    if (mine < 0) continue;\n", "                    CNT(5); if (lane == 0) CNT(12); if (mine < 0) continue; CNT(6);\n"),
-    ("                        if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;\n",
-     "                        if (!dead) CNT(11); if ((RGB == 2 || !NEED_GF) && __all(dead)) continue; CNT(7);\n"),
+    ("                        if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue;\n",
+     "                        if (!dead) CNT(11); if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue; CNT(7);\n"),
     ("                    if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis, A.amb_thr)) continue;\n",
      "                    if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis, A.amb_thr)) continue; CNT(8); CREC(n, f, pn4 >> 2);\n"),
     ("                    if (zp < c_near || zp > c_far) continue;  // :592\n", "                    if (zp < c_near || zp > c_far) continue; CNT(9);\n"),
@@ -115,6 +115,9 @@ def main():
     report("texel-gradient backward <1, false, true>")
     HR.backward(fv, tex, out["soft_colors"], out["aggrs_info"], g_rgb, IS, need_gf=True, need_gt=True, grad_flags=HR.BWD_GRAD_POOLED, dist_eps_log=DEL, L=L)
     report("vertex + texel backward <1, true, true>")
+    HR.backward(fv, tex, out["soft_colors"], out["aggrs_info"], g_rgb, IS, need_gf=True, need_gt=True,
+                grad_flags=HR.BWD_GRAD_POOLED | HR.BWD_ALPHA_GEOMETRY, dist_eps_log=DEL, L=L)
+    report("one-pass backward of the shared render (alpha -> vertices, rgb -> texels)")
     outa = HR.forward(fv, None, IS, flags=HR.ALPHA_ONLY | HR.NO_P2F, pooled=True, dist_eps_log=DEL, L=L)
     g_a = rng.standard_normal((n, IS // 2, IS // 2)).astype(np.float32)
     HR.backward(fv, None, outa["soft_colors"], None, g_a, IS, need_gf=True, need_gt=False,

@@ -129,7 +129,7 @@ extern "C" int umr_debug_trap(int reset, unsigned long long *when) {
 
 extern "C" {
 
-const char *umr_version(void) { return "umr_hip 0.4 gfx950"; }
+const char *umr_version(void) { return "umr_hip 0.5 gfx950"; }
 
 #ifndef UMR_SRC_HASH
 #define UMR_SRC_HASH "unknown"
@@ -288,6 +288,9 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     (void)faces_info;  // recomputed into the workspace (bit-identical: same kernel, same input)
     int R = 0;
     const bool alpha_only = (grad_is_pooled & UMR_BWD_ALPHA_ONLY) != 0;
+    // the rgb gradient reaches the texels only, the alpha gradient the geometry: the shared mask / texture render of
+    // train_s1 / train_s2 (silhouette backward on the render's alpha plane + texel-only backward) in ONE pass over the pairs
+    const bool alpha_geom = (grad_is_pooled & UMR_BWD_ALPHA_GEOMETRY) != 0;
     const int tex_group = ((grad_is_pooled >> 8) & 0xffff) ? ((grad_is_pooled >> 8) & 0xffff) : 1;
     grad_is_pooled &= UMR_BWD_GRAD_POOLED;
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
@@ -302,6 +305,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     if (workspace_bytes < umr_raster_workspace_bytes_for(N, F, image_size)) return UMR_ERR_ARG;
     if (grad_is_pooled && (image_size & 1)) return UMR_ERR_ARG;
     if (!need_grad_faces && !need_grad_textures) return UMR_OK;
+    if (alpha_geom && (alpha_only || !need_grad_faces || !need_grad_textures || func_id_rgb != 1 || general)) return UMR_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     RasterArgs A = {};
     A.bbox = (const float4 *)workspace;
@@ -328,7 +332,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     // texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel: with 16 meshes' heavy
     // faces in flight an XCD's 4 MB L2 no longer holds their state); silhouette unchanged.  So: texel-only variant only,
     // one group when the launch has <= 16 meshes, groups of 8 otherwise.
-    const int order_mode = alpha_only ? 2 : ((!need_grad_faces && func_id_rgb == 1) ? 1 : 0);
+    const int order_mode = alpha_only ? 2 : (((!need_grad_faces || alpha_geom) && func_id_rgb == 1) ? 1 : 0);
     const bool ordered = face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 &&
                          F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
     int *order = (int *)((char *)workspace + ws_order_offset(N, F, image_size));
@@ -336,7 +340,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                    sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size, g_thin_face_h);
     // light variants at small N: four runs of faces per XCD instead of one (fm_owned_face)
-    A.fm_split = (face_major && N <= 16 && (alpha_only || !need_grad_faces) && F % 32 == 0) ? 4 : 1;
+    A.fm_split = (face_major && N <= 16 && (alpha_only || !need_grad_faces || alpha_geom) && F % 32 == 0) ? 4 : 1;
     if (ordered) {
         int G = std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / (F / 8)));
         if (g_face_order_group) G = std::min(G, g_face_order_group);
@@ -353,10 +357,13 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         //   vertex grads only:           (40 | 28) IS^2 + F (180 + 12 TS)
         //   texel grads only:            (20 | 11) IS^2 + F (144 + 12 TS)          (3 colour-gradient planes + aggrs)
         //   silhouette (id 3):           ( 8 |  5) IS^2 + 72 F
+        //   alpha -> geometry + rgb -> texels (one pass): texel-only's + the alpha plane (4) + its gradient plane (4 | 1)
+        //                                (28 | 16) IS^2 + F (180 + 12 TS)          (grad_faces written as well)
         const double is2 = (double)image_size * image_size;
         const bool gp = grad_is_pooled != 0;
         double per_mesh;
         if (alpha_only) per_mesh = (gp ? 5.0 : 8.0) * is2 + 72.0 * F;
+        else if (alpha_geom) per_mesh = (gp ? 16.0 : 28.0) * is2 + (double)F * (180.0 + 12.0 * TS);
         else if (need_grad_faces && need_grad_textures) per_mesh = (gp ? 28.0 : 40.0) * is2 + (double)F * (180.0 + 24.0 * TS);
         else if (need_grad_faces) per_mesh = (gp ? 28.0 : 40.0) * is2 + (double)F * (180.0 + 12.0 * TS);
         else per_mesh = (gp ? 11.0 : 20.0) * is2 + (double)F * (144.0 + 12.0 * TS);
@@ -369,7 +376,8 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
             setup_bins(A, workspace, N, F, image_size, st);
             if (func_id_rgb == 0) UMR_LAUNCH((k_raster_backward<0>), blocks, BLK_THREADS, 0, st, A);
             else UMR_LAUNCH((k_raster_backward<1>), blocks, BLK_THREADS, 0, st, A);
-        } else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);
+        } else if (alpha_geom) launch_backward_fm_ag(A, st);
+        else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);
         else launch_backward_fm<1>(A, st);
     }
     return umr_launch_status();

@@ -240,9 +240,6 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
 #else
 #define FM_ACC(acc, a, b) acc += (a) * (b)
 #endif
-#ifndef FM_SLOTS
-#define FM_SLOTS 1        // 1: the silhouette variant hands its sub-tiles out through LDS slots (k_raster_backward_fm_slots,
-#endif                    // raster_backward_fm.h); -DFM_SLOTS=0: v_readlane rounds for every variant (round 2's form)
 #ifndef FM_STATE_CULL
 #define FM_STATE_CULL 1   // sub-tile skips from the saved forward state inside the culling pass (A/B: -DFM_STATE_CULL=0)
 #endif
@@ -302,26 +299,62 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
         atomicAdd(&my_tex[tix * 3 + 2], c);
     }
 }
-#define FM_BODY_SLOTS 0
+#define FM_ALPHA_GEOM 0
+#define FM_QUADS 0
 #define FM_KERNEL_NAME k_raster_backward_fm
 #include "raster_backward_fm.h"
-#undef FM_BODY_SLOTS
 #undef FM_KERNEL_NAME
-#define FM_BODY_SLOTS 1
-#define FM_KERNEL_NAME k_raster_backward_fm_slots
+#undef BWD_WPE              // (BWD_WPE_ATTR expands it at the kernel's declaration)
+#define BWD_WPE 6            // vertex + texel variant: 84 VGPRs and no SGPR spill traffic in the visit (213 -> 201 us at N = 16)
+#define FM_KERNEL_NAME k_raster_backward_fm_w6
 #include "raster_backward_fm.h"
-#undef FM_BODY_SLOTS
 #undef FM_KERNEL_NAME
+#undef BWD_WPE
+#define BWD_WPE 7
+#undef FM_QUADS
+#define FM_QUADS 1
+#define FM_KERNEL_NAME k_raster_backward_fm_quads
+#include "raster_backward_fm.h"
+#undef FM_KERNEL_NAME
+#undef FM_ALPHA_GEOM
+#define FM_ALPHA_GEOM 1
+#define FM_KERNEL_NAME k_raster_backward_fm_ag
+#include "raster_backward_fm.h"
+#undef FM_KERNEL_NAME
+#undef FM_ALPHA_GEOM
+#undef FM_QUADS
+#ifndef FM_QUADS_MASK
+#define FM_QUADS_MASK 1   // which variants take the quad hand-out: bit 0 silhouette, bit 1 texel-gradient-only, bit 2 vertex + texel
+#endif                    // (measured: header of raster_backward_fm.h)
+#ifndef FM_FULL_W6
+#define FM_FULL_W6 1      // vertex + texel variant at 6 waves / SIMD
+#endif
 
 template <int RGB, bool COMMON>
 void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
     const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
     const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
-    if (RGB == 2 && FM_SLOTS) UMR_LAUNCH((k_raster_backward_fm_slots<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
-    else if (RGB == 2) UMR_LAUNCH((k_raster_backward_fm<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
-    else if (A.need_gf && A.need_gt) UMR_LAUNCH((k_raster_backward_fm<RGB, true, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
-    else if (A.need_gf) UMR_LAUNCH((k_raster_backward_fm<RGB, true, false, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
-    else UMR_LAUNCH((k_raster_backward_fm<RGB, false, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+    if constexpr (RGB == 2) {
+        if constexpr ((FM_QUADS_MASK & 1) != 0) UMR_LAUNCH((k_raster_backward_fm_quads<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
+        else UMR_LAUNCH((k_raster_backward_fm<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
+    } else if (A.need_gf && A.need_gt) {
+        if constexpr ((FM_QUADS_MASK & 4) != 0) UMR_LAUNCH((k_raster_backward_fm_quads<RGB, true, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+        else if constexpr (FM_FULL_W6 != 0) UMR_LAUNCH((k_raster_backward_fm_w6<RGB, true, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+        else UMR_LAUNCH((k_raster_backward_fm<RGB, true, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+    } else if (A.need_gf) {
+        UMR_LAUNCH((k_raster_backward_fm<RGB, true, false, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+    } else {
+        if constexpr ((FM_QUADS_MASK & 2) != 0) UMR_LAUNCH((k_raster_backward_fm_quads<RGB, false, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+        else UMR_LAUNCH((k_raster_backward_fm<RGB, false, true, COMMON>), blocks, FM_WAVES * 64, lds, st, A);
+    }
+}
+// d alpha -> vertices and d rgb -> texels of a soft-max render in one pass (UMR_BWD_ALPHA_GEOMETRY)
+void launch_backward_fm_ag(const RasterArgs &A, hipStream_t st) {
+    const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
+    const size_t lds = A.TS > 1 ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
+    const bool common = A.grad_pooled && A.double_side && (A.IS & (A.IS - 1)) == 0;
+    if (common) UMR_LAUNCH((k_raster_backward_fm_ag<1, true, true, true>), blocks, FM_WAVES * 64, lds, st, A);
+    else UMR_LAUNCH((k_raster_backward_fm_ag<1, true, true, false>), blocks, FM_WAVES * 64, lds, st, A);
 }
 template <int RGB>
 void launch_backward_fm(const RasterArgs &A, hipStream_t st) {

@@ -1,12 +1,24 @@
-// raster_backward_fm.h -- BODY of the face-major backward kernel; NOT a standalone header: raster_backward.h includes it twice,
-//   FM_BODY_SLOTS 0, FM_KERNEL_NAME k_raster_backward_fm        sub-tile hand-out by v_readlane rounds (round 2's form)
-//   FM_BODY_SLOTS 1, FM_KERNEL_NAME k_raster_backward_fm_slots  sub-tile hand-out through LDS slots
-// as two kernels, because the two forms want different register allocations: measured on MI355X (us per launch, N = 16 / 128,
-// readlane -> slots) silhouette 82.6 -> 73.7 / 490 -> 451 (-8..11 %; -14 % at F = 5120, IS = 1024), colour variants the other
-// way -- texel-only 121 -> 125 / 812 -> 826, vertex + texel 206 -> 241 / 1321 -> 1571 (they sit at the 72-VGPR budget of 7 waves
-// and the slot's 4 values spill); and merely merging the two forms behind `if constexpr` in ONE function cost the vertex + texel
-// variant 10 % even on its untouched readlane path (229 vs 206 us).  raster.hip launches the slots kernel for the silhouette
-// variant only.
+// raster_backward_fm.h -- BODY of the face-major backward kernel; NOT a standalone header: raster_backward.h includes it once
+// per (hand-out form, register budget, gradient routing) as separate kernels, because the forms want different register
+// allocations (merging two forms behind `if constexpr` in ONE function once cost the vertex + texel variant 10 % on its
+// untouched path):
+//   FM_QUADS 0  k_raster_backward_fm      4x4 sub-tiles handed out by v_readlane rounds, four per visit
+//   FM_QUADS 0  k_raster_backward_fm_w6   the same at 6 waves / SIMD (vertex + texel variant: no SGPR spills in the visit, -5 %)
+//   FM_QUADS 1  k_raster_backward_fm_quads   2x2 quads through an LDS list, sixteen per visit (silhouette variant: -14 %)
+//   FM_QUADS 1, FM_ALPHA_GEOM 1  k_raster_backward_fm_ag   one pass for a render whose alpha gradient goes to the geometry and
+//               whose rgb gradient goes to the texels only (UMR_BWD_ALPHA_GEOMETRY)
+// Why quads (tools/r4/visit_census.py: this source with counters on the emulator): of the lanes a 4x4 hand-out carries 66 % lie
+// inside the face's band; by 2x2 pieces it is 89 %.  Wave visits per mesh of the SURVEY 8d scene: silhouette 12 694 -> 8 878,
+// texel-only 14 266 -> 12 140, vertex + texel 17 520 -> 14 956.  Measured on MI355X (us, N = 16): silhouette (N = 32) 158 -> 136,
+// texel-only 134 -> 126.5 (only with FM_VREC 0: at the 72-VGPR budget its allocation swings between 126 and 141 with
+// incidental source changes), vertex + texel 213 -> 202 -- so only the silhouette variant and the one-pass kernel take it.
+#ifndef UMR_MUL24
+#ifdef UMR_HOST_SHIM
+#define UMR_MUL24(a, b) ((a) * (b))
+#else
+#define UMR_MUL24(a, b) __mul24(a, b)     // v_mul_u32_u24 / v_mad_u32_u24: full rate (v_mul_lo_u32 is quarter rate)
+#endif
+#endif
 template <int RGB, bool NEED_GF, bool NEED_GT, bool COMMON>  // RGB 2 = silhouette only (soft_colors / grads are alpha planes)
 // COMMON = the production case (gradient arrives 2x2-pooled, power-of-two image, double-sided faces) as compile-time
 // facts: the wave-uniform flags otherwise live as 64-bit lane masks in SGPRs that spill (v_readlane per visit)
@@ -22,15 +34,21 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #else
     extern __shared__ __attribute__((aligned(16))) float s_tex[];  // [FM_WAVES][FM_TEXCOPY][FM_TEX_STRIDE(TS)]
 #endif
-#if FM_BODY_SLOTS
-    // sub-tile hand-out: the lane that owns a wanted candidate of the culling pass writes the sub-tile's origin (pixel-centre
-    // coordinates and byte offsets into the full / pooled planes) into slot [its rank among the wanted]; visit v hands slot
-    // 4 v + g to lane group g with one 16-byte LDS read (a broadcast within the group) -- it replaced four rounds of
-    // s_ff1 / v_readlane / v_cndmask and ~20 half-rate instructions of per-lane coordinate arithmetic per visit
-    __shared__ float4 s_slot[FM_WAVES][64];
+#if FM_QUADS
+    // quad hand-out: the culling lanes refine their surviving 4x4 sub-tile into its four 2x2 quads (band test + saved-state test
+    // per quad) and write one packed origin (qx | qy << 16, in quad units) per surviving quad at its rank; a visit hands 16 quads
+    // to the 16 lane groups of 4
+    __shared__ unsigned s_quad[FM_WAVES][256 + 32];   // (+32: the prefetch of the visit after the last reads past the end)
+    // silhouette variant on a power-of-two image: the slot holds the quad origin's pixel-centre coordinates (exact floats) and its
+    // byte offsets into the full / pooled planes, as the 4x4 slots form does -- the visit adds its lane's place, no integer decode
+    constexpr bool QSLOT16 = RGB == 2 && COMMON;
+    __shared__ float4 s_quad4[FM_WAVES][QSLOT16 ? 256 + 32 : 1];
 #endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
     const int F = A.F, IS = A.IS, TS = A.TS;
+    // AG: the rgb gradient reaches the texels only and the alpha gradient the geometry (silhouette backward + texel-only
+    // backward of one render in one pass); instantiated as <1, true, true, .>
+    constexpr bool AG = FM_ALPHA_GEOM != 0;
     const bool pooled = COMMON ? true : (A.grad_pooled != 0);
     const bool two_sided = COMMON ? true : (A.double_side != 0);
     // Wave-uniform float constants of the visit body, held in VGPRs on purpose: with the 32-float face record in SGPRs
@@ -87,7 +105,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     if (live) {
         // VGPR-resident operands where the register budget of 7 waves / SIMD has room for them (silhouette and
         // texel-gradient-only variants; the full variant would spill)
-        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF);
+        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF);      // (the one-pass kernel: 21 VGPR spills with the copies)
         typename std::conditional<VREC, FaceV, Face>::type fc;
         load_face(fc, A.rec + ((size_t)n * F + f) * REC);
         if constexpr (VREC) fc.fill();
@@ -117,12 +135,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const float4 i2 = make_float4(fc.template g<R_I8>(), fc.template g<R_K2>(), fc.template g<R_K0>(), fc.template g<R_K1>());
             const float thr_cull = A.thr + A.rec[((size_t)n * F + f) * REC + R_CULL];   // band of the cull: + the reference's noise
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
-#if FM_BODY_SLOTS
-            // this lane's place inside a sub-tile, as the increments the slot's origin takes (exact: see the visit)
-            const bool fastxy = pow2 && IS % FM_TW == 0 && IS % FM_TH == 0;   // exact incremental pixel centres, no ragged sub-tile
-            const int lx = sl % FM_TW, ly = sl / FM_TW;
-            const float lxf = (float)(2 * lx) * inv_is, lyf = (float)(2 * ly) * inv_is;
-            const unsigned lo_pn = (unsigned)(ly * IS + lx) * 4u, lo_gp = pooled ? (unsigned)((ly >> 1) * H2 + (lx >> 1)) * 4u : lo_pn;
+#if FM_QUADS
+            const int qsub = lane >> 2, qlx = lane & 1, qly = (lane >> 1) & 1;
+            const float qlxf = (float)(2 * qlx) * inv_is, qlyf = (float)(2 * qly) * inv_is;
+            const unsigned qlo_pn = (unsigned)(qly * IS + qlx) * 4u;
 #endif
 #ifdef FM_NO_CULL            // time-split experiment (-DFM_NO_CULL, HISTORY.md 4.2): per-face set-up and reductions only
             for (int tb = ntiles; tb < ntiles; tb += 64) {
@@ -133,14 +149,46 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                 const int ti = tb + lane;
                 bool want = false;
                 int tpk = 0;   // packed (tx, ty) of this lane's candidate
+#if FM_QUADS
+                unsigned qm = 0;   // surviving 2x2 quads of the candidate: bit q = quad (q & 1, q >> 1)
+#endif
                 if (ti < ntiles) {
                     const int ttx = tx0 + ti % ntx, tty = ty0 + ti / ntx;
                     tpk = ttx | (tty << 16);
                     const int px0 = ttx * FM_TW, px1 = min(px0 + FM_TW - 1, IS - 1), pr0 = tty * FM_TH, pr1 = min(pr0 + FM_TH - 1, IS - 1);
                     const float cxl = ndc_coord_fast(px0, IS, inv_is, pow2), cxh = ndc_coord_fast(px1, IS, inv_is, pow2);
                     const float cyh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, pow2), cyl = ndc_coord_fast(IS - 1 - pr1, IS, inv_is, pow2);
+#if FM_QUADS
+                    const bool whole = pow2 && IS >= 4 && FM_TW == 4 && FM_TH == 4;   // no ragged sub-tile: one evaluation for the sub-tile and its quads
+                    if (whole) {
+                        // (loop-variant VGPR copies: the per-face products of the quad test are then recomputed per pass -- a dozen
+                        // instructions -- instead of living in SGPRs across the visit loop, where they spill)
+                        float pxv = 2.f * inv_is, thrv = thr_cull;
+#ifndef UMR_HOST_SHIM
+                        asm volatile("" : "+v"(pxv), "+v"(thrv));
+#endif
+                        qm = subtile_quads_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), pxv, thrv);
+                        want = qm != 0;
+                    } else
+#endif
                     want = tile_may_hit(i0, i1, i2, 0.5f * (cxl + cxh), 0.5f * (cyl + cyh), 0.5f * (cxh - cxl),
                                         0.5f * (cyh - cyl), thr_cull);
+#if FM_QUADS
+                    if (want && !whole) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int qx0 = px0 + 2 * (q & 1), qr0 = pr0 + 2 * (q >> 1);
+                            if (qx0 < IS && qr0 < IS) {
+                                const int qx1 = min(qx0 + 1, IS - 1), qr1 = min(qr0 + 1, IS - 1);
+                                const float axl = ndc_coord_fast(qx0, IS, inv_is, pow2), axh = ndc_coord_fast(qx1, IS, inv_is, pow2);
+                                const float ayh = ndc_coord_fast(IS - 1 - qr0, IS, inv_is, pow2), ayl = ndc_coord_fast(IS - 1 - qr1, IS, inv_is, pow2);
+                                if (tile_may_hit(i0, i1, i2, 0.5f * (axl + axh), 0.5f * (ayl + ayh), 0.5f * (axh - axl), 0.5f * (ayh - ayl), thr_cull))
+                                    qm |= 1u << q;
+                            }
+                        }
+                        want = qm != 0;
+                    }
+#endif
 #if FM_STATE_CULL
                     // Exact sub-tile skips from the saved forward state, decided HERE by the one lane that owns the
                     // candidate (64 candidates per pass) instead of by a whole wave visit that finds its four sub-tiles dead:
@@ -148,11 +196,47 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     //  * texel gradients only, soft-max: even the face's nearest depth is >= 89 gamma behind the soft-max
                     //    maximum of every pixel -> p = D exp(<-89) / S = 0.0f (:608); hard mode: the face wins no pixel (:596).
                     // Inside the silhouette that removes most of the back-facing half of the mesh before any visit.
-                    if (FM_TW == 4 && FM_TH == 4 && (RGB == 2 || !NEED_GF) && want && px0 + 3 < IS && pr0 + 3 < IS && (IS & 3) == 0) {
+                    if (FM_TW == 4 && FM_TH == 4 && (RGB == 2 || !NEED_GF || (AG && FM_QUADS)) && want && px0 + 3 < IS && pr0 + 3 < IS && (IS & 3) == 0) {
                         const char *plane = RGB == 2 ? sc_n : ag_n + pst;           // alpha | soft-max maximum (hard: face id)
                         const unsigned o0 = (unsigned)(pr0 * IS + px0) * 4u, rs = (unsigned)IS * 4u;
                         const float4 q0 = ld_u4(plane, o0), q1 = ld_u4(plane, o0 + rs), q2 = ld_u4(plane, o0 + 2u * rs),
                                      q3 = ld_u4(plane, o0 + 3u * rs);
+#if FM_QUADS
+                        // the same exact skips per QUAD: quad (0,0) = rows 0-1 x columns 0-1, (1,0) = columns 2-3, (.,1) = rows 2-3.  NaN in
+                        // the saved state: never skipped (compares false / the sum test), as the per-pixel test of the visit has it.
+                        // One-pass kernel: a quad dies only when BOTH terms vanish (depth-dead AND alpha == 1)
+                        const float e[4][4] = {{q0.x, q0.y, q1.x, q1.y}, {q0.z, q0.w, q1.z, q1.w}, {q2.x, q2.y, q3.x, q3.y}, {q2.z, q2.w, q3.z, q3.w}};
+                        unsigned alive = 0;
+                        float ea[4][4] = {};
+                        if (AG) {   // second plane: the render's alpha (the geometry term dies where it is 1.0f)
+                            const char *pa = sc_n + 3u * pst;
+                            const float4 a0 = ld_u4(pa, o0), a1 = ld_u4(pa, o0 + rs), a2 = ld_u4(pa, o0 + 2u * rs), a3 = ld_u4(pa, o0 + 3u * rs);
+                            const float t[4][4] = {{a0.x, a0.y, a1.x, a1.y}, {a0.z, a0.w, a1.z, a1.w}, {a2.x, a2.y, a3.x, a3.y}, {a2.z, a2.w, a3.z, a3.w}};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) ea[q][k] = t[q][k];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bool al;
+                            if (RGB == 2) {
+                                al = !((e[q][0] == 1.f) & (e[q][1] == 1.f) & (e[q][2] == 1.f) & (e[q][3] == 1.f));
+                            } else if (RGB == 1) {
+                                const float mn = fminf(fminf(e[q][0], e[q][1]), fminf(e[q][2], e[q][3]));
+                                const float zmin_c = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
+                                const float sm = (e[q][0] + e[q][1]) + (e[q][2] + e[q][3]);
+                                al = !(((c_far - zmin_c) * c_rr - mn) * c_ig < -89.f) || !(sm == sm);
+                                if (AG) al = al || !((ea[q][0] == 1.f) & (ea[q][1] == 1.f) & (ea[q][2] == 1.f) & (ea[q][3] == 1.f));
+                            } else {
+                                const float ff = (float)f;
+                                al = (e[q][0] == ff) | (e[q][1] == ff) | (e[q][2] == ff) | (e[q][3] == ff);
+                            }
+                            alive |= al ? 1u << q : 0u;
+                        }
+                        qm &= alive;
+                        want = qm != 0;
+#else
                         if (RGB == 2) {
                             want = !((q0.x == 1.f) & (q0.y == 1.f) & (q0.z == 1.f) & (q0.w == 1.f) & (q1.x == 1.f) & (q1.y == 1.f) &
                                      (q1.z == 1.f) & (q1.w == 1.f) & (q2.x == 1.f) & (q2.y == 1.f) & (q2.z == 1.f) & (q2.w == 1.f) &
@@ -174,6 +258,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                                    (q1.w == ff) | (q2.x == ff) | (q2.y == ff) | (q2.z == ff) | (q2.w == ff) | (q3.x == ff) | (q3.y == ff) |
                                    (q3.z == ff) | (q3.w == ff);
                         }
+#endif
                     }
 #endif
                 }
@@ -182,28 +267,46 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #ifdef FM_NO_VISIT          // time-split experiment (-DFM_NO_VISIT, HISTORY.md 4.2): per-face set-up + culling pass only
                 tm = 0;
 #endif
-#if FM_BODY_SLOTS
-                const int nv = __popcll(tm);
+#if FM_QUADS
+                // this lane's first quad's rank among the wave's surviving quads, in (lane, quad) order: prefix sum of the lanes' quad
+                // counts (0 .. 4) from three ballots of the count's bits
+                const int cnt = tm != 0 ? __popcll((unsigned long long)qm) : 0;
+                const unsigned long long b0 = __ballot((cnt & 1) != 0), b1 = __ballot((cnt & 2) != 0), b2 = __ballot((cnt & 4) != 0);
+                const int nq = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
                 if (want) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tm, 0u));
+                    int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u)) +
+                              2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u)) +
+                              4 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u));
                     const int px0 = (tpk & 0xffff) * FM_TW, pr0 = (tpk >> 16) * FM_TH;
-                    const unsigned o_pn = (unsigned)(pr0 * IS + px0) * 4u;
-                    const unsigned o_gp = pooled ? (unsigned)((pr0 >> 1) * H2 + (px0 >> 1)) * 4u : o_pn;
-                    // power-of-two image: the origin's pixel-centre coordinates (exact floats); otherwise the packed tile index
-                    // and the visit evaluates the fp64 expression per lane as before
-                    s_slot[wave][rank] = make_float4(fastxy ? ndc_coord_fast(px0, IS, inv_is, true) : __int_as_float(tpk),
-                                                     fastxy ? ndc_coord_fast(IS - 1 - pr0, IS, inv_is, true) : 0.f,
-                                                     __int_as_float((int)o_pn), __int_as_float((int)o_gp));
+                    if constexpr (QSLOT16) {
+                        const float x0 = ndc_coord_fast(px0, IS, inv_is, true), y0 = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, true);
+                        const float dq = 4.f * inv_is;                                        // two pixels
+                        const unsigned o_pn = (unsigned)(pr0 * IS + px0) * 4u, o_gp = (unsigned)((pr0 >> 1) * H2 + (px0 >> 1)) * 4u;
+                        const unsigned r_pn = 2u * (unsigned)IS * 4u, r_gp = (unsigned)H2 * 4u;      // two rows down / one pooled row down
+                        if (qm & 1u) s_quad4[wave][pos++] = make_float4(x0, y0, __int_as_float((int)o_pn), __int_as_float((int)o_gp));
+                        if (qm & 2u) s_quad4[wave][pos++] = make_float4(x0 + dq, y0, __int_as_float((int)(o_pn + 8u)), __int_as_float((int)(o_gp + 4u)));
+                        if (qm & 4u) s_quad4[wave][pos++] = make_float4(x0, y0 - dq, __int_as_float((int)(o_pn + r_pn)), __int_as_float((int)(o_gp + r_gp)));
+                        if (qm & 8u) s_quad4[wave][pos++] = make_float4(x0 + dq, y0 - dq, __int_as_float((int)(o_pn + r_pn + 8u)), __int_as_float((int)(o_gp + r_gp + 4u)));
+                    } else {
+                    // origin of a quad in PIXELS: x | row << 16 (both even: a lane ORs its place in the quad in)
+                    const unsigned base = (unsigned)px0 | ((unsigned)pr0 << 16);
+                    if (qm & 1u) s_quad[wave][pos++] = base;
+                    if (qm & 2u) s_quad[wave][pos++] = base + 2u;
+                    if (qm & 4u) s_quad[wave][pos++] = base + 0x20000u;
+                    if (qm & 8u) s_quad[wave][pos++] = base + 0x20002u;
+                    }
                 }
                 UMR_WAVE_LDS_HANDOVER();
-                // the slot of visit v + 1 is read at the top of visit v: LDS operations of a wave complete in order, so a read
-                // issued behind this visit's texel atomics (ds_add_f32, ~12 cycles a lane) would stall the next visit on them
-                float4 sd_next = s_slot[wave][sub < nv ? sub : 0];
-                for (int v0 = 0; v0 < nv; v0 += FM_NQ) {
-                    // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
-                    const int mine = v0 + sub < nv ? v0 + sub : -1;
-                    const float4 sd = sd_next;
-                    sd_next = s_slot[wave][v0 + FM_NQ + sub < nv ? v0 + FM_NQ + sub : 0];
+                const unsigned *qslot = &s_quad[wave][qsub];
+                const float4 *qslot4 = &s_quad4[wave][QSLOT16 ? qsub : 0];
+                unsigned qe_next = QSLOT16 ? 0u : qslot[0];
+                float4 q4_next = QSLOT16 ? qslot4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int v0 = 0; v0 < nq; v0 += 16) {
+                    const int mine = v0 + qsub < nq ? 0 : -1;
+                    const unsigned qe = qe_next;
+                    const float4 q4 = q4_next;
+                    if constexpr (QSLOT16) q4_next = qslot4[v0 + 16];
+                    else qe_next = qslot[v0 + 16];     // (past the last quad: stale or unwritten words of the array, never used)
 #else
                 while (tm) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
@@ -218,7 +321,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         }
                     }
 #endif
-                    if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2) {
+                    if (FM_RELOAD_PER_TILE && NEED_GF && RGB != 2 && !AG) {
                         // re-fetch the record from the scalar cache every visit: keeps the 32 constants loop-VARIANT so the
                         // compiler cannot hoist 30+ SGPR->VGPR copies out of the tile loop.  Only for the variants that
                         // also carry the 9 vertex-gradient accumulators and the colour path (measured 4-6 % faster with
@@ -230,20 +333,21 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         reload_face(fc, rp);
                     }
                     if (mine < 0) continue;
-#if FM_BODY_SLOTS
+#if FM_QUADS
                     float xp, yp;
-                    if (fastxy) {
-                        // (2 (x0 + lx) + 1 - IS) / IS = origin + 2 lx / IS: every term and the sum are small integers over a power
-                        // of two -- exact in fp32, the same bits as ndc_coord_fast per pixel (IS % 4 == 0: no ragged sub-tile)
-                        xp = sd.x + lxf; yp = sd.y - lyf;
+                    unsigned pn4, gp4;
+                    if constexpr (QSLOT16) {
+                        xp = q4.x + qlxf; yp = q4.y - qlyf;     // exact: small integers over a power of two
+                        pn4 = (unsigned)__float_as_int(q4.z) + qlo_pn;
+                        gp4 = (unsigned)__float_as_int(q4.w);   // (COMMON: the gradient arrives pooled -- the quad IS one pooled pixel)
                     } else {
-                        const int tp = __float_as_int(sd.x);
-                        const int row = (tp >> 16) * FM_TH + ly, xi = (tp & 0xffff) * FM_TW + lx;
-                        if (xi >= IS || row >= IS) continue;
-                        yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2); xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                        const int xi = (int)(qe & 0xffffu) | qlx, row = (int)(qe >> 16) | qly;
+                        if (!(pow2 && IS >= 4) && (xi >= IS || row >= IS)) continue;      // (a power-of-two image has no ragged sub-tile)
+                        yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
+                        xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+                        pn4 = (unsigned)(UMR_MUL24(row, IS) + xi) * 4u;               // byte offset in a full plane (< 2^24 pixels a side)
+                        gp4 = pooled ? (unsigned)(UMR_MUL24(row >> 1, H2) + (xi >> 1)) * 4u : pn4;
                     }
-                    const unsigned pn4 = (unsigned)__float_as_int(sd.z) + lo_pn;               // byte offset in a full plane
-                    const unsigned gp4 = (unsigned)__float_as_int(sd.w) + lo_gp;
 #else
                     const int row = (mine >> 16) * FM_TH + sl / FM_TW;
                     const int xi = (mine & 0xffff) * FM_TW + sl % FM_TW;
@@ -263,14 +367,15 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                             dead = ld_u(sc_n, pn4) == 1.f;
                         } else {
                             dead = false;
-                            if (!NEED_GF) {   // (with vertex gradients both terms must vanish: too rare to pay for)
+                            if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
                                 const float smx = ld_u(ag_n, pn4 + pst);
                                 const float zmin_f = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
                                                 : ((c_far - zmin_f) * c_rr - smx) * c_ig < -89.f;
+                                if (AG) dead = dead && ld_u(sc_n, pn4 + 3 * pst) == 1.f;
                             }
                         }
-                        if ((RGB == 2 || !NEED_GF) && __all(dead)) continue;
+                        if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue;
                     }
                     Pair p;
                     if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis, A.amb_thr)) continue;
@@ -318,7 +423,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                             if (TS == 1) { FM_ACC(gt0, ps, g0); FM_ACC(gt1, ps, g1); FM_ACC(gt2, ps, g2); }
                             else texel_accumulate(my_tex, tix, ps * g0, ps * g1, ps * g2, lane);
                         }
-                        if (NEED_GF) {
+                        if (NEED_GF && !AG) {
                             const char *tx = (const char *)tex_f;
                             const unsigned t12 = (unsigned)tix * 12u;
                             float c_rgb = g0 * (ld_u(tx, t12) - ld_u(sc_n, pn4));
@@ -336,9 +441,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         c_xy *= p.frag * (1.f - p.frag) * (-c_nis);  // :632
                         const float k2 = 2.f * p.sign * c_xy;        // :640
                         const float b0 = k2 * p.b0, b1 = k2 * p.b1, b2 = k2 * p.b2;
-                        FM_ACC(gv[0], b0, p.dx); FM_ACC(gv[1], b0, p.dy); gv[2] += gz0;
-                        FM_ACC(gv[3], b1, p.dx); FM_ACC(gv[4], b1, p.dy); gv[5] += gz1;
-                        FM_ACC(gv[6], b2, p.dx); FM_ACC(gv[7], b2, p.dy); gv[8] += gz2;
+                        FM_ACC(gv[0], b0, p.dx); FM_ACC(gv[1], b0, p.dy);
+                        FM_ACC(gv[3], b1, p.dx); FM_ACC(gv[4], b1, p.dy);
+                        FM_ACC(gv[6], b2, p.dx); FM_ACC(gv[7], b2, p.dy);
+                        if (!AG) { gv[2] += gz0; gv[5] += gz1; gv[8] += gz2; }
                     }
                 }
             }

@@ -592,6 +592,33 @@ __device__ __forceinline__ bool tile_may_hit(const float4 q0, const float4 q1, c
     return sliver | !out;
 }
 
+// tile_may_hit for a 4x4 sub-tile AND its four 2x2 quads (power-of-two image: no ragged sub-tile): returns bit q set when quad
+// (q & 1, q >> 1) -- columns 2 (q & 1) .. +1, rows 2 (q >> 1) .. +1 of the sub-tile -- may hold a surviving pixel centre, 0 when the
+// sub-tile as a whole cannot.  w_k is affine, so a quad's bound is the sub-tile centre's w_k moved by one pixel each way plus the
+// half-pixel extent: three adds per (edge, quad) instead of a fresh evaluation.  `px` = one pixel in screen units (2 / IS).
+__device__ __forceinline__ unsigned subtile_quads_may_hit(const float4 q0, const float4 q1, const float4 q2, float cx, float cy,
+                                                         float px, float thr) {
+    const float t0 = -(thr * __frsqrt_rn(q2.z)) - 1e-3f, t1 = -(thr * __frsqrt_rn(q2.w)) - 1e-3f, t2 = -(thr * __frsqrt_rn(q2.y)) - 1e-3f;
+    const bool sliver = !((q2.z >= 1e-9f) & (q2.w >= 1e-9f) & (q2.y >= 1e-9f));
+    const float c0 = fmaf(q0.x, cx, fmaf(q0.z, cy, q1.x)), c1 = fmaf(q0.y, cx, fmaf(q0.w, cy, q1.y)), c2 = fmaf(q1.z, cx, fmaf(q1.w, cy, q2.x));
+    // whole sub-tile: half extents 1.5 pixels
+    const float a0 = px * q0.x, b0 = px * q0.z, a1 = px * q0.y, b1 = px * q0.w, a2 = px * q1.z, b2 = px * q1.w;
+    const float e0 = fabsf(a0) + fabsf(b0), e1 = fabsf(a1) + fabsf(b1), e2 = fabsf(a2) + fabsf(b2);
+    const bool out = fmaf(1.5f, e0, c0) < t0 || fmaf(1.5f, e1, c1) < t1 || fmaf(1.5f, e2, c2) < t2;
+    if (sliver) return 15u;
+    if (out) return 0u;
+    // quads: centre one pixel off the sub-tile's centre each way (rows grow downwards: row pair 0 is +y), half extent 0.5 pixel
+    const float m0 = fmaf(0.5f, e0, c0), m1 = fmaf(0.5f, e1, c1), m2 = fmaf(0.5f, e2, c2);
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float sx = (q & 1) ? 1.f : -1.f, sy = (q >> 1) ? -1.f : 1.f;
+        const bool o = (m0 + sx * a0) + sy * b0 < t0 || (m1 + sx * a1) + sy * b1 < t1 || (m2 + sx * a2) + sy * b2 < t2;
+        m |= o ? 0u : 1u << q;
+    }
+    return m;
+}
+
 // XCD-aware work mapping: hardware places workgroup b on XCD b % 8; give each XCD a contiguous
 // run of (mesh, tile) work items so one mesh's face records stay in one L2.
 __device__ __forceinline__ int xcd_remap(int b, int total) {

@@ -36,6 +36,8 @@ from torch.library import custom_op
 from . import _lib
 from ._lib import ptr
 
+BWD_ALPHA_GEOMETRY = 4      # UMR_BWD_ALPHA_GEOMETRY (include/umr_hip.h)
+
 
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
@@ -267,11 +269,48 @@ def soft_rasterize_alpha_geometry_op(face_vertices: torch.Tensor, textures: torc
 soft_rasterize_alpha_geometry_op.register_fake(_raster_fake)
 
 
+@custom_op("umr::soft_rasterize_alpha_geometry_backward", mutates_args=(), device_types="cuda")
+def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textures: torch.Tensor, soft_colors: torch.Tensor,
+                                              aggrs_info: torch.Tensor, grad_image: torch.Tensor, image_size: int, near: float,
+                                              far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
+                                              gamma_val: float, modes: int, pool: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Both gradients of the shared render from ONE pass over its (pixel, face) pairs (UMR_BWD_ALPHA_GEOMETRY): what
+    umr::silhouette_backward on the alpha plane and the texel-only umr::soft_rasterize_backward return."""
+    L = _lib.lib()
+    fv, tex = _f32c(face_vertices), _f32c(textures)
+    dev = fv.device
+    N, F = fv.shape[:2]
+    TS = tex.shape[2]
+    G = N // tex.shape[0]
+    grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32)
+    grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32)   # per view
+    g = grad_image.to(torch.float32).contiguous()
+    ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
+    rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces), ptr(grad_textures), ptr(g),
+                               (1 if pool else 0) | BWD_ALPHA_GEOMETRY | (G << 8), 1, 1, N, F, TS, *sc, ptr(ws), ws_bytes,
+                               _lib.stream_ptr(dev))
+    _lib.check(rc, "umr_raster_backward(alpha geometry)")
+    if G > 1:
+        grad_textures = grad_textures.view(N // G, G, F, TS, 3).sum(1)   # autograd of the reference's repeat
+    return grad_faces.view(N, F, 3, 3), grad_textures
+
+
+@soft_rasterize_alpha_geometry_backward_op.register_fake
+def _(face_vertices, textures, soft_colors, aggrs_info, grad_image, image_size, near, far, fill_back, eps, sigma_val, dist_eps,
+      gamma_val, modes, pool):
+    return (face_vertices.new_empty(face_vertices.shape, dtype=torch.float32), textures.new_empty(textures.shape, dtype=torch.float32))
+
+
 def _raster_ag_backward(ctx, g_image, g_p2f, g_aggrs, g_saved, g_vis):
     fv, tex, soft_colors, aggrs = ctx.saved_tensors
     image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool = ctx.cfg
     need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     gf = gt = None
+    if need_gf and need_gt:
+        gf, gt = torch.ops.umr.soft_rasterize_alpha_geometry_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg)
+        return (gf, gt) + (None,) * 13
     if need_gf:      # alpha -> geometry: the mask render's backward on this render's alpha plane
         gf = torch.ops.umr.silhouette_backward(fv, soft_colors[:, 3].contiguous(), g_image[:, 3].contiguous(), image_size, near, far,
                                                fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
