@@ -125,3 +125,33 @@ def test_shared_mask_render_equals_the_two_renders_on_the_emulator():
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
     for a, b in zip(res[0][2], res[1][2]):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+def test_shared_render_backward_beyond_the_one_pass_kernels_texel_budget():
+    """umr::soft_rasterize_alpha_geometry with 32 x 32 texels per face: the face-major kernels' LDS accumulators hold at most 1023
+    texels, so the autograd formula takes the two-launch form (silhouette backward on the alpha plane + texel-only backward) and
+    the one-pass operator refuses; gradients still route as the reference's two renders do."""
+    import torch
+    from host_raster import emulated_product
+    from helpers import scene
+    from umr_amd import functional as UF, ops
+    with emulated_product():
+        verts, faces, cams, gen = scene(2, 1, seed=3)
+        _, fv, _ = UF.project_faces(verts, cams, faces.int(), 5.0, -2.732)
+        fv = fv.detach()
+        tex = torch.rand(2, faces.shape[1], 1024, 3, generator=gen)
+        IS = 32
+        args = (IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface')
+        g = torch.randn(2, 4, IS, IS, generator=gen)
+        fv1, tex1 = fv.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        img = UF.soft_rasterize(fv1, tex1, *args, detach_rgb_geometry=True)[0]
+        (img * g).sum().backward()
+        fv2, tex2 = fv.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        alpha = UF.silhouette(fv2, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, False)
+        img2 = UF.soft_rasterize(fv2.detach(), tex2, *args)[0]
+        ((alpha * g[:, 3]).sum() + (img2[:, :3] * g[:, :3]).sum()).backward()
+        assert torch.equal(img[:, 3], alpha) and float(fv2.grad.abs().max()) > 0 and float(tex2.grad.abs().max()) > 0
+        assert torch.equal(fv1.grad, fv2.grad) and torch.equal(tex1.grad, tex2.grad)        # the same two kernels on the same inputs
+        with pytest.raises(RuntimeError, match="texels per face"):
+            torch.ops.umr.soft_rasterize_alpha_geometry_backward(fv, tex, img.detach().contiguous(), torch.zeros(2, 2, IS, IS), g,
+                                                                 IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, ops.pack_modes(1), False)

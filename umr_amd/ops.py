@@ -37,6 +37,7 @@ from . import _lib
 from ._lib import ptr
 
 BWD_ALPHA_GEOMETRY = 4      # UMR_BWD_ALPHA_GEOMETRY (include/umr_hip.h)
+ONE_PASS_MAX_TS = 1023      # texels per face the face-major backward's LDS accumulators take (4 copies x (3 TS | 1) floats <= 48 KB)
 
 
 def _f32c(t):
@@ -281,6 +282,9 @@ def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textu
     dev = fv.device
     N, F = fv.shape[:2]
     TS = tex.shape[2]
+    if TS > ONE_PASS_MAX_TS:
+        raise RuntimeError("soft_rasterize_alpha_geometry_backward: %d texels per face; the one-pass kernel takes at most %d "
+                           "(use the silhouette + texel-only backward pair)" % (TS, ONE_PASS_MAX_TS))
     G = N // tex.shape[0]
     grad_faces = torch.zeros(N, F, 9, device=dev, dtype=torch.float32)
     grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32)   # per view
@@ -308,7 +312,9 @@ def _raster_ag_backward(ctx, g_image, g_p2f, g_aggrs, g_saved, g_vis):
     image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool = ctx.cfg
     need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     gf = gt = None
-    if need_gf and need_gt:
+    # ONE pass for both gradients where the face-major kernels run: their per-wave LDS texel accumulators hold TS <= 1023 texels
+    # (beyond that umr_raster_backward takes its pixel-major route, which library 0.5 does not specialise for this flag)
+    if need_gf and need_gt and tex.shape[2] <= ONE_PASS_MAX_TS:
         gf, gt = torch.ops.umr.soft_rasterize_alpha_geometry_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg)
         return (gf, gt) + (None,) * 13
     if need_gf:      # alpha -> geometry: the mask render's backward on this render's alpha plane
