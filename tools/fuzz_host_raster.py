@@ -110,8 +110,11 @@ def run_one(rng, kind, IS, L, stats):
     rgfa, _ = softras.raster_backward(faces, tex, ref["soft_colors"], ref["faces_info"], ref["aggrs_info"], ga, IS, n_threads=1, **cfg)
     gfa, _ = HR.backward(faces, None, np.ascontiguousarray(ref["soft_colors"][:, 3]), None, np.ascontiguousarray(ga[:, 3]), IS,
                          need_gt=False, grad_flags=HR.BWD_ALPHA_ONLY, L=L, **cfg)
+    # the one-pass backward of a shared mask / texture render: its vertex gradient is the alpha term alone, its texel gradient
+    # the full one
+    gf1p, gt1p = HR.backward(faces, tex, ref["soft_colors"], ref["aggrs_info"], gsc, IS, grad_flags=HR.BWD_ALPHA_GEOMETRY, L=L, **cfg)
     bad = []
-    for name, a, r in (("gf", gf, rgf), ("gt", gt, rgt), ("gt", gt1, rgt), ("gfa", gfa, rgfa)):
+    for name, a, r in (("gf", gf, rgf), ("gt", gt, rgt), ("gt", gt1, rgt), ("gfa", gfa, rgfa), ("gfa", gf1p, rgfa), ("gt", gt1p, rgt)):
         fr = np.isfinite(r).all()
         if fr and not np.isfinite(a).all():
             rec["nonfinite_host_only"] += 1
