@@ -215,6 +215,7 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
 //   out[2] ... whose 4x4 sub-tile the cull drops         out[3] ... dropped at 8x8 but KEPT at 4x4: the backward includes a pair
 // the forward did not -- where no nearer face covers the pixel the saved soft-max maximum is then far below the pair's depth and
 // exp((zn - max) / gamma) overflows (round 3's non-finite training runs at configs[3], HISTORY.md 10).
+//   out[4] ... kept at 4x4 whose 2x2 QUAD the backward's quad refinement drops (subtile_quads_may_hit; power-of-two images)
 // noise_scale multiplies the per-face widening R_CULL of the band: 0 = the band at the exact threshold (round 3's early builds).
 // first[0..3]: (face, xi, row, -) of the first out[3] case.
 int host_cull_granularity(const float *faces, int n, int IS, float thr, float threshold, float nis, float noise_scale, long *out, int *first) {
@@ -227,7 +228,7 @@ int host_cull_granularity(const float *faces, int n, int IS, float thr, float th
     }
     const bool pow2 = (IS & (IS - 1)) == 0;
     const float inv_is = 1.f / (float)IS, h = 0.5f * IS;
-    out[0] = out[1] = out[2] = out[3] = 0;
+    out[0] = out[1] = out[2] = out[3] = out[4] = 0;
     first[0] = -1;
     auto hit = [&](const float4 *q, const float4 bb, float band, int px0, int pr0, int T) {
         const int px1 = min(px0 + T - 1, IS - 1), pr1 = min(pr0 + T - 1, IS - 1);
@@ -254,12 +255,19 @@ int host_cull_granularity(const float *faces, int n, int IS, float thr, float th
                         const int px0 = tx * 8 + sx * 4, pr0 = ty * 8 + sy * 4;
                         if (px0 >= IS || pr0 >= IS) continue;
                         const bool h4 = hit(q, bb, band, px0, pr0, 4);
+                        unsigned qm = 15u;
+                        if (h4 && pow2 && IS >= 4) {
+                            const float xl = ndc_coord_fast(px0, IS, inv_is, true), xh = ndc_coord_fast(px0 + 3, IS, inv_is, true);
+                            const float yh = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, true), yl = ndc_coord_fast(IS - 1 - (pr0 + 3), IS, inv_is, true);
+                            qm = subtile_quads_may_hit(q[0], q[1], q[2], 0.5f * (xl + xh), 0.5f * (yl + yh), 2.f * inv_is, band);
+                        }
                         for (int row = pr0; row < min(pr0 + 4, IS); ++row)
                             for (int xi = px0; xi < min(px0 + 4, IS); ++xi) {
                                 Pair pr;
                                 if (!eval_pair(pr, fc, ndc_coord_fast(xi, IS, inv_is, pow2), ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2), threshold, nis)) continue;
                                 ++out[0];
                                 out[1] += !h8; out[2] += !h4;
+                                if (h4 && !((qm >> ((((row - pr0) >> 1) << 1) | ((xi - px0) >> 1))) & 1u)) ++out[4];
                                 if (!h8 && h4) {
                                     if (!out[3]) { first[0] = i; first[1] = xi; first[2] = row; }
                                     ++out[3];

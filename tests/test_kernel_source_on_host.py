@@ -347,8 +347,17 @@ def test_tile_culls_of_both_directions_agree_where_a_pixel_is_included(host_lib)
     fv[:, 2, :2] = c + ((rng.uniform(0.05, 0.95, n) - 0.5) * L)[:, None] * u + hh[:, None] * v
     fv[:, :, 2] = rng.uniform(3, 6, (n, 3))
     fv = np.ascontiguousarray(fv.reshape(n, 9))
-    cnt, first = (ctypes.c_long * 4)(), (ctypes.c_int * 4)()
+    cnt, first = (ctypes.c_long * 5)(), (ctypes.c_int * 4)()
     host_lib.host_cull_granularity(p(fv), n, 1024, thr, threshold, -1.0 / sigma, 1.0, cnt, first)
-    assert cnt[0] > 1000000 and cnt[1] == 0 and cnt[2] == 0 and cnt[3] == 0, list(cnt)
+    # ... nor by the backward's refinement of a surviving 4x4 sub-tile into 2x2 quads (cnt[4]; the quad hand-out of round 4)
+    assert cnt[0] > 1000000 and cnt[1] == 0 and cnt[2] == 0 and cnt[3] == 0 and cnt[4] == 0, list(cnt)
     host_lib.host_cull_granularity(p(fv), n, 1024, thr, threshold, -1.0 / sigma, 0.0, cnt, first)
     assert cnt[1] > 0 and cnt[2] > 0      # with the exact band both culls DO drop pixels the reference's arithmetic includes
+    # the same count on ordinary faces (the bench's proportions): no included pixel is lost at any granularity
+    n2 = 3000
+    c2 = rng.uniform(-0.9, 0.9, (n2, 1, 2)); fv2 = np.zeros((n2, 3, 3), f32)
+    fv2[:, :, :2] = c2 + rng.uniform(-0.06, 0.06, (n2, 3, 2)); fv2[:, :, 2] = rng.uniform(3, 6, (n2, 3))
+    fv2 = np.ascontiguousarray(fv2.reshape(n2, 9))
+    for IS in (512, 64):
+        host_lib.host_cull_granularity(p(fv2), n2, IS, thr, threshold, -1.0 / sigma, 1.0, cnt, first)
+        assert cnt[0] > 10000 and cnt[1] == 0 and cnt[2] == 0 and cnt[3] == 0 and cnt[4] == 0, (IS, list(cnt))
