@@ -264,6 +264,11 @@ def test_ctypes_signatures_match_the_header_prototypes():
                 assert a in (ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_uint), (name, p, a)
         checked += 1
     assert checked >= 40
+    # the flag values the Python layer passes are the header's
+    raw = open(os.path.join(ROOT, "include", "umr_hip.h")).read()
+    flag = lambda n: int(re.search(r"#define\s+%s\s+(\d+)" % n, raw).group(1))
+    from umr_amd import ops
+    assert (flag("UMR_BWD_GRAD_POOLED"), flag("UMR_BWD_ALPHA_ONLY"), flag("UMR_BWD_ALPHA_GEOMETRY")) == (1, 2, ops.BWD_ALPHA_GEOMETRY)
 
 
 def test_every_kernel_of_the_path_is_a_registered_operator_with_a_fake_kernel():
