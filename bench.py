@@ -509,7 +509,8 @@ def main(device=None, backend="nccl"):
               "visibility render; unseen-view silhouette) + IoU / AlexNet-perceptual "
               "texture / texture-dt / tex-cycle / Laplacian / flatten / GAN losses, fwd+bwd, epoch %d%s"
               % (args.batch, args.image_size, args.image_size, 2 * args.image_size, faces.shape[0],
-                 "2 fwd + 2 bwd (ONE backward pass for the shared render's two gradients)" if args.share_mask_render else "4 fwd + 3 bwd", args.epoch, net_note))
+                 "2 fwd + 2 bwd (ONE backward pass for the shared render's two gradients)" if args.share_mask_render else
+                 "2 fwd + 2 bwd (mask and unseen-view silhouettes in one 2B-view launch each way)", args.epoch, net_note))
     else:
         wl = ("train_s2 CUB-shaped bs=%d/GPU %dx%d (IS=%d) %d-face icosphere, 8 camera hypotheses: the reference's 22 raster fwd + 21 bwd per "
               "image as %s (8 textured hypothesis renders whose alpha channels are the 8 mask renders, 1 visibility, 1 unseen "
