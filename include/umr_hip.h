@@ -114,7 +114,9 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
                                    loss_utils.py:313) and whose alpha channel is the mask render of the same views (:199, :265):
                                    grad_faces receives the alpha term only, grad_textures the rgb term -- what
                                    UMR_BWD_ALPHA_ONLY on the alpha plane plus a texel-only call return, from one pass over the
-                                   (pixel, face) pairs; needs need_grad_faces and need_grad_textures, func_id_rgb 1 */
+                                   (pixel, face) pairs; needs need_grad_faces and need_grad_textures, func_id_rgb 1, and
+                                   TS <= 1023 texels per face (the face-major kernels' LDS accumulators): anything else returns
+                                   UMR_ERR_ARG with nothing enqueued -- the flag is never silently dropped */
 
 /* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins, the backward's
  * start order).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst

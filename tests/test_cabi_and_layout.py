@@ -103,6 +103,20 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.umr_dt_barrier(one, one, None, None, 1, 16, 16, 50.0, one, 8, None) == -1   # workspace too small
     assert L.umr_project_faces_forward(one, one, one, None, one, 0, 4, 4, 5.0, -2.732, 1, None) == -1
     assert L.umr_debug_set(b"no_such_switch", 1) == -1
+    # UMR_BWD_ALPHA_GEOMETRY (4) is routed by the face-major kernels only: where umr_raster_backward would take its pixel-major
+    # pair -- more texels per face than the LDS accumulators hold, or the A/B switch -- the call is REJECTED (round 4 returned
+    # UMR_OK with the rgb gradient in grad_faces).  soft_rasterize_cuda.cpp:122-129: the reference raises, never returns other data
+    b = [one] * 8
+    btail = [1.0, 100.0, 1e-3, 1e-5, 2, 23.0, 1e-4, 1, 2, 0, 1, one, 1 << 30, None]
+    assert L.umr_raster_backward(*b, 1 | 4, 1, 1, 1, 8, 1024, 64, *btail) == -1      # TS = 1024 > 1023
+    assert L.umr_raster_backward(*b, 4, 1, 1, 1, 8, 1024, 64, *btail) == -1          # ... with a full-resolution gradient as well
+    assert L.umr_raster_backward(*b, 1 | 4, 1, 0, 1, 8, 36, 64, *btail) == -1        # the flag asks for both gradients
+    assert L.umr_raster_backward(*b, 1 | 4 | 2, 1, 0, 1, 8, 36, 64, *btail) == -1    # ... and excludes ALPHA_ONLY
+    assert L.umr_debug_set(b"bwd_pixel_major", 1) == 0
+    try:
+        assert L.umr_raster_backward(*b, 1 | 4, 1, 1, 1, 8, 36, 64, *btail) == -1    # pixel-major A/B route: rejected too
+    finally:
+        assert L.umr_debug_set(b"bwd_pixel_major", 0) == 0
 
 
 def test_symmetric_face_ordering_matches_reference_constants():

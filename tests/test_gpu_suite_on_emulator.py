@@ -1,5 +1,5 @@
 """CPU tests (no GPU): the `-m gpu` parity tests themselves -- tests/test_gpu_parity.py, test_gpu_round2.py, test_gpu_round3.py,
-test_gpu_zz_collapsed_edges.py, unmodified, with their MI355X bounds -- executed on HOST tensors over libumr_host.so: every
+test_gpu_round5.py, test_gpu_zz_collapsed_edges.py, unmodified, with their MI355X bounds -- executed on HOST tensors over libumr_host.so: every
 translation unit of the product library (umr_amd/csrc/*.hip) compiled for x86-64 on the wave64 emulator of
 tests/host_kernel/wave_emu.h, driven by the product's own Python layer (functional.py, smr.py, loss_utils.py, train_step.py,
 eval_utils.py ...) through tests/host_raster.py::emulated_product.  So the reference's goldens, the oracle comparisons and the
@@ -38,6 +38,7 @@ GPU_TESTS = {
         "test_small_regularisers_and_masked_l1_vs_reference_goldens", "test_rotate_cam_vs_reference_golden",
         "test_keypoint_transfer_vs_reference_golden"],
     "test_gpu_zz_collapsed_edges": ["test_collapsed_edges_stay_finite_and_follow_the_reference"],
+    "test_gpu_round5": ["test_alpha_geometry_backward_vs_oracle", "test_alpha_geometry_flag_is_refused_off_the_face_major_route"],
 }
 
 

@@ -115,7 +115,7 @@ if dd:
              % (tag, dd["value"], cfg.get("allreduce_bytes", 0) / 1e6, cfg.get("ddp_buckets", 0), cfg.get("ddp_bucket_mb", 0),
                 cfg.get("allreduce_ms_standalone", float("nan"))))
 if ev:
-    L.append("Evaluation path (BASELINE configs[4], `tools/r3/eval_bench.py`, `profiles/%s_eval_bench.json`): %d synthetic pairs x 2 "
+    L.append("Evaluation path (BASELINE configs[4], `profiles/%s_eval_bench.json`): %d synthetic pairs x 2 "
              "directions x %d keypoints -- flow mode %.0f pairs/s (%.1f us/pair), cam mode %.0f pairs/s (%.1f us/pair), PCK counters on "
              "the device.\n" % (tag, ev["pairs"], ev["keypoints"], ev["flow"]["pairs_per_s"], ev["flow"]["us_per_pair"],
                                  ev["cam"]["pairs_per_s"], ev["cam"]["us_per_pair"]))

@@ -49,7 +49,7 @@ finally:
     info = int(where & 0xffffff) if where != 2 ** 64 - 1 else None
     if info is not None:
         sys.stderr.write("bench_trap: first raster-backward offender: launch with N %s 32, mesh-of-launch %d, face %d\n"
-                         % (">" if info >> 20 else "<=", (info >> 13) & 127, info & 0x1fff))
+                         % (">" if info >> 23 else "<=", (info >> 16) & 127, info & 0xffff))
     bad_terms = [(s, k) for s, r in ring for k, v in r.get("terms", {}).items() if not math.isfinite(float(v))]
     first_bad = min([s for s, _ in bad_terms], default=None)
     sys.stderr.write("bench_trap: earliest non-finite report: site %d (0 = none) at device clock %d; steps seen %d; non-finite terms in the last steps: %s\n"

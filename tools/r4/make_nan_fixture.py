@@ -18,7 +18,7 @@ thr = float(np.sqrt(np.float32(math.log(1e10 - 1.) * 1e-5)))
 for c, fn in enumerate(sys.argv[1:]):
     d = torch.load(fn, weights_only=False)
     info = d["where"]
-    big, n, f = info >> 20, (info >> 13) & 127, info & 0x1fff
+    big, n, f = info >> 23, (info >> 16) & 127, info & 0xffff
     rec = dict(d["ring"])[d["first_bad_step"] - 1]
     fv, b = view_faces(d, rec, n, big)
     x, y = fv[:, 0::3], fv[:, 1::3]

@@ -46,7 +46,7 @@ def main():
     exact = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     thin = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     info = d["where"]
-    big, n, f = info >> 20, (info >> 13) & 127, info & 0x1fff
+    big, n, f = info >> 23, (info >> 16) & 127, info & 0xffff
     step = d["first_bad_step"] - 1
     rec = dict(d["ring"])[step]
     fv, b = view_faces(d, rec, n, big)

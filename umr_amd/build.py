@@ -16,8 +16,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
          "-munsafe-fp-atomics",   # native global_atomic_add_f32 instead of CAS loops
          "-ffp-contract=off",     # branch-deciding expressions round like the reference's float code
-         "-fno-slp-vectorize",    # no v_pk_{mul,add,fma}_f32 pairs: a packed op issues in ~5 cycles against 2 x 2.4 for the
-                                  # two scalar ops it replaces (tools/ubench), and the pairing costs extra moves (-2..11 %)
+         "-fno-slp-vectorize",    # no COMPILER-made v_pk_{mul,add,fma}_f32 pairs: on VGPR operands a packed op issues in 4.3-4.5
+                                  # cycles against 2 x 2.4 for the two scalar ops it replaces, and the pairing costs extra moves
+                                  # (-2..11 %).  The hand-written packed ops of raster_core.h are the other case: their operand
+                                  # is an SGPR PAIR of the face record, where the two scalar ops would cost 2 x 4.2
+                                  # (profiles/r04_valu_ubench2.log)
          "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 

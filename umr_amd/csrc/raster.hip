@@ -327,6 +327,10 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     const int blocks = N * A.tiles_x * A.tiles_y;
     const bool lds_ok = (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(TS) * sizeof(float) <= 48 * 1024;
     const bool face_major = !general && (alpha_only || !(g_bwd_pixel_major || !lds_ok));
+    // only the face-major kernels route the two gradients of UMR_BWD_ALPHA_GEOMETRY; the pixel-major pair (umr_debug_set
+    // "bwd_pixel_major", or TS beyond the LDS accumulators) would send the rgb gradient into grad_faces: rejected, nothing
+    // enqueued (soft_rasterize_cuda.cpp:122-129 raises on what it cannot do, it never returns other data)
+    if (alpha_geom && !face_major) return UMR_ERR_ARG;
     // Cost-ordered wave start (k_face_order).  Measured on MI355X, us per launch at N = 16 / 128 (F = 1280, IS = 512), index
     // order -> ordered in groups of 16 | 8 meshes: texel gradients only 137.6 -> 122.3 | 129.7 and 814 -> 838 | 798; vertex +
     // texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel: with 16 meshes' heavy

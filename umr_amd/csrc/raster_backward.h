@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                             }
                         } else if (fc.front() || A.double_side) {
                             const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
-                            const float ps = p.frag * __expf((zn - smax) * A.inv_gamma) * __builtin_amdgcn_rcpf(ssum);  // :608
+                            const float ps = p.frag * __expf(fminf((zn - smax) * A.inv_gamma, 0.f)) * __builtin_amdgcn_rcpf(ssum);  // :608 (clamp: raster_backward_fm.h)
                             tix = texel_index(q0, q1, A.R);
                             const float *tx = tex_n + ((size_t)f * TS + tix) * 3;
                             gt0 = ps * g0; gt1 = ps * g1; gt2 = ps * g2;

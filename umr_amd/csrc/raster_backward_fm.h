@@ -417,7 +417,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         }
                     } else if (two_sided || fc.front()) {
                         const float zn = div_r(c_far - zp, c_far - c_near, c_rr);
-                        const float ps = p.frag * __expf((zn - smax) * c_ig) * __builtin_amdgcn_rcpf(ssum);  // :608
+                        // (exponent clamped at 0: zn <= smax for every pair the forward included, so this changes no bit of a legitimate
+                        // pair; a pair only the backward's cull kept -- profiles/r04_nan_replay.md -- then weighs at most D / S
+                        // instead of exp(9300) = inf)
+                        const float ps = p.frag * __expf(fminf((zn - smax) * c_ig, 0.f)) * __builtin_amdgcn_rcpf(ssum);  // :608
                         const int tix = texel_index(q0, q1, A.R);
                         if (NEED_GT) {
                             if (TS == 1) { FM_ACC(gt0, ps, g0); FM_ACC(gt1, ps, g1); FM_ACC(gt2, ps, g2); }
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const float sv = wave_sum_full(gv[k]);
             if (lane == k) mine = sv;
         }
-        UMR_TRAP_AT(umr_bad(mine), 4 | (RGB == 2 ? 0x40 : (RGB == 0 ? 0x80 : 0)), ((unsigned)(A.N > 32) << 20) | ((unsigned)(n & 127) << 13) | (unsigned)f);
+        UMR_TRAP_AT(umr_bad(mine), 4 | (RGB == 2 ? 0x40 : (RGB == 0 ? 0x80 : 0)), ((unsigned)(A.N > 32) << 23) | ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
         if (live && lane < 9) A.grad_faces[((size_t)n * F + f) * 9 + lane] += mine;
     }
     if (NEED_GT) {
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     float acc = wave_tex[j];
 #pragma unroll
                     for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
-                    UMR_TRAP_AT(umr_bad(acc), 5 | (RGB == 0 ? 0x80 : 0), ((unsigned)(A.N > 32) << 20) | ((unsigned)(n & 127) << 13) | (unsigned)f);
+                    UMR_TRAP_AT(umr_bad(acc), 5 | (RGB == 0 ? 0x80 : 0), ((unsigned)(A.N > 32) << 23) | ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
                     dst[j] += acc;
                 }
             }

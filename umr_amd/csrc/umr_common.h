@@ -107,7 +107,7 @@ __device__ __forceinline__ void umr_trap(bool nonfinite, unsigned site) {
 }
 #define UMR_TRAP_IF(cond, site) umr_trap((cond), (site))
 // ... and WHERE: a second word, min over reports of (device clock << 24 | 24 bits the site packs -- the raster backward:
-// launch size class << 20 | mesh of the launch << 13 | face), so the offending (view, face) can be replayed on the CPU
+// launch size class (N > 32) << 23 | mesh of the launch (mod 128) << 16 | face (16 bits: the face-major path takes F <= 65535)), so the offending (view, face) can be replayed on the CPU
 static __device__ unsigned long long g_umr_trap_info = ~0ull;
 __device__ __forceinline__ void umr_trap_at(bool nonfinite, unsigned site, unsigned info) {
     if (nonfinite) {

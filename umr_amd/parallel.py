@@ -21,10 +21,23 @@ def init_distributed(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # several ranks cannot agree on a free port by themselves, and a fixed default collides as soon as two jobs share
+            # a node: the launcher has to name it (torchrun does; `python bench.py --gpus N` picks a free one: free_port())
+            raise RuntimeError("init_distributed: WORLD_SIZE=%d but no MASTER_PORT in the environment; start the ranks with "
+                               "torchrun / torch.distributed.run, or export MASTER_PORT=<umr_amd.parallel.free_port()> for all "
+                               "of them" % world)
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def free_port(host="127.0.0.1"):
+    """A TCP port that is free right now on `host` -- for the launcher of a single-node job (bench.py's self-launch, tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind((host, 0))
+        return s.getsockname()[1]
 
 
 def wrap_ddp(module, device, world):
