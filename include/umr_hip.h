@@ -106,6 +106,20 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * nnutils/loss_utils.py:303-306) is folded into indexing.  umr_raster_backward takes the same field in bits 8-23 of
  * `grad_is_pooled`; grad_textures stays PER VIEW [N,F,TS,3] (the caller sums the G views, as autograd does for repeat). */
 #define UMR_RASTER_TEX_GROUP(G) (((G) & 0xffff) << 8)
+/* flags bit 3: packed saved state (soft-max colour with UMR's modes; needs pooled_out, a by-value `background` and an image size
+ * that is a multiple of 8).  For a render whose caller consumes the POOLED image and whose backward is the one-pass
+ * UMR_BWD_ALPHA_GEOMETRY | UMR_BWD_PACKED_STATE call: `aggrs_info` is then a buffer of umr_raster_state_bytes(N, image_size)
+ * bytes that receives the render's saved state in the backward's own layout -- per mesh (IS/4)^2 records of 64 floats, one per
+ * 4x4 pixel tile (row-major over tiles; pixel (x, y) of a tile at i = 4 y + x): [0,16) v_rcp_f32 of the soft-max sum (:608 uses
+ * the sum only through its reciprocal), [16,32) soft-max maximum, [32,48) alpha, [48,52) per 2x2 quad the smallest maximum (NaN if
+ * one of its pixels holds NaN), [52,56) per quad 1.0f iff all four alphas are exactly 1.0f, [56,64) unused -- and NOTHING is
+ * written at full resolution besides it: soft_colors is not touched (may be NULL).  Same arithmetic, same pooled image, same
+ * p2f as the planar call; the forward writes 20 B per pixel instead of 28 (+ 4 | 8 for visibility), the backward's waves read
+ * whole 256-byte records instead of 8-byte pieces of 6 - 8 rows of three planes. */
+#define UMR_RASTER_PACKED_STATE 8
+/* flags bit 4 (umr_raster_forward_vis): `visibility` is [N,IS,IS], the face-id plane alone -- TexCycle reads nothing else
+ * (nnutils/loss_utils.py:327-328, train_s1.py:223-224). */
+#define UMR_RASTER_VIS_IDS_ONLY 16
 /* umr_raster_backward `grad_is_pooled` is a bit field: */
 #define UMR_BWD_GRAD_POOLED 1   /* gradient arrives at the 2x2-pooled resolution */
 #define UMR_BWD_ALPHA_ONLY 2    /* soft_colors and grad_soft_colors are alpha planes (see above); exact when the rgb
@@ -117,6 +131,9 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
                                    (pixel, face) pairs; needs need_grad_faces and need_grad_textures, func_id_rgb 1, and
                                    TS <= 1023 texels per face (the face-major kernels' LDS accumulators): anything else returns
                                    UMR_ERR_ARG with nothing enqueued -- the flag is never silently dropped */
+#define UMR_BWD_PACKED_STATE 8   /* with UMR_BWD_ALPHA_GEOMETRY: `aggrs_info` is the packed saved state a UMR_RASTER_PACKED_STATE
+                                   forward wrote (see there); soft_colors is not read (may be NULL).  Same gradients, bit for bit,
+                                   as the planar call on the same render */
 
 /* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins, the backward's
  * start order).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst
@@ -124,6 +141,8 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
  * per mesh up to 512^2: a quarter of it) -- a caller that knows the size it is about to render may allocate this instead. */
 size_t umr_raster_workspace_bytes(int N, int F);
 size_t umr_raster_workspace_bytes_for(int N, int F, int image_size);
+/* Bytes of the packed saved state of UMR_RASTER_PACKED_STATE (16 per pixel); 0 when image_size is not a multiple of 8. */
+size_t umr_raster_state_bytes(int N, int image_size);
 
 int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
                        const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,

@@ -50,6 +50,7 @@ struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct uint2 { unsigned x, y; };
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -57,6 +58,7 @@ struct dim3 {
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
 typedef int hipError_t;

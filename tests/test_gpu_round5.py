@@ -13,40 +13,52 @@ from tests.helpers import scene, assert_close_frac, t2n  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-UMR_BWD_GRAD_POOLED, UMR_BWD_ALPHA_GEOMETRY = 1, 4
+UMR_BWD_GRAD_POOLED, UMR_BWD_ALPHA_GEOMETRY, UMR_BWD_PACKED_STATE = 1, 4, 8
+UMR_RASTER_PACKED_STATE, UMR_RASTER_VIS_IDS_ONLY = 8, 16
 
 
-def _forward_cabi(fv, tex, IS, pooled, flags=0):
-    """umr_raster_forward with the reference's buffer contract (soft_colors pre-filled with (background, 1), the rest zeroed)."""
+def _forward_cabi(fv, tex, IS, pooled, flags=0, packed=False, vis=False):
+    """umr_raster_forward[_vis] with the reference's buffer contract (soft_colors pre-filled with (background, 1), the rest
+    zeroed).  packed: UMR_RASTER_PACKED_STATE -- `aggrs` is the packed saved state, soft_colors NULL, background by value."""
+    import ctypes
     from umr_amd import _lib
     from umr_amd.functional import standard_grid
     L, p = _lib.lib(), _lib.ptr
     N, F = fv.shape[:2]
     TS = tex.shape[2]
-    st = dict(faces_info=torch.zeros(N, F, 27, device=DEV), aggrs=torch.zeros(N, 2, IS, IS, device=DEV),
-              p2f_info=torch.zeros(N, F, 2, device=DEV), p2f_sum=torch.zeros(N, F, 2, device=DEV),
-              sc=torch.cat((torch.zeros(N, 3, IS, IS, device=DEV), torch.ones(N, 1, IS, IS, device=DEV)), 1).contiguous(),
-              pool=torch.empty(N, 4, IS // 2, IS // 2, device=DEV) if pooled else None)
+    st = dict(faces_info=torch.zeros(N, F, 27, device=DEV), p2f_info=torch.zeros(N, F, 2, device=DEV),
+              p2f_sum=torch.zeros(N, F, 2, device=DEV), pool=torch.empty(N, 4, IS // 2, IS // 2, device=DEV) if pooled else None)
+    if packed:
+        assert L.umr_raster_state_bytes(N, IS) == N * IS * IS * 16
+        st["aggrs"] = torch.full((N, IS * IS * 4), float("nan"), device=DEV)
+        st["sc"] = None
+        flags |= UMR_RASTER_PACKED_STATE | (UMR_RASTER_VIS_IDS_ONLY if vis else 0)
+    else:
+        st["aggrs"] = torch.zeros(N, 2, IS, IS, device=DEV)
+        st["sc"] = torch.cat((torch.zeros(N, 3, IS, IS, device=DEV), torch.ones(N, 1, IS, IS, device=DEV)), 1).contiguous()
+    st["vis"] = (torch.empty((N, IS, IS) if packed else (N, 2, IS, IS), device=DEV)) if vis else None
     wsb = L.umr_raster_workspace_bytes(N, F)
     st["ws"], st["wsb"] = torch.empty(wsb, dtype=torch.uint8, device=DEV), wsb
     st["scal"] = (1.0, 100.0, 1e-3, 1e-5, 2, float(math.log(1e10 - 1.)), 1e-4, 1, 2, 0, 1)
     grid = standard_grid(IS, torch.device(DEV))
-    rc = L.umr_raster_forward(p(fv), p(tex), p(st["faces_info"]), p(st["aggrs"]), p(grid), p(st["p2f_info"]), p(st["p2f_sum"]),
-                              p(st["sc"]), p(st["pool"]), N, F, TS, IS, *st["scal"], flags, None, p(st["ws"]), wsb,
-                              _lib.stream_ptr(torch.device(DEV)))
+    bg = (ctypes.c_float * 3)(0., 0., 0.) if packed else None
+    rc = L.umr_raster_forward_vis(p(fv), p(tex), p(st["faces_info"]), p(st["aggrs"]), p(grid), p(st["p2f_info"]), p(st["p2f_sum"]),
+                                  p(st["sc"]), p(st["pool"]), N, F, TS, IS, *st["scal"], flags, bg, p(st["ws"]), wsb,
+                                  _lib.stream_ptr(torch.device(DEV)), p(st["vis"]))
     assert rc == 0
     return st
 
 
-@pytest.mark.parametrize("pooled", [True, False])
-def test_alpha_geometry_backward_vs_oracle(oracle_built, pooled):
+@pytest.mark.parametrize("pooled,packed", [(True, False), (False, False), (True, True), (False, True)])
+def test_alpha_geometry_backward_vs_oracle(oracle_built, pooled, packed):
     """UMR_BWD_ALPHA_GEOMETRY -- the backward the timed step lives on -- against the ORACLE, directly, through the C ABI at
     BASELINE size (2 x 1280 faces x 512^2, TS 36).  The reference's backward (soft_rasterize_cuda_kernel.cu:480-656) is linear in
     the upstream gradient, so what the flag promises is two oracle calls:
         grad_faces    = backward with upstream (0, 0, 0, g_alpha)   (the alpha term alone reaches the geometry: the mask render's)
         grad_textures = backward with upstream (g_r, g_g, g_b, 0)   (the rgb term reaches the texels: the detached textured render's)
     every element, at the bounds of test_full_size_vs_oracle.  pooled: the gradient arrives at the 2x2-pooled resolution (the
-    step's form, `COMMON` kernel); else at full resolution (the general instantiation)."""
+    step's form, `COMMON` kernel); else at full resolution (the general instantiation).  packed: the render's saved state in
+    the packed form the training steps use (UMR_RASTER_PACKED_STATE / UMR_BWD_PACKED_STATE) instead of the reference's planes."""
     from oracle import softras, torch_ref
     from umr_amd import _lib
     L, p = _lib.lib(), _lib.ptr
@@ -71,16 +83,20 @@ def test_alpha_geometry_backward_vs_oracle(oracle_built, pooled):
     _, gt_ref = softras.raster_backward(*args, g_rgb.numpy(), IS, backend="port", n_threads=nt, **cfg)
 
     fvd, texd = fv.to(DEV).reshape(N, F, 9).contiguous(), tex.to(DEV)
-    st = _forward_cabi(fvd, texd, IS, pooled)
+    st = _forward_cabi(fvd, texd, IS, pooled or packed, packed=packed)
     gd = g.to(DEV)
     gf = torch.zeros(N, F, 9, device=DEV)
     gt = torch.zeros(N, F, TS, 3, device=DEV)
     rc = L.umr_raster_backward(p(fvd), p(texd), p(st["sc"]), p(st["faces_info"]), p(st["aggrs"]), p(gf), p(gt), p(gd),
-                               (UMR_BWD_GRAD_POOLED if pooled else 0) | UMR_BWD_ALPHA_GEOMETRY, 1, 1, N, F, TS, IS, *st["scal"],
-                               p(st["ws"]), st["wsb"], _lib.stream_ptr(torch.device(DEV)))
+                               (UMR_BWD_GRAD_POOLED if pooled else 0) | UMR_BWD_ALPHA_GEOMETRY | (UMR_BWD_PACKED_STATE if packed else 0),
+                               1, 1, N, F, TS, IS, *st["scal"], p(st["ws"]), st["wsb"], _lib.stream_ptr(torch.device(DEV)))
     assert rc == 0
     torch.cuda.synchronize()
-    assert_close_frac(t2n(st["sc"]), o["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="soft_colors")
+    if packed:      # the image leaves through the pooled output alone
+        ref_pool = torch.nn.functional.avg_pool2d(torch.from_numpy(o["soft_colors"]), 2, 2).numpy()
+        assert_close_frac(t2n(st["pool"]), ref_pool, atol=1e-4, frac=1.0, max_outlier=1e-5, name="pooled image")
+    else:
+        assert_close_frac(t2n(st["sc"]), o["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="soft_colors")
     sf = np.abs(gf_ref).max()
     assert sf > 0 and np.abs(gt_ref).max() > 0
     assert_close_frac(t2n(gf).reshape(gf_ref.shape), gf_ref, atol=1e-5 * sf, rtol=1e-4, frac=1.0, name="grad_faces (alpha term)")
@@ -121,3 +137,80 @@ def test_alpha_geometry_flag_is_refused_off_the_face_major_route():
     finally:
         _lib.debug_set("bwd_pixel_major", 0)
     assert run(1024) == (-1, 0.0, 0.0)          # 32 x 32 texels per face: beyond the one-pass kernel's budget
+
+
+@pytest.mark.parametrize("IS,subdiv,scale", [(128, 2, (0.6, 0.9)), (72, 1, (0.9, 1.3)), (256, 2, (1.6, 2.2))])
+def test_packed_state_equals_the_planar_state(IS, subdiv, scale):
+    """UMR_RASTER_PACKED_STATE / UMR_BWD_PACKED_STATE against the planar call on the same render, through the C ABI: the pooled
+    image and the visible-face ids are the same bits; the records hold the planes' values (maximum and alpha bit for bit, the
+    sum as its v_rcp_f32) and the quad summaries the backward's cull would compute from them; and both gradients of the one-pass
+    backward are the SAME BITS (same pairs visited in the same order with the same operands).  Shapes: power-of-two image;
+    a multiple of 8 that is not one (the general kernel instantiation); a mesh larger than the frame (clipped faces, tiles
+    with background only)."""
+    from umr_amd import _lib
+    from umr_amd import functional as UF
+    L, p = _lib.lib(), _lib.ptr
+    N = 3
+    verts, faces, cams, gen = scene(N, subdiv, seed=IS, scale=scale)
+    _, fv, _ = UF.ProjectFacesFunction.apply(verts.to(DEV), cams.to(DEV), faces.int().to(DEV), 5.0, -2.732, False)
+    F, TS = fv.shape[1], 36
+    fvd = fv.detach().reshape(N, F, 9).contiguous()
+    tex = torch.rand(N, F, TS, 3, generator=gen).to(DEV)
+    a = _forward_cabi(fvd, tex, IS, True, vis=True)
+    b = _forward_cabi(fvd, tex, IS, True, packed=True, vis=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a["pool"], b["pool"])
+    assert torch.equal(a["vis"][:, 1], b["vis"])
+    T = IS // 4
+    rec = b["aggrs"].view(N, T, T, 64)
+    tiles = lambda plane: plane.reshape(N, T, 4, T, 4).permute(0, 1, 3, 2, 4).reshape(N, T, T, 16)     # [N,IS,IS] -> per-tile 4y + x
+    ssum, smax, alpha = a["aggrs"][:, 0], a["aggrs"][:, 1], a["sc"][:, 3]
+    assert torch.equal(rec[..., 16:32], tiles(smax)) and torch.equal(rec[..., 32:48], tiles(alpha))
+    assert float((rec[..., 0:16] * tiles(ssum) - 1).abs().max()) <= 3e-7
+    quads = lambda plane: plane.reshape(N, T, 2, 2, T, 2, 2).permute(0, 1, 4, 2, 5, 3, 6).reshape(N, T, T, 4, 4)   # per tile, quad 2 qy + qx
+    assert torch.equal(rec[..., 48:52], quads(smax).amin(-1))
+    assert torch.equal(rec[..., 52:56], (quads(alpha) == 1).all(-1).float())
+    for pooled in (True, False):
+        g = torch.randn(N, 4, IS // 2 if pooled else IS, IS // 2 if pooled else IS, generator=gen).to(DEV)
+        out = []
+        for st, packed in ((a, False), (b, True)):
+            gf, gt = torch.zeros(N, F, 9, device=DEV), torch.zeros(N, F, TS, 3, device=DEV)
+            rc = L.umr_raster_backward(p(fvd), p(tex), p(st["sc"]), None, p(st["aggrs"]), p(gf), p(gt), p(g),
+                                       (UMR_BWD_GRAD_POOLED if pooled else 0) | UMR_BWD_ALPHA_GEOMETRY | (UMR_BWD_PACKED_STATE if packed else 0),
+                                       1, 1, N, F, TS, IS, *st["scal"], p(st["ws"]), st["wsb"], _lib.stream_ptr(torch.device(DEV)))
+            assert rc == 0
+            torch.cuda.synchronize()
+            out.append((gf, gt))
+        assert float(out[0][0].abs().max()) > 0 and float(out[0][1].abs().max()) > 0
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    # the flag pair is checked: packed state without the one-pass flag, or an image size that has no whole records
+    gf, gt = torch.zeros(N, F, 9, device=DEV), torch.zeros(N, F, TS, 3, device=DEV)
+    assert L.umr_raster_backward(p(fvd), p(tex), None, None, p(b["aggrs"]), p(gf), p(gt), p(g), UMR_BWD_PACKED_STATE, 1, 1, N, F, TS, IS,
+                                 *b["scal"], p(b["ws"]), b["wsb"], _lib.stream_ptr(torch.device(DEV))) == -1
+    assert L.umr_raster_state_bytes(N, 36) == 0
+
+
+def test_lean_shared_render_step_equals_the_planar_one():
+    """RenderCompareS1's shared render with lean_state (what the training steps run) against the same module with the planar
+    saved state: every term equal to the bit, every gradient too (vertex / camera / flow)."""
+    from umr_amd.synthetic import make_s1_inputs
+    from umr_amd.train_step import RenderCompareS1
+    from umr_amd import smr
+    dev = torch.device(DEV)
+    tv, faces, outputs, batch = make_s1_inputs(2, 64, 2, seed=7, device=dev)
+    res = []
+    for lean in (True, False):
+        rc = RenderCompareS1(tv.to(dev), faces.to(dev), 64, share_mask_render=True).to(dev)
+        if not lean:        # the planar route of the same operator
+            orig = rc.tex_renderer.forward
+            rc.tex_renderer.forward = lambda *a, **k: (lambda o: (o[0], o[1], o[2], o[3][:, 1]))(orig(*a, **dict(k, lean_state=False)))
+        leaves = [outputs[k].detach().clone().requires_grad_(True) for k in ("delta_v", "cam", "tex_flow")]
+        out = dict(outputs, delta_v=leaves[0], cam=leaves[1], tex_flow=leaves[2])
+        out["pred_vs"] = outputs["mean_shape"][None] + leaves[0]
+        total, terms = rc(out, batch)
+        total.backward()
+        res.append(({k: float(v.detach()) for k, v in terms.items()}, [l.grad.clone() for l in leaves]))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for x, y in zip(res[0][1], res[1][1]):
+        assert float(y.abs().max()) > 0
+        assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max())      # (p2f / IoU atomics: order not fixed)

@@ -38,7 +38,8 @@ GPU_TESTS = {
         "test_small_regularisers_and_masked_l1_vs_reference_goldens", "test_rotate_cam_vs_reference_golden",
         "test_keypoint_transfer_vs_reference_golden"],
     "test_gpu_zz_collapsed_edges": ["test_collapsed_edges_stay_finite_and_follow_the_reference"],
-    "test_gpu_round5": ["test_alpha_geometry_backward_vs_oracle", "test_alpha_geometry_flag_is_refused_off_the_face_major_route"],
+    "test_gpu_round5": ["test_alpha_geometry_backward_vs_oracle", "test_alpha_geometry_flag_is_refused_off_the_face_major_route",
+                        "test_packed_state_equals_the_planar_state", "test_lean_shared_render_step_equals_the_planar_one"],
 }
 
 

@@ -22,6 +22,7 @@ SIGNATURES = {
                              ctypes.POINTER(ctypes.c_double)], _I),
     "umr_raster_workspace_bytes": ([_I, _I], _Z),
     "umr_raster_workspace_bytes_for": ([_I, _I, _I], _Z),
+    "umr_raster_state_bytes": ([_I, _I], _Z),
     "umr_raster_forward": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I,
                             ctypes.POINTER(ctypes.c_float), _P, _Z, _P], _I),
     "umr_raster_forward_vis": ([_P] * 9 + [_I, _I, _I, _I, _F, _F, _F, _F, _I, _F, _F, _I, _I, _I, _I, _I,

@@ -178,6 +178,11 @@ size_t umr_raster_workspace_bytes_for(int N, int F, int image_size) {
 
 size_t umr_raster_workspace_bytes(int N, int F) { return umr_raster_workspace_bytes_for(N, F, 0); }
 
+size_t umr_raster_state_bytes(int N, int image_size) {   // the packed saved state: 16 B per pixel (RasterArgs::state)
+    if (N <= 0 || image_size <= 0 || (image_size & 7)) return 0;
+    return (size_t)N * image_size * image_size * (STATE_REC / 16) * sizeof(float);
+}
+
 int umr_raster_forward(const float *faces, const float *textures, float *faces_info, float *aggrs_info,
                        const float *grid, float *p2f_info, float *p2f_sum, float *soft_colors,
                        float *pooled_out, int N, int F, int TS, int image_size, float near_, float far_,
@@ -201,16 +206,23 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     int R = 0;
     const bool alpha_only = (flags & UMR_RASTER_ALPHA_ONLY) != 0;
     const bool ids_only = (flags & UMR_RASTER_FACE_ID_ONLY) != 0;
+    // packed saved state: `aggrs_info` is the tiled buffer of umr_raster_state_bytes(N, image_size) bytes, soft_colors is not
+    // written (may be NULL); the image leaves through pooled_out alone
+    const bool packed = (flags & UMR_RASTER_PACKED_STATE) != 0;
+    const bool vis_ids = (flags & UMR_RASTER_VIS_IDS_ONLY) != 0;
     const int tex_group = ((flags >> 8) & 0xffff) ? ((flags >> 8) & 0xffff) : 1;
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (alpha_only && ids_only) return UMR_ERR_ARG;
     if (ids_only && (func_id_rgb != 0 || !aggrs_info)) return UMR_ERR_ARG;
-    if (!faces || (!soft_colors && !ids_only) || !workspace) return UMR_ERR_ARG;
+    if (packed && (alpha_only || ids_only || func_id_rgb != 1 || !pooled_out || !background || !aggrs_info || (image_size & 7)))
+        return UMR_ERR_ARG;
+    if (vis_ids && !visibility) return UMR_ERR_ARG;
+    if (!faces || (!soft_colors && !ids_only && !packed) || !workspace) return UMR_ERR_ARG;
     if (!alpha_only && !ids_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (N <= 0 || F <= 0 || TS <= 0 || image_size <= 0) return UMR_ERR_ARG;
     bool general = false;
     if (!modes_ok(func_id_dist, func_id_rgb, func_id_alpha, texture_sample_type, TS, &R, &general)) return UMR_ERR_ARG;
-    if (general && (alpha_only || ids_only || pooled_out)) return UMR_ERR_ARG;   // fused variants exist for UMR's modes only
+    if (general && (alpha_only || ids_only || pooled_out || packed)) return UMR_ERR_ARG;   // fused variants exist for UMR's modes only
     if (visibility && (general || alpha_only || ids_only || func_id_rgb != 1)) return UMR_ERR_ARG;
     if (workspace_bytes < umr_raster_workspace_bytes_for(N, F, image_size)) return UMR_ERR_ARG;
     const int with_p2f = func_id_rgb == 1 && !alpha_only && !(flags & UMR_RASTER_NO_P2F);
@@ -222,8 +234,9 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     RasterArgs A = {};
     A.bbox = (const float4 *)workspace;
     A.rec = (const float *)((char *)workspace + ws_bbox_bytes(N, F));
-    A.textures = textures; A.grid = grid; A.aggrs = aggrs_info; A.p2f_info = p2f_info; A.p2f_sum = p2f_sum;
-    A.soft_colors = soft_colors; A.pooled = pooled_out; A.vis = visibility;
+    A.textures = textures; A.grid = grid; A.aggrs = packed ? nullptr : aggrs_info; A.p2f_info = p2f_info; A.p2f_sum = p2f_sum;
+    A.soft_colors = packed ? nullptr : soft_colors; A.pooled = pooled_out; A.vis = visibility;
+    A.state = packed ? aggrs_info : nullptr; A.vis_ids_only = vis_ids;
     A.N = N; A.F = F; A.IS = image_size; A.TS = TS; A.R = R;
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;
     A.threshold = dist_eps * sigma_val;  // :332
@@ -246,6 +259,10 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
         ProfScope ps(st, (alpha_only || ids_only) ? 2 : 0,
                      alpha_only ? (double)N * (4.0 * image_size * image_size + 36.0 * F)
                      : ids_only ? (double)N * (8.0 * image_size * image_size + 36.0 * F)
+                     // packed state: 16 B / pixel of state + the pooled image (4 planes at a quarter of the pixels = 4 B / pixel)
+                     // [+ the id plane]; the planar form: 24 IS^2 (SURVEY 8d's op boundary; its fused pool / visibility planes
+                     // are not counted there)
+                     : packed ? (double)N * ((20.0 + (visibility ? 4.0 : 0.0)) * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0))
                                 : (double)N * (24.0 * image_size * image_size + (double)F * (36.0 + 12.0 * TS + 16.0)));
         // p2f accumulation and face culling are compile-time: as run-time flags they cost SGPRs in every variant
         if (general) {
@@ -291,10 +308,12 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     // the rgb gradient reaches the texels only, the alpha gradient the geometry: the shared mask / texture render of
     // train_s1 / train_s2 (silhouette backward on the render's alpha plane + texel-only backward) in ONE pass over the pairs
     const bool alpha_geom = (grad_is_pooled & UMR_BWD_ALPHA_GEOMETRY) != 0;
+    const bool packed = (grad_is_pooled & UMR_BWD_PACKED_STATE) != 0;    // aggrs_info = the forward's packed saved state
     const int tex_group = ((grad_is_pooled >> 8) & 0xffff) ? ((grad_is_pooled >> 8) & 0xffff) : 1;
     grad_is_pooled &= UMR_BWD_GRAD_POOLED;
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
-    if (!faces || !soft_colors || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
+    if (!faces || (!soft_colors && !packed) || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
+    if (packed && (!alpha_geom || !aggrs_info || (image_size & 7))) return UMR_ERR_ARG;   // the one-pass kernel reads it, no other
     if (!alpha_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (alpha_only && (need_grad_textures || !need_grad_faces)) return UMR_ERR_ARG;
     if ((need_grad_faces && !grad_faces) || (need_grad_textures && !grad_textures)) return UMR_ERR_ARG;
@@ -310,7 +329,8 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     RasterArgs A = {};
     A.bbox = (const float4 *)workspace;
     A.rec = (const float *)((char *)workspace + ws_bbox_bytes(N, F));
-    A.textures = textures; A.aggrs = (float *)aggrs_info; A.soft_colors = (float *)soft_colors;
+    A.textures = textures; A.aggrs = packed ? nullptr : (float *)aggrs_info; A.soft_colors = packed ? nullptr : (float *)soft_colors;
+    A.state = packed ? (float *)aggrs_info : nullptr;
     A.grad_colors = grad_soft_colors; A.grad_faces = grad_faces; A.grad_textures = grad_textures;
     A.N = N; A.F = F; A.IS = image_size; A.TS = TS; A.R = R;
     A.near_ = near_; A.far_ = far_; A.eps = eps; A.sigma = sigma_val;

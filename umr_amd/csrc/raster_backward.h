@@ -300,6 +300,7 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
     }
 }
 #define FM_ALPHA_GEOM 0
+#define FM_PACKED 0
 #define FM_QUADS 0
 #define FM_KERNEL_NAME k_raster_backward_fm
 #include "raster_backward_fm.h"
@@ -321,6 +322,12 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #define FM_KERNEL_NAME k_raster_backward_fm_ag
 #include "raster_backward_fm.h"
 #undef FM_KERNEL_NAME
+#undef FM_PACKED
+#define FM_PACKED 1
+#define FM_KERNEL_NAME k_raster_backward_fm_agp
+#include "raster_backward_fm.h"
+#undef FM_KERNEL_NAME
+#undef FM_PACKED
 #undef FM_ALPHA_GEOM
 #undef FM_QUADS
 #ifndef FM_QUADS_MASK
@@ -353,7 +360,10 @@ void launch_backward_fm_ag(const RasterArgs &A, hipStream_t st) {
     const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
     const size_t lds = A.TS > 1 ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
     const bool common = A.grad_pooled && A.double_side && (A.IS & (A.IS - 1)) == 0;
-    if (common) UMR_LAUNCH((k_raster_backward_fm_ag<1, true, true, true>), blocks, FM_WAVES * 64, lds, st, A);
+    if (A.state) {    // packed saved state (UMR_BWD_PACKED_STATE)
+        if (common) UMR_LAUNCH((k_raster_backward_fm_agp<1, true, true, true>), blocks, FM_WAVES * 64, lds, st, A);
+        else UMR_LAUNCH((k_raster_backward_fm_agp<1, true, true, false>), blocks, FM_WAVES * 64, lds, st, A);
+    } else if (common) UMR_LAUNCH((k_raster_backward_fm_ag<1, true, true, true>), blocks, FM_WAVES * 64, lds, st, A);
     else UMR_LAUNCH((k_raster_backward_fm_ag<1, true, true, false>), blocks, FM_WAVES * 64, lds, st, A);
 }
 template <int RGB>

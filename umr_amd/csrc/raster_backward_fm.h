@@ -7,6 +7,8 @@
 //   FM_QUADS 1  k_raster_backward_fm_quads   2x2 quads through an LDS list, sixteen per visit (silhouette variant: -14 %)
 //   FM_QUADS 1, FM_ALPHA_GEOM 1  k_raster_backward_fm_ag   one pass for a render whose alpha gradient goes to the geometry and
 //               whose rgb gradient goes to the texels only (UMR_BWD_ALPHA_GEOMETRY)
+//   ... + FM_PACKED 1  k_raster_backward_fm_agp   the same reading the forward's PACKED saved state (RasterArgs::state: one
+//               256-byte record per 4x4 tile with per-quad cull summaries) instead of the planes (UMR_BWD_PACKED_STATE)
 // Why quads (tools/r4/visit_census.py: this source with counters on the emulator): of the lanes a 4x4 hand-out carries 66 % lie
 // inside the face's band; by 2x2 pieces it is 89 %.  Wave visits per mesh of the SURVEY 8d scene: silhouette 12 694 -> 8 878,
 // texel-only 14 266 -> 12 140, vertex + texel 17 520 -> 14 956.  Measured on MI355X (us, N = 16): silhouette (N = 32) 158 -> 136,
@@ -38,7 +40,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     // quad hand-out: the culling lanes refine their surviving 4x4 sub-tile into its four 2x2 quads (band test + saved-state test
     // per quad) and write one packed origin (qx | qy << 16, in quad units) per surviving quad at its rank; a visit hands 16 quads
     // to the 16 lane groups of 4
-    __shared__ unsigned s_quad[FM_WAVES][256 + 32];   // (+32: the prefetch of the visit after the last reads past the end)
+    constexpr bool PK = FM_PACKED != 0;               // packed saved state: a slot also carries the quad's byte offset in it
+    __shared__ unsigned s_quad[FM_WAVES][PK ? 1 : 256 + 32];   // (+32: the prefetch of the visit after the last reads past the end)
+    __shared__ uint2 s_quad2[FM_WAVES][PK ? 256 + 32 : 1];
     // silhouette variant on a power-of-two image: the slot holds the quad origin's pixel-centre coordinates (exact floats) and its
     // byte offsets into the full / pooled planes, as the 4x4 slots form does -- the visit adds its lane's place, no integer decode
     constexpr bool QSLOT16 = RGB == 2 && COMMON;
@@ -94,6 +98,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     const char *sc_n = (const char *)(A.soft_colors + (size_t)n * cplanes * npix);
     const char *ag_n = (const char *)(A.aggrs + (size_t)n * 2 * npix);
     const char *gc_n = (const char *)(A.grad_colors + (size_t)n * cplanes * (pooled ? (size_t)H2 * H2 : npix));
+#if FM_PACKED
+    const char *st_n = (const char *)(A.state + (size_t)n * npix * (STATE_REC / 16));   // 16 B of state per pixel
+    (void)ag_n; (void)sc_n;
+    const unsigned tpr = (unsigned)IS >> 2;                                            // tile records per row
+#endif
     float *wave_tex = s_tex + (size_t)wave * FM_TEXCOPY * FM_TEX_STRIDE(TS);
     // this lane's copy: horizontally and vertically adjacent pixels of a 4x4 / 8x8 tile get different copies
     float *my_tex = wave_tex + ((lane ^ (lane >> 2) ^ (lane >> 4)) & (FM_TEXCOPY - 1)) * FM_TEX_STRIDE(TS);
@@ -139,6 +148,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const int qsub = lane >> 2, qlx = lane & 1, qly = (lane >> 1) & 1;
             const float qlxf = (float)(2 * qlx) * inv_is, qlyf = (float)(2 * qly) * inv_is;
             const unsigned qlo_pn = (unsigned)(qly * IS + qlx) * 4u;
+#if FM_PACKED
+            const unsigned qlo_st = (unsigned)(qly * 4 + qlx) * 4u;      // this lane's place in its quad, in a tile record
+#endif
 #endif
 #ifdef FM_NO_CULL            // time-split experiment (-DFM_NO_CULL, HISTORY.md 4.2): per-face set-up and reductions only
             for (int tb = ntiles; tb < ntiles; tb += 64) {
@@ -196,6 +208,22 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     //  * texel gradients only, soft-max: even the face's nearest depth is >= 89 gamma behind the soft-max
                     //    maximum of every pixel -> p = D exp(<-89) / S = 0.0f (:608); hard mode: the face wins no pixel (:596).
                     // Inside the silhouette that removes most of the back-facing half of the mesh before any visit.
+#if FM_PACKED
+                    if (want) {   // (IS is a multiple of 8: no ragged sub-tile) the record's quad summaries decide, 32 B per candidate
+                        const unsigned to = (UMR_MUL24((unsigned)pr0 >> 2, tpr) + ((unsigned)px0 >> 2)) * (STATE_REC * 4u);
+                        const float4 mn4 = ld_u4(st_n, to + STATE_O_QMIN * 4u), op4 = ld_u4(st_n, to + STATE_O_QOPAQUE * 4u);
+                        const float zmin_c = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
+                        const float zq = (c_far - zmin_c) * c_rr;
+                        // a quad dies only when BOTH terms vanish: depth-dead (NaN maximum: compares false, visited) AND alpha == 1
+                        unsigned alive = 0;
+                        alive |= (!((zq - mn4.x) * c_ig < -89.f) || !(op4.x == 1.f)) ? 1u : 0u;
+                        alive |= (!((zq - mn4.y) * c_ig < -89.f) || !(op4.y == 1.f)) ? 2u : 0u;
+                        alive |= (!((zq - mn4.z) * c_ig < -89.f) || !(op4.z == 1.f)) ? 4u : 0u;
+                        alive |= (!((zq - mn4.w) * c_ig < -89.f) || !(op4.w == 1.f)) ? 8u : 0u;
+                        qm &= alive;
+                        want = qm != 0;
+                    }
+#else
                     if (FM_TW == 4 && FM_TH == 4 && (RGB == 2 || !NEED_GF || (AG && FM_QUADS)) && want && px0 + 3 < IS && pr0 + 3 < IS && (IS & 3) == 0) {
                         const char *plane = RGB == 2 ? sc_n : ag_n + pst;           // alpha | soft-max maximum (hard: face id)
                         const unsigned o0 = (unsigned)(pr0 * IS + px0) * 4u, rs = (unsigned)IS * 4u;
@@ -261,6 +289,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #endif
                     }
 #endif
+#endif
                 }
                 unsigned long long tm = __ballot(want);
                 visited |= tm != 0;
@@ -290,23 +319,37 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     } else {
                     // origin of a quad in PIXELS: x | row << 16 (both even: a lane ORs its place in the quad in)
                     const unsigned base = (unsigned)px0 | ((unsigned)pr0 << 16);
+#if FM_PACKED
+                    // ... and its byte offset in the mesh's packed state: quad (qx, qy) of a tile starts 8 qx + 32 qy bytes into a plane
+                    const unsigned to = (UMR_MUL24((unsigned)pr0 >> 2, tpr) + ((unsigned)px0 >> 2)) * (STATE_REC * 4u);
+                    if (qm & 1u) s_quad2[wave][pos++] = make_uint2(base, to);
+                    if (qm & 2u) s_quad2[wave][pos++] = make_uint2(base + 2u, to + 8u);
+                    if (qm & 4u) s_quad2[wave][pos++] = make_uint2(base + 0x20000u, to + 32u);
+                    if (qm & 8u) s_quad2[wave][pos++] = make_uint2(base + 0x20002u, to + 40u);
+#else
                     if (qm & 1u) s_quad[wave][pos++] = base;
                     if (qm & 2u) s_quad[wave][pos++] = base + 2u;
                     if (qm & 4u) s_quad[wave][pos++] = base + 0x20000u;
                     if (qm & 8u) s_quad[wave][pos++] = base + 0x20002u;
+#endif
                     }
                 }
                 UMR_WAVE_LDS_HANDOVER();
-                const unsigned *qslot = &s_quad[wave][qsub];
+                const unsigned *qslot = &s_quad[wave][PK ? 0 : qsub];
+                const uint2 *qslot2 = &s_quad2[wave][PK ? qsub : 0];
                 const float4 *qslot4 = &s_quad4[wave][QSLOT16 ? qsub : 0];
-                unsigned qe_next = QSLOT16 ? 0u : qslot[0];
+                unsigned qe_next = (QSLOT16 || PK) ? 0u : qslot[0];
+                uint2 q2_next = PK ? qslot2[0] : make_uint2(0u, 0u);
                 float4 q4_next = QSLOT16 ? qslot4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int v0 = 0; v0 < nq; v0 += 16) {
                     const int mine = v0 + qsub < nq ? 0 : -1;
-                    const unsigned qe = qe_next;
+                    const unsigned qe = PK ? q2_next.x : qe_next;
+                    const unsigned qst = q2_next.y;
                     const float4 q4 = q4_next;
                     if constexpr (QSLOT16) q4_next = qslot4[v0 + 16];
+                    else if constexpr (PK) q2_next = qslot2[v0 + 16];
                     else qe_next = qslot[v0 + 16];     // (past the last quad: stale or unwritten words of the array, never used)
+                    (void)qst;
 #else
                 while (tm) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
@@ -345,8 +388,13 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         if (!(pow2 && IS >= 4) && (xi >= IS || row >= IS)) continue;      // (a power-of-two image has no ragged sub-tile)
                         yp = ndc_coord_fast(IS - 1 - row, IS, inv_is, pow2);
                         xp = ndc_coord_fast(xi, IS, inv_is, pow2);
+#if FM_PACKED
+                        pn4 = qst + qlo_st;                                           // byte offset of the pixel in the packed state
+                        gp4 = pooled ? (unsigned)(UMR_MUL24(row >> 1, H2) + (xi >> 1)) * 4u : (unsigned)(UMR_MUL24(row, IS) + xi) * 4u;
+#else
                         pn4 = (unsigned)(UMR_MUL24(row, IS) + xi) * 4u;               // byte offset in a full plane (< 2^24 pixels a side)
                         gp4 = pooled ? (unsigned)(UMR_MUL24(row >> 1, H2) + (xi >> 1)) * 4u : pn4;
+#endif
                     }
 #else
                     const int row = (mine >> 16) * FM_TH + sl / FM_TW;
@@ -368,11 +416,19 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         } else {
                             dead = false;
                             if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
+#if FM_PACKED
+                                const float smx = ld_u(st_n, pn4 + STATE_O_MAX * 4u);
+#else
                                 const float smx = ld_u(ag_n, pn4 + pst);
+#endif
                                 const float zmin_f = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
                                                 : ((c_far - zmin_f) * c_rr - smx) * c_ig < -89.f;
+#if FM_PACKED
+                                dead = dead && ld_u(st_n, pn4 + STATE_O_ALPHA * 4u) == 1.f;
+#else
                                 if (AG) dead = dead && ld_u(sc_n, pn4 + 3 * pst) == 1.f;
+#endif
                             }
                         }
                         if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue;
@@ -402,9 +458,15 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                                 g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
                     const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
                     UMR_TRAP_IF(umr_bad(g0) | umr_bad(g1) | umr_bad(g2) | umr_bad(g3), 3);
+#if FM_PACKED
+                    const float rsum = ld_u(st_n, pn4), smax = ld_u(st_n, pn4 + STATE_O_MAX * 4u);   // (the sum's v_rcp_f32, taken by the forward)
+                    float c_xy = g3 * ((1.f - ld_u(st_n, pn4 + STATE_O_ALPHA * 4u)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+#else
                     const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
+                    const float rsum = __builtin_amdgcn_rcpf(ssum);
                     float c_xy = 0.f;
                     if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+#endif
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
                     if (zp < c_near || zp > c_far) continue;  // :592
@@ -420,7 +482,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         // (exponent clamped at 0: zn <= smax for every pair the forward included, so this changes no bit of a legitimate
                         // pair; a pair only the backward's cull kept -- profiles/r04_nan_replay.md -- then weighs at most D / S
                         // instead of exp(9300) = inf)
-                        const float ps = p.frag * __expf(fminf((zn - smax) * c_ig, 0.f)) * __builtin_amdgcn_rcpf(ssum);  // :608
+                        const float ps = p.frag * __expf(fminf((zn - smax) * c_ig, 0.f)) * rsum;  // :608
                         const int tix = texel_index(q0, q1, A.R);
                         if (NEED_GT) {
                             if (TS == 1) { FM_ACC(gt0, ps, g0); FM_ACC(gt1, ps, g1); FM_ACC(gt2, ps, g2); }

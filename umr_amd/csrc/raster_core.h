@@ -98,7 +98,23 @@ struct RasterArgs {
     int no_xcd_remap;   // A/B switch (umr_debug_set("xcd_remap", 0)): pixel-major work items in plain blockIdx order
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
+    // UMR_RASTER_PACKED_STATE / UMR_BWD_PACKED_STATE: the soft-max render's saved state as ONE tiled buffer instead of the planes
+    // soft_colors[:, 3] + aggrs_info -- per mesh (IS/4)^2 records of 64 floats (256 B), one per 4x4 pixel tile, row-major over
+    // tiles; in a record, pixel (x, y) of the tile sits at i = 4 y + x:
+    //   [0,16)  RN-free v_rcp_f32 of the soft-max sum  (the backward's only use of the sum is that reciprocal, :608)
+    //   [16,32) soft-max maximum          [32,48) alpha
+    //   [48,52) per 2x2 quad q = 2 (y / 2) + x / 2: smallest maximum of its four pixels (NaN if any of them is NaN)
+    //   [52,56) per quad: 1.0f when all four alphas are exactly 1.0f, else 0.0f          [56,64) unused
+    // What a backward wave touches of a face's neighbourhood is then whole records (a quad's state: 3 x 16 B of one record; a
+    // culling lane's sub-tile: 32 B) instead of 8-byte pieces of 6 - 8 rows of three planes.
+    float *state;
+    int vis_ids_only;   // k_raster_forward<.., VIS>: `vis` is [N,IS,IS], the face-id plane alone (UMR_RASTER_VIS_IDS_ONLY)
 };
+#define STATE_REC 64          // floats per 4x4-tile record of the packed state
+#define STATE_O_MAX 16
+#define STATE_O_ALPHA 32
+#define STATE_O_QMIN 48
+#define STATE_O_QOPAQUE 52
 
 // ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
 __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,

@@ -176,14 +176,36 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
     if (RGB == 0) { o0 = c0; o1 = c1; o2 = c2; }
     else { o0 = c0 / ssum; o1 = c1 / ssum; o2 = c2 / ssum; }
     UMR_TRAP_IF(t.valid && (umr_bad(o0) | umr_bad(o1) | umr_bad(o2) | umr_bad(ssum) | umr_bad(smax)), 2);
-    if (t.valid) {
+    if (RGB == 1 && A.state) {
+        // packed saved state (RasterArgs::state; IS is a multiple of 8 here, so every lane of the wave holds a pixel): nothing
+        // else is written at full resolution -- the caller consumes the pooled image, the backward this buffer
+        const int tpr = IS >> 2;
+        float *rec = A.state + (((size_t)t.n * tpr + (t.row >> 2)) * tpr + (t.xi >> 2)) * STATE_REC;
+        const int i = (t.row & 3) * 4 + (t.xi & 3);
+        rec[i] = __builtin_amdgcn_rcpf(ssum);
+        rec[STATE_O_MAX + i] = smax;
+        rec[STATE_O_ALPHA + i] = o3;
+        // quad summaries for the backward's culling lanes: the quad's lanes are this one, ^1 (x) and ^8 (y)
+        float mn = fminf(smax, __shfl_xor(smax, 1, 64)), sm = smax + __shfl_xor(smax, 1, 64);
+        mn = fminf(mn, __shfl_xor(mn, 8, 64)); sm += __shfl_xor(sm, 8, 64);
+        float op = o3 == 1.f ? 1.f : 0.f;
+        op = fminf(op, __shfl_xor(op, 1, 64)); op = fminf(op, __shfl_xor(op, 8, 64));
+        if (!(t.lane & 1) && !(t.lane & 8)) {
+            const int q = ((t.row & 3) >> 1) * 2 + ((t.xi & 3) >> 1);
+            rec[STATE_O_QMIN + q] = sm == sm ? mn : sm;     // fminf drops NaNs: a NaN anywhere in the quad keeps it visited
+            rec[STATE_O_QOPAQUE + q] = op;
+        }
+    } else if (t.valid) {
         float *sc = A.soft_colors + (size_t)t.n * 4 * npix + pn;
         if (RGB == 1 || face_min != -1 || A.bg_arg) { sc[0] = o0; sc[npix] = o1; sc[2 * npix] = o2; }
         sc[3 * npix] = o3;
         float *ag = A.aggrs + (size_t)t.n * 2 * npix + pn;
         ag[0] = RGB == 0 ? depth_min : ssum;
         ag[npix] = RGB == 0 ? (float)face_min : smax;
-        if (VIS) {
+    }
+    if (VIS && t.valid) {
+        if (A.vis_ids_only) A.vis[(size_t)t.n * npix + pn] = (float)face_min;
+        else {
             float *vg = A.vis + (size_t)t.n * 2 * npix + pn;
             vg[0] = depth_min;
             vg[npix] = (float)face_min;

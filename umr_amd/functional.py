@@ -78,13 +78,18 @@ class SoftRasterizeFunction:
                   alpha channel keeps its gradient to face_vertices: ONE render where the reference renders the same views
                   twice, for the mask and -- with detached vertices -- for the texture term (torch.ops.umr.
                   soft_rasterize_alpha_geometry)
+      lean_state: (with detach_rgb_geometry and pool) the caller consumes the pooled image, p2f and the visible-face ids ONLY:
+                  returns (image, p2f, None[, face ids [N,IS,IS]]) -- no aggrs_info, and of the visibility planes the id plane alone.
+                  The render then keeps its saved state as one packed buffer in the one-pass backward's layout and writes nothing
+                  else at full resolution (UMR_RASTER_PACKED_STATE); where that form does not apply (image size not a multiple
+                  of 8, > 1023 texels per face) the planar call runs and the same values come back
     """
 
     @staticmethod
     def apply(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
               fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
               gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-              pool=False, need_p2f=True, want_visibility=False, detach_rgb_geometry=False):
+              pool=False, need_p2f=True, want_visibility=False, detach_rgb_geometry=False, lean_state=False):
         from . import ops  # noqa: F401  (registers torch.ops.umr.*)
         _check_raster_shapes(face_vertices, textures)
         modes = ops.pack_modes(_FUNC_RGB[aggr_func_rgb], _FUNC_DIST[dist_func], _FUNC_ALPHA[aggr_func_alpha],
@@ -100,11 +105,21 @@ class SoftRasterizeFunction:
             raise RuntimeError("soft_rasterize: want_visibility needs aggr_func_rgb='softmax' with UMR's own modes")
         if detach_rgb_geometry and modes != 1:
             raise RuntimeError("soft_rasterize: detach_rgb_geometry needs aggr_func_rgb='softmax' with UMR's own modes")
-        op = torch.ops.umr.soft_rasterize_alpha_geometry if detach_rgb_geometry else torch.ops.umr.soft_rasterize
-        image, p2f, aggrs, _, vis = op(
-            face_vertices, textures, int(image_size), [float(c) for c in background_color], float(near), float(far),
-            bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), modes, bool(pool), bool(need_p2f),
-            bool(want_visibility))
+        args = (face_vertices, textures, int(image_size), [float(c) for c in background_color], float(near), float(far),
+                bool(fill_back), float(eps), float(sigma_val), float(dist_eps), float(gamma_val), modes, bool(pool), bool(need_p2f),
+                bool(want_visibility))
+        if lean_state:
+            if not (detach_rgb_geometry and pool):
+                raise RuntimeError("soft_rasterize: lean_state goes with detach_rgb_geometry and pool")
+            packed = ops.lean_state_ok(image_size, textures.shape[2], modes, pool)
+            image, p2f, _, _, vis = torch.ops.umr.soft_rasterize_alpha_geometry(*args, packed)
+            if want_visibility and not packed:
+                vis = vis[:, 1]
+            return (image, p2f, None, vis) if want_visibility else (image, p2f, None)
+        if detach_rgb_geometry:
+            image, p2f, aggrs, _, vis = torch.ops.umr.soft_rasterize_alpha_geometry(*args, False)
+        else:
+            image, p2f, aggrs, _, vis = torch.ops.umr.soft_rasterize(*args)
         return (image, p2f, aggrs, vis) if want_visibility else (image, p2f, aggrs)
 
 
@@ -153,7 +168,7 @@ def silhouette(face_vertices, image_size, near, far, fill_back, eps, sigma_val, 
 def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0, 0, 0], near=1, far=100,
                    fill_back=True, eps=1e-3, sigma_val=1e-5, dist_func='euclidean', dist_eps=1e-4,
                    gamma_val=1e-4, aggr_func_rgb='softmax', aggr_func_alpha='prod', texture_type='surface',
-                   pool=False, need_p2f=True, want_visibility=False, detach_rgb_geometry=False):
+                   pool=False, need_p2f=True, want_visibility=False, detach_rgb_geometry=False, lean_state=False):
     """Same signature and return as soft_renderer.functional.soft_rasterize
     (functional/soft_rasterize.py:111-125): (soft_colors [N,4,IS,IS], p2f_info [N,F,2], aggrs_info)."""
     if not _lib.on_device(face_vertices):
@@ -162,7 +177,7 @@ def soft_rasterize(face_vertices, textures, image_size=256, background_color=[0,
     return SoftRasterizeFunction.apply(face_vertices, textures, image_size, background_color, near, far,
                                        fill_back, eps, sigma_val, dist_func, dist_eps, gamma_val,
                                        aggr_func_rgb, aggr_func_alpha, texture_type, pool, need_p2f, want_visibility,
-                                       detach_rgb_geometry)
+                                       detach_rgb_geometry, lean_state)
 
 
 class ProjectFacesKernel:

@@ -213,7 +213,8 @@ class MultiTextureLoss(nn.Module):
         channels with the geometry detached, as the reference passes it (vs.detach(), cams.detach()), alpha channel with
         its gradient to vs and cams_all_hypo -- which makes it MultiMaskLoss's render (:265) as well (same meshes, same
         cameras, same rasterizer settings; alpha depends on neither textures nor lighting).  -> [B*K,4,H,H]"""
-        return self.renderer.forward(vs, fs, cams_all_hypo.view(-1, 7), tx, detach_rgb_geometry=True)[0]
+        return self.renderer.forward(vs, fs, cams_all_hypo.view(-1, 7), tx, detach_rgb_geometry=True,
+                                     lean_state=self.renderer.anti_aliasing)[0]
 
     def forward(self, vs, fs, cams_all_hypo, cam_probs, proj_cam, rgbs, masks_gt, masks_pred, tx, tex_flow,
                 dts_barrier, texture_rgba=None):

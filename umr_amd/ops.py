@@ -37,6 +37,8 @@ from . import _lib
 from ._lib import ptr
 
 BWD_ALPHA_GEOMETRY = 4      # UMR_BWD_ALPHA_GEOMETRY (include/umr_hip.h)
+BWD_PACKED_STATE = 8        # UMR_BWD_PACKED_STATE
+RASTER_PACKED_STATE, RASTER_VIS_IDS_ONLY = 8, 16   # UMR_RASTER_PACKED_STATE, UMR_RASTER_VIS_IDS_ONLY
 ONE_PASS_MAX_TS = 1023      # texels per face the face-major backward's LDS accumulators take (4 copies x (3 TS | 1) floats <= 48 KB)
 
 
@@ -62,9 +64,17 @@ def _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_v
             float(gamma_val), rgb, alpha, tex, 1 if fill_back else 0)
 
 
+def lean_state_ok(image_size, TS, modes, pool):
+    """Can the shared render keep its saved state packed (UMR_RASTER_PACKED_STATE)?  Needs the fused pool, an image size that is
+    a multiple of 8, UMR's own modes and a texel count the one-pass backward takes."""
+    return bool(pool) and int(image_size) % 8 == 0 and int(modes) == 1 and int(TS) <= ONE_PASS_MAX_TS
+
+
 def _raster_forward(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps,
-                    gamma_val, modes, pool, need_p2f, want_visibility):
-    """Body of umr::soft_rasterize and umr::soft_rasterize_alpha_geometry: one umr_raster_forward_vis call."""
+                    gamma_val, modes, pool, need_p2f, want_visibility, lean=False):
+    """Body of umr::soft_rasterize and umr::soft_rasterize_alpha_geometry: one umr_raster_forward_vis call.
+    lean (alpha_geometry only): the saved state is ONE packed buffer in the one-pass backward's layout, returned in the
+    aggrs_info slot; no full-resolution image or soft-max plane is written, and visibility is the id plane [N,IS,IS] alone."""
     from .functional import standard_grid
     L = _lib.lib()
     dev = face_vertices.device
@@ -78,9 +88,15 @@ def _raster_forward(face_vertices, textures, image_size, background, near, far, 
     TS, IS = tex.shape[2], int(image_size)
     # the reference fills 0.8 GB of buffers per N=128 call (functional/soft_rasterize.py:47-55); here the kernel takes the
     # background colour by value and writes every plane, so nothing is pre-filled
-    aggrs_info = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
+    if lean:
+        if not lean_state_ok(IS, TS, modes, pool):
+            raise RuntimeError("soft_rasterize_alpha_geometry(lean): needs pool, image_size %% 8 == 0, UMR's modes, TS <= %d" % ONE_PASS_MAX_TS)
+        aggrs_info = torch.empty(N, IS * IS * 4, device=dev, dtype=torch.float32)      # umr_raster_state_bytes(N, IS): 16 B / pixel
+        soft_colors = None
+    else:
+        aggrs_info = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
+        soft_colors = torch.empty(N, 4, IS, IS, device=dev, dtype=torch.float32)
     p2f_acc = torch.zeros(2, N, F, 2, device=dev, dtype=torch.float32)
-    soft_colors = torch.empty(N, 4, IS, IS, device=dev, dtype=torch.float32)
     bg = (ctypes.c_float * 3)(float(background[0]), float(background[1]), float(background[2]))
     pooled = torch.empty(N, 4, IS // 2, IS // 2, device=dev, dtype=torch.float32) if pool else None
     with_p2f = need_p2f and (modes & 0xf) == 1
@@ -89,12 +105,17 @@ def _raster_forward(face_vertices, textures, image_size, background, near, far, 
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
     # the hard render's (depth, face id) planes of the same faces, from the same visits (umr_raster_forward_vis)
-    vis = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32) if want_visibility else None
+    vis = (torch.empty((N, IS, IS) if lean else (N, 2, IS, IS), device=dev, dtype=torch.float32)) if want_visibility else None
+    flags = (0 if need_p2f else 1) | (G << 8)
+    if lean:
+        flags |= RASTER_PACKED_STATE | (RASTER_VIS_IDS_ONLY if want_visibility else 0)
     rc = L.umr_raster_forward_vis(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_acc[0]), ptr(p2f_acc[1]),
-                                  ptr(soft_colors), ptr(pooled), N, F, TS, *sc, (0 if need_p2f else 1) | (G << 8), bg, ptr(ws),
+                                  ptr(soft_colors), ptr(pooled), N, F, TS, *sc, flags, bg, ptr(ws),
                                   ws_bytes, _lib.stream_ptr(dev), ptr(vis))
     _lib.check(rc, "umr_raster_forward_vis")
     p2f = p2f_acc[0] / p2f_acc[1].clamp_min(1e-12)  # functional/soft_rasterize.py:73
+    if lean:
+        return pooled, p2f, aggrs_info, pooled.new_empty(0), (vis if want_visibility else pooled.new_empty(0))
     # custom-op outputs may not alias each other: without the fused pool the image IS the saved state, returned once more
     # as an empty placeholder in the 4th slot
     return ((pooled if pool else soft_colors), p2f, aggrs_info, (soft_colors if pool else soft_colors.new_empty(0)),
@@ -111,11 +132,13 @@ def soft_rasterize_op(face_vertices: torch.Tensor, textures: torch.Tensor, image
 
 
 def _raster_fake(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes,
-                 pool, need_p2f, want_visibility):
+                 pool, need_p2f, want_visibility, lean=False):
     N, F = face_vertices.shape[:2]
     IS = int(image_size)
     S = IS // 2 if pool else IS
     f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
+    if lean:
+        return (f(N, 4, S, S), f(N, F, 2), f(N, IS * IS * 4), f(0), (f(N, IS, IS) if want_visibility else f(0)))
     return (f(N, 4, S, S), f(N, F, 2), f(N, 2, IS, IS), (f(N, 4, IS, IS) if pool else f(0)),
             (f(N, 2, IS, IS) if want_visibility else f(0)))
 
@@ -259,12 +282,15 @@ silhouette_op.register_autograd(_sil_backward, setup_context=_sil_setup)
 @custom_op("umr::soft_rasterize_alpha_geometry", mutates_args=(), device_types="cuda")
 def soft_rasterize_alpha_geometry_op(face_vertices: torch.Tensor, textures: torch.Tensor, image_size: int, background: List[float],
                                      near: float, far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
-                                     gamma_val: float, modes: int, pool: bool, need_p2f: bool, want_visibility: bool
+                                     gamma_val: float, modes: int, pool: bool, need_p2f: bool, want_visibility: bool,
+                                     lean: bool = False
                                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """lean: for callers that consume the pooled image, p2f and the visible-face ids only (the training steps): outputs 3 - 5 are
+    then (packed saved state [N, 4 IS^2] -- opaque, the backward's input --, empty, face ids [N,IS,IS])."""
     if int(modes) != 1:
         raise RuntimeError("soft_rasterize_alpha_geometry: soft-max colour with UMR's own modes only")
     return _raster_forward(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps,
-                           gamma_val, modes, pool, need_p2f, want_visibility)
+                           gamma_val, modes, pool, need_p2f, want_visibility, lean)
 
 
 soft_rasterize_alpha_geometry_op.register_fake(_raster_fake)
@@ -274,7 +300,8 @@ soft_rasterize_alpha_geometry_op.register_fake(_raster_fake)
 def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textures: torch.Tensor, soft_colors: torch.Tensor,
                                               aggrs_info: torch.Tensor, grad_image: torch.Tensor, image_size: int, near: float,
                                               far: float, fill_back: bool, eps: float, sigma_val: float, dist_eps: float,
-                                              gamma_val: float, modes: int, pool: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+                                              gamma_val: float, modes: int, pool: bool, lean: bool = False
+                                              ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Both gradients of the shared render from ONE pass over its (pixel, face) pairs (UMR_BWD_ALPHA_GEOMETRY): what
     umr::silhouette_backward on the alpha plane and the texel-only umr::soft_rasterize_backward return."""
     L = _lib.lib()
@@ -292,9 +319,11 @@ def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textu
     ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
-    rc = L.umr_raster_backward(ptr(fv), ptr(tex), ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces), ptr(grad_textures), ptr(g),
-                               (1 if pool else 0) | BWD_ALPHA_GEOMETRY | (G << 8), 1, 1, N, F, TS, *sc, ptr(ws), ws_bytes,
-                               _lib.stream_ptr(dev))
+    # lean: aggrs_info is the forward's packed saved state, soft_colors an empty placeholder
+    rc = L.umr_raster_backward(ptr(fv), ptr(tex), None if lean else ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
+                               ptr(grad_textures), ptr(g),
+                               (1 if pool else 0) | BWD_ALPHA_GEOMETRY | (BWD_PACKED_STATE if lean else 0) | (G << 8), 1, 1, N, F, TS,
+                               *sc, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "umr_raster_backward(alpha geometry)")
     if G > 1:
         grad_textures = grad_textures.view(N // G, G, F, TS, 3).sum(1)   # autograd of the reference's repeat
@@ -303,8 +332,13 @@ def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textu
 
 @soft_rasterize_alpha_geometry_backward_op.register_fake
 def _(face_vertices, textures, soft_colors, aggrs_info, grad_image, image_size, near, far, fill_back, eps, sigma_val, dist_eps,
-      gamma_val, modes, pool):
+      gamma_val, modes, pool, lean=False):
     return (face_vertices.new_empty(face_vertices.shape, dtype=torch.float32), textures.new_empty(textures.shape, dtype=torch.float32))
+
+
+def _raster_ag_setup(ctx, inputs, output):
+    _raster_setup(ctx, inputs[:15], output)
+    ctx.lean = bool(inputs[15]) if len(inputs) > 15 else False
 
 
 def _raster_ag_backward(ctx, g_image, g_p2f, g_aggrs, g_saved, g_vis):
@@ -312,17 +346,24 @@ def _raster_ag_backward(ctx, g_image, g_p2f, g_aggrs, g_saved, g_vis):
     image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes, pool = ctx.cfg
     need_gf, need_gt = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     gf = gt = None
+    if ctx.lean:
+        # the packed state feeds the one-pass kernel only; a gradient nobody asked for is computed and dropped (the training
+        # steps ask for both)
+        if not (need_gf or need_gt):
+            return (None,) * 16
+        gf, gt = torch.ops.umr.soft_rasterize_alpha_geometry_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg, True)
+        return (gf if need_gf else None, gt if need_gt else None) + (None,) * 14
     # ONE pass for both gradients where the face-major kernels run: their per-wave LDS texel accumulators hold TS <= 1023 texels
     # (beyond that umr_raster_backward takes its pixel-major route, which library 0.5 does not specialise for this flag)
     if need_gf and need_gt and tex.shape[2] <= ONE_PASS_MAX_TS:
         gf, gt = torch.ops.umr.soft_rasterize_alpha_geometry_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg)
-        return (gf, gt) + (None,) * 13
+        return (gf, gt) + (None,) * 14
     if need_gf:      # alpha -> geometry: the mask render's backward on this render's alpha plane
         gf = torch.ops.umr.silhouette_backward(fv, soft_colors[:, 3].contiguous(), g_image[:, 3].contiguous(), image_size, near, far,
                                                fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
     if need_gt:      # rgb -> texels only
         _, gt = torch.ops.umr.soft_rasterize_backward(fv, tex, soft_colors, aggrs, g_image, *ctx.cfg, False, True)
-    return (gf, gt) + (None,) * 13
+    return (gf, gt) + (None,) * 14
 
 
-soft_rasterize_alpha_geometry_op.register_autograd(_raster_ag_backward, setup_context=_raster_setup)
+soft_rasterize_alpha_geometry_op.register_autograd(_raster_ag_backward, setup_context=_raster_ag_setup)

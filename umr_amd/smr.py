@@ -73,7 +73,7 @@ class SoftRenderer(torch.nn.Module):
         return UF.silhouette(face_out, size, self.near, self.far, True, self.eps, self.sigma_val,
                                            self.dist_eps, self.gamma_val, self.anti_aliasing)
 
-    def forward(self, vertices, faces, cams, textures=None, with_visibility=False, detach_rgb_geometry=False):
+    def forward(self, vertices, faces, cams, textures=None, with_visibility=False, detach_rgb_geometry=False, lean_state=False):
         """vertices [N,V,3] float, faces [N,F,3] integer, cams [N,7] = [s,tx,ty,qw,qx,qy,qz],
         textures None | [N,F,TS,3].
         K camera hypotheses per mesh without the reference's x K repeats (loss_utils.py:260-262, 303-306): pass
@@ -85,7 +85,9 @@ class SoftRenderer(torch.nn.Module):
         detach_rgb_geometry (soft-max renders with ambient-only lighting): gradients of imgs[:, 0:3] reach the textures only,
         as if vertices and cams had been passed detached, while imgs[:, 3] keeps its gradient to vertices and cams -- the mask
         render (train_s1.py:199, loss_utils.py:265) and the textured render of the same views with detached geometry (:217,
-        :313) as ONE render."""
+        :313) as ONE render.
+        lean_state (with detach_rgb_geometry and anti_aliasing): for callers that read imgs, p2f and the visible-face ids only --
+        `aggr` comes back None and the 4th value is the id plane [N,IS,IS] alone (UF.soft_rasterize lean_state)."""
         faces = faces.int().contiguous()                                  # smr.py:81
         N = cams.shape[0]
         if self.ids_only and self.render_type == 'hard':
@@ -134,4 +136,4 @@ class SoftRenderer(torch.nn.Module):
                                  self.eps, self.sigma_val, 'euclidean', self.dist_eps, self.gamma_val,
                                  self.render_type, 'prod', 'surface', pool=self.anti_aliasing,
                                  need_p2f=self.need_p2f, want_visibility=with_visibility,
-                                 detach_rgb_geometry=detach_rgb_geometry)
+                                 detach_rgb_geometry=detach_rgb_geometry, lean_state=lean_state)

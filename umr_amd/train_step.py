@@ -134,8 +134,11 @@ class RenderCompareS1(nn.Module):
         if self.share_mask_render:
             # ... and :199, the mask render of the same meshes and cameras again: its alpha channel, with the gradient to
             # vertices and camera the mask render has; the colour channels see the geometry detached as at :217
-            texture_rgba, p2f_info, _, aggr_info = self.tex_renderer(pred_vs, faces, proj_cam, tex, with_visibility=True,
-                                                                     detach_rgb_geometry=True)
+            # (lean_state: of this render the step reads the pooled image, p2f and the visible-face ids -- nothing else is written)
+            texture_rgba, p2f_info, _, aggr_ids = self.tex_renderer(pred_vs, faces, proj_cam, tex, with_visibility=True,
+                                                                    detach_rgb_geometry=True, lean_state=self.tex_renderer.anti_aliasing)
+            if not self.tex_renderer.anti_aliasing:
+                aggr_ids = aggr_ids[:, 1]
             mask_pred_seen = texture_rgba[:, 3]
             mask_pred_unseen = self.dis_renderer.silhouettes(pred_vs, faces, random_cams)
         else:
@@ -144,6 +147,7 @@ class RenderCompareS1(nn.Module):
             mask_pred_seen, mask_pred_unseen = both[:, 0], both[:, 1]
             texture_rgba, p2f_info, _, aggr_info = self.tex_renderer(pred_vs.detach(), faces, proj_cam.detach(), tex,
                                                                      with_visibility=True)
+            aggr_ids = aggr_info[:, 1]
         terms["mask"] = loss_utils.neg_iou_loss(mask_pred_seen, masks)
         terms["triangle"] = self.laplacian_loss_fn(pred_vs).mean()
         terms["flatten"] = self.flatten_loss_fn(pred_vs).mean()
@@ -152,7 +156,7 @@ class RenderCompareS1(nn.Module):
         texture_pred = texture_rgba[:, 0:3]
         terms["tex"] = self.texture_loss(texture_pred, imgs, masks, mask_pred_seen)
         terms["tex_dt"] = loss_utils.texture_dt_loss(tex_flow, dts)
-        aggr_ids = aggr_info[:, 1].reshape(bs, -1)
+        aggr_ids = aggr_ids.reshape(bs, -1)
         tex_cycle, _ = self.texture_cycle_fn(tex_flow, p2f_info.detach(), aggr_ids.detach())
         terms["tex_cycle"] = tex_cycle
         # adversarial term on the unseen view (:232-245)
