@@ -59,10 +59,17 @@ def parse():
                     help="1: the mask render is the alpha channel of the textured render of the same views (one render where the "
                          "reference makes two); 0: both renders, for A/B")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
-    ap.add_argument("--graph", type=int, default=0,
+    ap.add_argument("--graph", type=int, default=-1,
                     help="capture the step in ONE HIP graph and time graph replays instead of eager launches: with --model 0 the "
-                         "render-and-compare step (every raster / loss kernel, forward and backward), otherwise (train_s1, 1 GPU) "
-                         "the whole training step incl. MeshNet, backward and Adam")
+                         "render-and-compare step (every raster / loss kernel, forward and backward), otherwise (1 GPU) "
+                         "the whole training step incl. MeshNet, backward and Adam.  Default (-1): on for --gpus 1 -- the eager "
+                         "step's wall time is its Python / dispatcher enqueue time (config.eager_host_enqueue_ms_per_step), which "
+                         "depends on the box's host more than on the GPU; falls back to the eager step if the capture fails.  "
+                         "N > 1 runs eager (DDP's bucketed all-reduce is driven from autograd hooks)")
+    ap.add_argument("--hot-path-sub", type=int, default=-1,
+                    help="1: also time the render-and-compare step alone (the --model 0 --graph 1 measurement) in this process and "
+                         "attach it as config.hot_path_images_per_s / hot_path_ms_per_step; default: on for the --gpus 1 train_s1 "
+                         "line with the network")
     return ap.parse_args()
 
 
@@ -111,7 +118,7 @@ def cpu_baseline(args, n_images):
                       "side" % (n_images, dt)}
 
 
-def fixed_scene_kernel_times(dev, iters=20):
+def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9)):
     """The four raster launches of one train_s1 step (bs 16) on a FIXED synthetic scene -- SURVEY.md 8d's: 1280-face icospheres with
     0.05 vertex noise, camera scale U(0.6, 0.9), translation U(-0.1, 0.1), random rotation, seed 0 -- timed with the library's HIP
     events: the per-kernel figures of `roofline` come from the live training state (meshes of steps 41-45 of THIS run's
@@ -125,7 +132,7 @@ def fixed_scene_kernel_times(dev, iters=20):
     verts = torch.from_numpy(v).float()[None].repeat(2 * N, 1, 1)
     verts = verts + 0.05 * torch.randn(verts.shape, generator=g)
     faces = torch.from_numpy(f).long()[None].repeat(2 * N, 1, 1)
-    sc_ = 0.6 + 0.3 * torch.rand(2 * N, 1, generator=g)          # (drawn in the order of tests/helpers.py:scene -- the geometry
+    sc_ = scale[0] + (scale[1] - scale[0]) * torch.rand(2 * N, 1, generator=g)   # (drawn in the order of tests/helpers.py:scene -- the geometry
     tr_ = -0.1 + 0.2 * torch.rand(2 * N, 2, generator=g)         # tools/r4/step_kernels.py times)
     q = torch.randn(2 * N, 4, generator=g)
     cams = torch.cat([sc_, tr_, q / q.norm(dim=1, keepdim=True)], 1)
@@ -153,20 +160,123 @@ def fixed_scene_kernel_times(dev, iters=20):
         ms, n, _ = _lib.profile_collect(k)
         out[name] = round(1e3 * ms / max(n, 1), 1)
     # the shared mask / texture render of the same 16 views: its ONE backward pass (alpha gradient -> vertices, rgb -> texels),
-    # which replaces a texel-gradient backward + a 16-view silhouette backward
+    # which replaces a texel-gradient backward + a 16-view silhouette backward -- with the saved state packed (lean_state: what
+    # the training steps run; its forward writes nothing else at full resolution) and with the reference's planes
     fv_sh = fv[:N].clone().requires_grad_(True)
-    for phase in range(2):
-        if phase:
-            _lib.profile_collect(1)
-        for _ in range(iters if phase else 2):
-            tex.grad = None; fv_sh.grad = None
-            UF.soft_rasterize(fv_sh, tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
-                              pool=True, need_p2f=True, want_visibility=True, detach_rgb_geometry=True)[0].backward(g_tex)
-        torch.cuda.synchronize()
-    ms, n, _ = _lib.profile_collect(1)
-    out["shared_render_backward_one_pass_N16"] = round(1e3 * ms / max(n, 1), 1)
+    for lean, tag in ((True, ""), (False, "_planar_state")):
+        for phase in range(2):
+            if phase:
+                _lib.profile_collect(0); _lib.profile_collect(1)
+            for _ in range(iters if phase else 2):
+                tex.grad = None; fv_sh.grad = None
+                UF.soft_rasterize(fv_sh, tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
+                                  pool=True, need_p2f=True, want_visibility=True, detach_rgb_geometry=True, lean_state=lean)[0].backward(g_tex)
+            torch.cuda.synchronize()
+        ms, n, _ = _lib.profile_collect(1)
+        out["shared_render_backward_one_pass%s_N16" % tag] = round(1e3 * ms / max(n, 1), 1)
+        if lean:
+            ms, n, _ = _lib.profile_collect(0)
+            out["shared_render_forward_packed_state_N16"] = round(1e3 * ms / max(n, 1), 1)
     _lib.profile_enable(False)
     return out
+
+
+def build_hot_path_step(args, dev, world, tv, faces, outputs, batch):
+    """The render-and-compare step alone (--model 0): every raster / loss kernel of one train_s1 step, forward and backward, on
+    fixed network outputs.  -> (step_fn, check_replay | None); with args.graph (one GPU) step_fn replays ONE HIP graph of it and
+    check_replay(where) raises unless the graph still reproduces the eager step's total."""
+    from umr_amd.perceptual import PerceptualTextureLoss
+    from umr_amd.train_step import RenderCompareS1
+    rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size, texture_loss=PerceptualTextureLoss(dev),
+                         epoch=args.epoch, share_mask_render=bool(args.share_mask_render)).to(dev)
+    leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
+    last_terms = {}
+
+    def step_fn():
+        for l in leaves:
+            l.grad = None
+        outputs["pred_vs"] = outputs["mean_shape"][None] + outputs["delta_v"]
+        total, terms = rc(outputs, batch)
+        last_terms.update(terms)
+        total.backward()
+        if world > 1:   # hot-path-only mode has no parameters; exchange the (tiny) camera gradient sums
+            import torch.distributed as dist
+            dist.all_reduce(outputs["cam"].grad)
+        return total
+
+    if not (args.graph and world == 1):
+        return step_fn, None
+    # ~140 launches of a few microseconds each: eager, the step is host-enqueue bound.  Everything -- the first
+    # eager step (module caches, MIOpen solver search, the leaves' AccumulateGrad nodes), the warm-up and the
+    # capture -- runs on ONE side stream, so no node of the captured autograd pass is tied to the default stream;
+    # what the warm-up allocated is dropped before the capture; the graph is then replayed on the timing stream.
+    eager_step = step_fn
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        # fresh leaves created ON the side stream: a leaf's AccumulateGrad node is tied to the stream it was first
+        # used on, and make_s1_inputs already used delta_v on the default stream -- the engine would then hop to
+        # the default stream inside the capture (fork / join through events) for that leaf's accumulation
+        outputs["pred_vs"] = None
+        for k in ("delta_v", "cam", "tex_flow"):
+            outputs[k] = outputs[k].detach().clone().requires_grad_(True)
+        leaves[:] = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
+        eager_total = float(eager_step())
+        eager_terms = {k: float(v) for k, v in last_terms.items()}
+        for _ in range(3):
+            eager_step()
+        outputs["pred_vs"] = None
+        last_terms.clear()
+        for l in leaves:
+            l.grad = None
+        torch.cuda.synchronize()
+        hip_graph = torch.cuda.CUDAGraph()
+        # single-threaded autograd: forward and backward launches of the captured step come from one host thread
+        with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(hip_graph, stream=side):
+            static_total = eager_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    def check_replay(where):
+        torch.cuda.synchronize()
+        got = float(static_total)
+        if not abs(got - eager_total) <= 1e-4 * abs(eager_total):
+            raise SystemExit("HIP-graph replay (%s) does not reproduce the eager step: total %r vs %r, terms %r vs %r"
+                             % (where, got, eager_total, {k: float(v) for k, v in last_terms.items()}, eager_terms))
+
+    hip_graph.replay()
+    check_replay("first replay")
+
+    def replay_fn():
+        hip_graph.replay()
+        return static_total
+
+    replay_fn.eager = eager_step
+    return replay_fn, check_replay
+
+
+def hot_path_submeasure(args, dev, steps=40, warmup=5):
+    """config.hot_path_*: the render-and-compare step alone -- the part of the training step this library IS (every raster / loss
+    kernel, forward and backward; the network, the optimizer and their MIOpen kernels excluded) -- replayed from one HIP graph on
+    the same synthetic shard, timed like the headline (synchronise, K replays, synchronise).  The headline moves with MIOpen's
+    fp32 convolutions (most of the step's GPU time); this figure moves with the kernels of this repository."""
+    import copy
+    from umr_amd.synthetic import make_s1_inputs
+    a = copy.copy(args)
+    a.graph = 1
+    tv, faces, outputs, batch = make_s1_inputs(args.batch, args.image_size, args.subdivide, seed=100, device=dev)
+    step, check = build_hot_path_step(a, dev, 1, tv, faces, outputs, batch)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    check("after the hot-path replays")
+    return {"hot_path_images_per_s": args.batch * steps / dt, "hot_path_ms_per_step": 1e3 * dt / steps, "hot_path_steps": steps,
+            "hot_path_scope": "render-and-compare step (all raster + loss kernels, fwd + bwd) from one HIP graph; network / Adam excluded"}
 
 
 def main(device=None, backend="nccl"):
@@ -233,84 +343,25 @@ def main(device=None, backend="nccl"):
         from umr_amd.model import build_training_step
         return build_training_step(tv, faces, args, dev, 2 if args.force_ddp else world)
 
+    if args.graph < 0:          # default: graph replay on one GPU (device runs only: the CPU suite's emulator has no graphs)
+        args.graph = 1 if (world == 1 and dev.type == "cuda" and not args.force_ddp) else 0
     step_fn = None
+    check_replay = None
     if args.workload == "s2":
         use_model = True
     if use_model:
         step_fn = build_step()
     else:
-        from umr_amd.perceptual import PerceptualTextureLoss
-        rc = RenderCompareS1(tv.to(dev), faces.to(dev), args.image_size, texture_loss=PerceptualTextureLoss(dev),
-                             epoch=args.epoch, share_mask_render=bool(args.share_mask_render)).to(dev)
-        leaves = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
-
-        last_terms = {}
-
-        def step_fn():
-            for l in leaves:
-                l.grad = None
-            outputs["pred_vs"] = outputs["mean_shape"][None] + outputs["delta_v"]
-            total, terms = rc(outputs, batch)
-            last_terms.update(terms)
-            total.backward()
-            if world > 1:   # hot-path-only mode has no parameters; exchange the (tiny) camera gradient sums
-                import torch.distributed as dist
-                dist.all_reduce(outputs["cam"].grad)
-            return total
-
-        if args.graph and world == 1:
-            # ~140 launches of a few microseconds each: eager, the step is host-enqueue bound.  Everything -- the first
-            # eager step (module caches, MIOpen solver search, the leaves' AccumulateGrad nodes), the warm-up and the
-            # capture -- runs on ONE side stream, so no node of the captured autograd pass is tied to the default stream;
-            # what the warm-up allocated is dropped before the capture; the graph is then replayed on the timing stream.
-            eager_step = step_fn
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                # fresh leaves created ON the side stream: a leaf's AccumulateGrad node is tied to the stream it was first
-                # used on, and make_s1_inputs already used delta_v on the default stream -- the engine would then hop to
-                # the default stream inside the capture (fork / join through events) for that leaf's accumulation
-                outputs["pred_vs"] = None
-                for k in ("delta_v", "cam", "tex_flow"):
-                    outputs[k] = outputs[k].detach().clone().requires_grad_(True)
-                leaves[:] = [outputs["delta_v"], outputs["cam"], outputs["tex_flow"]]
-                eager_total = float(eager_step())
-                eager_terms = {k: float(v) for k, v in last_terms.items()}
-                for _ in range(3):
-                    eager_step()
-                outputs["pred_vs"] = None
-                last_terms.clear()
-                for l in leaves:
-                    l.grad = None
-                torch.cuda.synchronize()
-                hip_graph = torch.cuda.CUDAGraph()
-                # single-threaded autograd: forward and backward launches of the captured step come from one host thread
-                with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(hip_graph, stream=side):
-                    static_total = eager_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-
-            def check_replay(where):
-                torch.cuda.synchronize()
-                got = float(static_total)
-                if not abs(got - eager_total) <= 1e-4 * abs(eager_total):
-                    raise SystemExit("HIP-graph replay (%s) does not reproduce the eager step: total %r vs %r, terms %r vs %r"
-                                     % (where, got, eager_total, {k: float(v) for k, v in last_terms.items()}, eager_terms))
-
-            hip_graph.replay()
-            check_replay("first replay")
-
-            def step_fn():
-                hip_graph.replay()
-                return static_total
+        step_fn, check_replay = build_hot_path_step(args, dev, world, tv, faces, outputs, batch)
 
     whole_graph = None
-    if args.graph and use_model and world == 1 and args.workload == "s1":
+    eager_host_ms = None
+    if args.graph and use_model and world == 1:
         # The WHOLE training step -- distance transform, MeshNet forward, every raster / loss kernel, backward, fused Adam with its
         # on-device learning-rate schedule -- captured once into one HIP graph and replayed: the eager step's host enqueue time
-        # (config.host_enqueue_ms_per_step of the eager line) leaves the timed region.  Same recipe as the hot-path capture
-        # above: first eager steps (MIOpen solver search, caches), warm-up and capture on ONE side stream; gradients dropped
-        # before the capture so that they become graph-private allocations.
+        # (config.eager_host_enqueue_ms_per_step) leaves the timed region.  Same recipe as the hot-path capture
+        # (build_hot_path_step): first eager steps (MIOpen solver search, caches), warm-up and capture on ONE side stream;
+        # gradients dropped before the capture so that they become graph-private allocations.
         eager_step = step_fn
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -318,6 +369,11 @@ def main(device=None, backend="nccl"):
             with torch.cuda.stream(side):
                 for _ in range(max(3, args.warmup)):
                     eager_step()
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()            # what the eager step costs the HOST (enqueue only; drained afterwards)
+                for _ in range(5):
+                    eager_step()
+                eager_host_ms = 1e3 * (time.perf_counter() - t_e) / 5
                 torch.cuda.synchronize()
                 whole_graph = torch.cuda.CUDAGraph()
                 with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(whole_graph, stream=side):
@@ -337,6 +393,7 @@ def main(device=None, backend="nccl"):
             sys.stderr.write("bench.py: whole-step HIP-graph capture failed (%s: %s); timing the eager step\n" % (type(ex).__name__, ex))
             whole_graph = None
             torch.cuda.synchronize()
+            args.graph = 0
             step_fn = build_step()
 
     def barrier():
@@ -411,7 +468,8 @@ def main(device=None, backend="nccl"):
     _lib.profile_enable(True)
     for k in range(4):
         _lib.profile_collect(k)
-    prof_step = eager_step if whole_graph is not None else step_fn     # graph replays do not pass through the C ABI's event scope
+    # (graph replays do not pass through the C ABI's event scope: the eager form of the same step is profiled)
+    prof_step = eager_step if whole_graph is not None else getattr(step_fn, "eager", step_fn)
     for _ in range(max(1, args.profile_steps)):
         prof_step()
     barrier()
@@ -531,6 +589,9 @@ def main(device=None, backend="nccl"):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                         "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+                        # host time to enqueue ONE eager step (Python + dispatcher + ~1000 launches), measured before the capture:
+                        # what the timed region would be bound by without the graph
+                        "eager_host_enqueue_ms_per_step": eager_host_ms,
                         "final_loss": float(loss.detach()), "discarded_nonfinite_runs": discarded,
                         "hip_graph": bool((args.graph and not use_model and world == 1) or whole_graph is not None),
                         "hip_graph_scope": ("whole training step (network + losses + Adam)" if whole_graph is not None else
@@ -551,6 +612,16 @@ def main(device=None, backend="nccl"):
                          silhouette_forward=dict(kernel_line(2), valu=valu.get("silhouette_forward")),
                          silhouette_backward=dict(kernel_line(3), valu=valu.get("silhouette_backward"))),
     }
+    # the step's raster launches together: summed HIP-event time of the raster main kernels per step of the profile pass
+    n_prof = max(1, args.profile_steps)
+    out["roofline"]["raster_kernels_us_per_step"] = round(1e3 * sum(prof[k][0] for k in range(4)) / n_prof, 1)
+    out["roofline"]["raster_launches_per_step"] = round(sum(prof[k][1] for k in range(4)) / n_prof, 2)
+    want_sub = (world == 1 and use_model and args.workload == "s1" and dev.type == "cuda") if args.hot_path_sub < 0 else bool(args.hot_path_sub)
+    if want_sub:
+        try:
+            out["config"].update(hot_path_submeasure(args, dev))
+        except (Exception, SystemExit) as ex:     # noqa: BLE001 -- a sub-measurement: report, keep the headline
+            out["config"]["hot_path_error"] = "%s: %s" % (type(ex).__name__, ex)
     if dev.type == "cuda" and args.fixed_scene:
         out["roofline"]["fixed_scene_us"] = dict(fixed_scene_kernel_times(dev),
                                                  scene="SURVEY 8d: 16 (32) x 1280-face icospheres, IS 512, TS 36, seed 0 -- identical every run")

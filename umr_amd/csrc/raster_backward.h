@@ -302,6 +302,9 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #define FM_ALPHA_GEOM 0
 #define FM_PACKED 0
 #define FM_QUADS 0
+#ifndef FM_AG_VREC
+#define FM_AG_VREC 0
+#endif
 #define FM_KERNEL_NAME k_raster_backward_fm
 #include "raster_backward_fm.h"
 #undef FM_KERNEL_NAME
@@ -319,6 +322,14 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #undef FM_KERNEL_NAME
 #undef FM_ALPHA_GEOM
 #define FM_ALPHA_GEOM 1
+#ifndef FM_AG_WPE
+#define FM_AG_WPE 7       // waves / SIMD of the one-pass kernels (A/B: -DFM_AG_WPE=6 [-DFM_AG_VREC=1])
+#endif
+#ifndef FM_AG_VREC
+#define FM_AG_VREC 0      // 1: VGPR copies of the barycentric rows / corners in the one-pass kernels as well (spills at 7 waves)
+#endif
+#undef BWD_WPE
+#define BWD_WPE FM_AG_WPE
 #define FM_KERNEL_NAME k_raster_backward_fm_ag
 #include "raster_backward_fm.h"
 #undef FM_KERNEL_NAME
@@ -330,6 +341,8 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #undef FM_PACKED
 #undef FM_ALPHA_GEOM
 #undef FM_QUADS
+#undef BWD_WPE
+#define BWD_WPE 7
 #ifndef FM_QUADS_MASK
 #define FM_QUADS_MASK 1   // which variants take the quad hand-out: bit 0 silhouette, bit 1 texel-gradient-only, bit 2 vertex + texel
 #endif                    // (measured: header of raster_backward_fm.h)

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     if (live) {
         // VGPR-resident operands where the register budget of 7 waves / SIMD has room for them (silhouette and
         // texel-gradient-only variants; the full variant would spill)
-        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF);      // (the one-pass kernel: 21 VGPR spills with the copies)
+        constexpr bool VREC = FM_VREC != 0 && (RGB == 2 || !NEED_GF || (FM_ALPHA_GEOM != 0 && FM_AG_VREC != 0));   // (the one-pass kernel: 21 VGPR spills with the copies at 7 waves)
         typename std::conditional<VREC, FaceV, Face>::type fc;
         load_face(fc, A.rec + ((size_t)n * F + f) * REC);
         if constexpr (VREC) fc.fill();

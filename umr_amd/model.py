@@ -472,8 +472,12 @@ def build_training_step_s2(args, dev, world):
                          discriminator=ddp_disc, tex_size=opts.tex_size,
                          num_sym_faces=net.texture_predictor.num_sym_faces,
                          share_mask_render=bool(getattr(args, "share_mask_render", 1))).to(dev)      # train_s2.py:154-161
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=opts.learning_rate,
-                           betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"))
+    # capturable (bench.py --graph 1): learning rate and step counter live on the device, as in build_training_step
+    capt = bool(getattr(args, "graph", 0)) and torch.device(dev).type == "cuda"
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad],
+                           lr=(torch.tensor(opts.learning_rate, device=dev) if capt else opts.learning_rate),
+                           betas=(opts.beta1, 0.999), fused=(torch.device(dev).type == "cuda"), capturable=capt)
+    it_dev = torch.zeros((), device=dev) if capt else None
     mean, std = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
     input_imgs = (batch["imgs"] - mean) / std
     state = dict(it=0)
@@ -482,7 +486,10 @@ def build_training_step_s2(args, dev, world):
 
     def step():
         for g in opt.param_groups:
-            g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)
+            if capt:
+                g['lr'].copy_(opts.learning_rate / (1 + it_dev * 5e-4))
+            else:
+                g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)
         opt.zero_grad(set_to_none=True)
         batch["dts_barrier"] = compute_dt_barrier(batch["masks"]).unsqueeze(1)        # train_s2.py:196
         out = ddp_net(input_imgs)
@@ -495,8 +502,11 @@ def build_training_step_s2(args, dev, world):
                                                       out["tex_flow"].detach().abs().max()])))
         total.backward()
         opt.step()
-        batch["random_imgs"] = (batch["imgs"] * batch["masks"].unsqueeze(1)).detach()  # :268
+        # :268 -- written IN PLACE: the next step (and the next replay of a captured step) reads this very buffer
+        torch.mul(batch["imgs"], batch["masks"].unsqueeze(1), out=batch["random_imgs"])
         state["it"] += 1
+        if capt:
+            it_dev.add_(1)
         return total.detach()
 
     step.model = model
