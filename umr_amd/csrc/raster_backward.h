@@ -305,6 +305,12 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #ifndef FM_AG_VREC
 #define FM_AG_VREC 0
 #endif
+#ifndef FM_AGP_SLOT16
+#define FM_AGP_SLOT16 1   // packed-state one-pass kernel (COMMON): 16-byte quad slots {x, y, state offset, gradient offset} as floats
+#endif
+#ifndef FM_DEAD_EAGER
+#define FM_DEAD_EAGER 1   // packed-state one-pass kernel: the visit's two dead-test words are loaded together
+#endif
 #define FM_KERNEL_NAME k_raster_backward_fm
 #include "raster_backward_fm.h"
 #undef FM_KERNEL_NAME
@@ -323,7 +329,8 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #undef FM_ALPHA_GEOM
 #define FM_ALPHA_GEOM 1
 #ifndef FM_AG_WPE
-#define FM_AG_WPE 7       // waves / SIMD of the one-pass kernels (A/B: -DFM_AG_WPE=6 [-DFM_AG_VREC=1])
+#define FM_AG_WPE 6       // waves / SIMD of the one-pass kernels: 6 leaves no VGPR spill and half the SGPR spills (planar state: 167.6 -> 158.6 us on the fixed
+                          // scene; packed state 142 either way -- its 6.2 KB of LDS per wave admit 25 waves per CU anyway); 5: 152, 8: 160
 #endif
 #ifndef FM_AG_VREC
 #define FM_AG_VREC 0      // 1: VGPR copies of the barycentric rows / corners in the one-pass kernels as well (spills at 7 waves)

@@ -41,11 +41,13 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
     // per quad) and write one packed origin (qx | qy << 16, in quad units) per surviving quad at its rank; a visit hands 16 quads
     // to the 16 lane groups of 4
     constexpr bool PK = FM_PACKED != 0;               // packed saved state: a slot also carries the quad's byte offset in it
-    __shared__ unsigned s_quad[FM_WAVES][PK ? 1 : 256 + 32];   // (+32: the prefetch of the visit after the last reads past the end)
-    __shared__ uint2 s_quad2[FM_WAVES][PK ? 256 + 32 : 1];
+    constexpr bool PK2 = PK && !(FM_AGP_SLOT16 != 0 && COMMON);   // ... as the second word of an 8-byte slot
+    __shared__ unsigned s_quad[FM_WAVES][(PK || (RGB == 2 && COMMON)) ? 1 : 256 + 32];   // (+32: the prefetch of the visit after the last reads past the end)
+    __shared__ uint2 s_quad2[FM_WAVES][PK2 ? 256 + 32 : 1];
     // silhouette variant on a power-of-two image: the slot holds the quad origin's pixel-centre coordinates (exact floats) and its
     // byte offsets into the full / pooled planes, as the 4x4 slots form does -- the visit adds its lane's place, no integer decode
-    constexpr bool QSLOT16 = RGB == 2 && COMMON;
+    // ... the packed-state one-pass kernel too (FM_AGP_SLOT16): .z is then the quad's byte offset in the packed state
+    constexpr bool QSLOT16 = (RGB == 2 || (FM_PACKED != 0 && FM_AGP_SLOT16 != 0)) && COMMON;
     __shared__ float4 s_quad4[FM_WAVES][QSLOT16 ? 256 + 32 : 1];
 #endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
@@ -310,8 +312,13 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     if constexpr (QSLOT16) {
                         const float x0 = ndc_coord_fast(px0, IS, inv_is, true), y0 = ndc_coord_fast(IS - 1 - pr0, IS, inv_is, true);
                         const float dq = 4.f * inv_is;                                        // two pixels
-                        const unsigned o_pn = (unsigned)(pr0 * IS + px0) * 4u, o_gp = (unsigned)((pr0 >> 1) * H2 + (px0 >> 1)) * 4u;
-                        const unsigned r_pn = 2u * (unsigned)IS * 4u, r_gp = (unsigned)H2 * 4u;      // two rows down / one pooled row down
+                        const unsigned o_gp = (unsigned)((pr0 >> 1) * H2 + (px0 >> 1)) * 4u, r_gp = (unsigned)H2 * 4u;   // (one pooled row down)
+#if FM_PACKED
+                        // packed state: the sub-tile IS one record; quad (qx, qy) starts 8 qx + 32 qy bytes into each of its planes
+                        const unsigned o_pn = (UMR_MUL24((unsigned)pr0 >> 2, tpr) + ((unsigned)px0 >> 2)) * (STATE_REC * 4u), r_pn = 32u;
+#else
+                        const unsigned o_pn = (unsigned)(pr0 * IS + px0) * 4u, r_pn = 2u * (unsigned)IS * 4u;             // two rows down
+#endif
                         if (qm & 1u) s_quad4[wave][pos++] = make_float4(x0, y0, __int_as_float((int)o_pn), __int_as_float((int)o_gp));
                         if (qm & 2u) s_quad4[wave][pos++] = make_float4(x0 + dq, y0, __int_as_float((int)(o_pn + 8u)), __int_as_float((int)(o_gp + 4u)));
                         if (qm & 4u) s_quad4[wave][pos++] = make_float4(x0, y0 - dq, __int_as_float((int)(o_pn + r_pn)), __int_as_float((int)(o_gp + r_gp)));
@@ -335,19 +342,19 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     }
                 }
                 UMR_WAVE_LDS_HANDOVER();
-                const unsigned *qslot = &s_quad[wave][PK ? 0 : qsub];
-                const uint2 *qslot2 = &s_quad2[wave][PK ? qsub : 0];
+                const unsigned *qslot = &s_quad[wave][(PK || QSLOT16) ? 0 : qsub];
+                const uint2 *qslot2 = &s_quad2[wave][PK2 ? qsub : 0];
                 const float4 *qslot4 = &s_quad4[wave][QSLOT16 ? qsub : 0];
                 unsigned qe_next = (QSLOT16 || PK) ? 0u : qslot[0];
-                uint2 q2_next = PK ? qslot2[0] : make_uint2(0u, 0u);
+                uint2 q2_next = PK2 ? qslot2[0] : make_uint2(0u, 0u);
                 float4 q4_next = QSLOT16 ? qslot4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int v0 = 0; v0 < nq; v0 += 16) {
                     const int mine = v0 + qsub < nq ? 0 : -1;
-                    const unsigned qe = PK ? q2_next.x : qe_next;
+                    const unsigned qe = PK2 ? q2_next.x : qe_next;
                     const unsigned qst = q2_next.y;
                     const float4 q4 = q4_next;
                     if constexpr (QSLOT16) q4_next = qslot4[v0 + 16];
-                    else if constexpr (PK) q2_next = qslot2[v0 + 16];
+                    else if constexpr (PK2) q2_next = qslot2[v0 + 16];
                     else qe_next = qslot[v0 + 16];     // (past the last quad: stale or unwritten words of the array, never used)
                     (void)qst;
 #else
@@ -381,7 +388,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     unsigned pn4, gp4;
                     if constexpr (QSLOT16) {
                         xp = q4.x + qlxf; yp = q4.y - qlyf;     // exact: small integers over a power of two
+#if FM_PACKED
+                        pn4 = (unsigned)__float_as_int(q4.z) + qlo_st;
+#else
                         pn4 = (unsigned)__float_as_int(q4.z) + qlo_pn;
+#endif
                         gp4 = (unsigned)__float_as_int(q4.w);   // (COMMON: the gradient arrives pooled -- the quad IS one pooled pixel)
                     } else {
                         const int xi = (int)(qe & 0xffffu) | qlx, row = (int)(qe >> 16) | qly;
@@ -418,20 +429,29 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                             if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
 #if FM_PACKED
                                 const float smx = ld_u(st_n, pn4 + STATE_O_MAX * 4u);
+#if FM_DEAD_EAGER
+                                const float sal = ld_u(st_n, pn4 + STATE_O_ALPHA * 4u);    // both words in flight before the first is tested
+#endif
 #else
                                 const float smx = ld_u(ag_n, pn4 + pst);
 #endif
                                 const float zmin_f = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
                                                 : ((c_far - zmin_f) * c_rr - smx) * c_ig < -89.f;
-#if FM_PACKED
+#if FM_PACKED && FM_DEAD_EAGER
+                                dead = dead & (sal == 1.f);
+#elif FM_PACKED
                                 dead = dead && ld_u(st_n, pn4 + STATE_O_ALPHA * 4u) == 1.f;
 #else
                                 if (AG) dead = dead && ld_u(sc_n, pn4 + 3 * pst) == 1.f;
 #endif
                             }
                         }
+#if FM_PACKED
+                        if (wave_all(dead)) continue;
+#else
                         if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue;
+#endif
                     }
                     Pair p;
                     if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis, A.amb_thr)) continue;
