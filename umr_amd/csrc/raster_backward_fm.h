@@ -420,6 +420,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
                     //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
                     //    is >= 89 gamma behind the pixel's soft-max maximum (hard mode: the face is not the winner).
+#if FM_PACKED
+                    float smx, sal;    // the pixel's saved maximum and alpha: read once, used by the dead test and by the terms
+#endif
                     {
                         bool dead;
                         if (RGB == 2) {
@@ -428,9 +431,9 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                             dead = false;
                             if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
 #if FM_PACKED
-                                const float smx = ld_u(st_n, pn4 + STATE_O_MAX * 4u);
+                                smx = ld_ui<STATE_O_MAX * 4u>(st_n, pn4);
 #if FM_DEAD_EAGER
-                                const float sal = ld_u(st_n, pn4 + STATE_O_ALPHA * 4u);    // both words in flight before the first is tested
+                                sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);    // both words in flight before the first is tested
 #endif
 #else
                                 const float smx = ld_u(ag_n, pn4 + pst);
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #if FM_PACKED && FM_DEAD_EAGER
                                 dead = dead & (sal == 1.f);
 #elif FM_PACKED
-                                dead = dead && ld_u(st_n, pn4 + STATE_O_ALPHA * 4u) == 1.f;
+                                sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);
+                                dead = dead & (sal == 1.f);
 #else
                                 if (AG) dead = dead && ld_u(sc_n, pn4 + 3 * pst) == 1.f;
 #endif
@@ -479,8 +483,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
                     UMR_TRAP_IF(umr_bad(g0) | umr_bad(g1) | umr_bad(g2) | umr_bad(g3), 3);
 #if FM_PACKED
-                    const float rsum = ld_u(st_n, pn4), smax = ld_u(st_n, pn4 + STATE_O_MAX * 4u);   // (the sum's v_rcp_f32, taken by the forward)
-                    float c_xy = g3 * ((1.f - ld_u(st_n, pn4 + STATE_O_ALPHA * 4u)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+                    const float rsum = ld_u(st_n, pn4), smax = smx;   // (rsum: the sum's v_rcp_f32, taken by the forward)
+                    float c_xy = g3 * ((1.f - sal) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
 #else
                     const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
                     const float rsum = __builtin_amdgcn_rcpf(ssum);

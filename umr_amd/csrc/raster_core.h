@@ -295,6 +295,11 @@ __device__ __forceinline__ float ld_u(const char *base, unsigned byte_off) {
 __device__ __forceinline__ float4 ld_u4(const char *base, unsigned byte_off) {
     return *(const float4 *)(base + byte_off);
 }
+// ... plus a compile-time displacement, added in the 64-bit address domain so that it becomes the instruction's immediate offset
+// (`pn4 + 64` in 32 bits may wrap as far as the compiler knows: it then spends a v_add_u32 per load)
+template <unsigned IMM> __device__ __forceinline__ float ld_ui(const char *base, unsigned byte_off) {
+    return *(const float *)(base + ((size_t)byte_off + IMM));
+}
 
 // Wave votes over the lanes that reach them (EXEC), straight on the lane mask: HIP's __all / __any take an int and cost a
 // select and a compare per vote.  The emulation build (tests/host_kernel) maps them to its subset vote.
@@ -562,9 +567,12 @@ __device__ __forceinline__ bool eval_pair(Pair &p, const FaceT &fc, float xp, fl
 // gamma = 1e-4: one ulp of zn moves a weight by ~7e-4, so this chain reproduces the reference's IEEE
 // divisions to the last bit (Markstein-corrected reciprocal multiplies; plain IEEE when z is degenerate).
 __device__ __forceinline__ float clip_depth(float &c0, float &c1, float &c2, const Pair &p, const Face &fc) {
-    c0 = fmaxf(fminf(p.w0, 1.f - 1e-5f), 1e-5f);
-    c1 = fmaxf(fminf(p.w1, 1.f - 1e-5f), 1e-5f);
-    c2 = fmaxf(fminf(p.w2, 1.f - 1e-5f), 1e-5f);
+    // clamp to [1e-5, 1 - 1e-5] (:56-57) as ONE v_med3_f32 each: fminf / fmaxf cost a canonicalising v_max_f32 x, x in front
+    // (three half-rate instructions per weight).  Same value for every non-NaN weight; a NaN weight never gets here (no region
+    // flag of a NaN is set: table entry 0, the pair is skipped; the visibility-only kernel tests 0 <= w <= 1 first)
+    c0 = fmed3_(p.w0, 1e-5f, 1.f - 1e-5f);
+    c1 = fmed3_(p.w1, 1e-5f, 1.f - 1e-5f);
+    c2 = fmed3_(p.w2, 1e-5f, 1.f - 1e-5f);
     const float s = fmaxf(c0 + c1 + c2, 1e-5f);
     if (fc.slow()) {
         c0 /= s; c1 /= s; c2 /= s;
