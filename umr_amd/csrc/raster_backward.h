@@ -277,10 +277,11 @@ __device__ __forceinline__ int dpp_i(int old, int v, const int ctrl_sel) {
 __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a, float b, float c, int lane) {
 #if FM_TEXMERGE >= 1
 #pragma unroll
-    for (int step = 0; step < (FM_TEXMERGE >= 2 ? 2 : 1); ++step) {
+    for (int step = 0; step < (FM_TEXMERGE >= 3 ? 3 : (FM_TEXMERGE >= 2 ? 2 : 1)); ++step) {
         // keeper = the lane of the pair with bit `step` clear.  The per-lane constants live in VGPRs (as 64-bit lane
         // masks they were SGPR spills, restored with v_readlane every visit); multiplying the partner's value by the
         // 0/1 weight lets the backend fuse the DPP read into one v_fmac_f32_dpp per channel.
+        // (step 2, FM_TEXMERGE 3: lane i takes lane i + 4 -- row_shl:4 -- the next quad of the hand-out)
         const bool keep = (lane & (1 << step)) == 0;
         const float keepf = keep ? 1.f : 0.f;
         const int dropm = keep ? 0 : -1;
@@ -293,7 +294,11 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
         tix |= same ? dropm : 0;                                // merged into the partner: nothing left to add
     }
 #endif
+#ifdef FM_NO_TEXACC      // time-split experiment: no LDS accumulation (results wrong)
+    if (tix == -12345) {
+#else
     if (tix >= 0) {
+#endif
         atomicAdd(&my_tex[tix * 3], a);
         atomicAdd(&my_tex[tix * 3 + 1], b);
         atomicAdd(&my_tex[tix * 3 + 2], c);

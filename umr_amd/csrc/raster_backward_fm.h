@@ -420,13 +420,14 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     //  * alpha term: a pixel with alpha == 1.0f exactly contributes g*(1-alpha)*finite = 0 (:584);
                     //  * colour term: p = D*exp((zn - max)/gamma)/S (:608) is 0.0f when even the face's nearest depth
                     //    is >= 89 gamma behind the pixel's soft-max maximum (hard mode: the face is not the winner).
-#if FM_PACKED
-                    float smx, sal;    // the pixel's saved maximum and alpha: read once, used by the dead test and by the terms
-#endif
+                    // the pixel's saved maximum and alpha: read once, used by the dead test and by the terms (the compiler does not
+                    // merge the two reads itself)
+                    float smx = 0.f, sal = 0.f;
                     {
                         bool dead;
                         if (RGB == 2) {
-                            dead = ld_u(sc_n, pn4) == 1.f;
+                            sal = ld_u(sc_n, pn4);
+                            dead = sal == 1.f;
                         } else {
                             dead = false;
                             if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                                 sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);    // both words in flight before the first is tested
 #endif
 #else
-                                const float smx = ld_u(ag_n, pn4 + pst);
+                                smx = ld_u(ag_n, pn4 + pst);
 #endif
                                 const float zmin_f = fminf(fminf(fc.template g<R_Z0>(), fc.template g<R_Z1>()), fc.template g<R_Z2>());
                                 dead = RGB == 0 ? (float)f != smx
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                                 sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);
                                 dead = dead & (sal == 1.f);
 #else
-                                if (AG) dead = dead && ld_u(sc_n, pn4 + 3 * pst) == 1.f;
+                                if (AG) { sal = ld_u(sc_n, pn4 + 3 * pst); dead = dead & (sal == 1.f); }
 #endif
                             }
                         }
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         }
                         const float ga = (pooled ? 0.25f : 1.f) * ld_u(gc_n, gp4);
                         UMR_TRAP_IF(umr_bad(ga), 3);
-                        const float oa = ld_u(sc_n, pn4);
+                        const float oa = sal;
                         float c_a = ga * ((1.f - oa) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));
                         c_a *= p.frag * (1.f - p.frag) * (-c_nis);
                         const float k2a = 2.f * p.sign * c_a;
@@ -486,10 +487,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     const float rsum = ld_u(st_n, pn4), smax = smx;   // (rsum: the sum's v_rcp_f32, taken by the forward)
                     float c_xy = g3 * ((1.f - sal) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
 #else
-                    const float ssum = ld_u(ag_n, pn4), smax = ld_u(ag_n, pn4 + pst);
+                    const float ssum = ld_u(ag_n, pn4), smax = (!NEED_GF || AG) ? smx : ld_u(ag_n, pn4 + pst);
                     const float rsum = __builtin_amdgcn_rcpf(ssum);
                     float c_xy = 0.f;
-                    if (NEED_GF) c_xy = g3 * ((1.f - ld_u(sc_n, pn4 + 3 * pst)) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
+                    if (NEED_GF) c_xy = g3 * ((1.f - (AG ? sal : ld_u(sc_n, pn4 + 3 * pst))) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
 #endif
                     float q0, q1, q2;
                     const float zp = clip_depth(q0, q1, q2, p, fc);
