@@ -470,7 +470,7 @@ def main(device=None, backend="nccl"):
         _lib.profile_collect(k)
     # (graph replays do not pass through the C ABI's event scope: the eager form of the same step is profiled)
     prof_step = eager_step if whole_graph is not None else getattr(step_fn, "eager", step_fn)
-    for _ in range(max(1, args.profile_steps)):
+    for _ in range(max(0, args.profile_steps)):
         prof_step()
     barrier()
     _lib.profile_enable(False)
@@ -604,7 +604,7 @@ def main(device=None, backend="nccl"):
         # `valu`: the resource that actually binds these kernels (HISTORY.md 4.6) -- issued wave64 VALU instructions per launch,
         # the share of their lanes that was active, and the issue rate against the fp32 vector peak (1228.9 G wave-instr/s),
         # from SQ PMC passes of this command on this build (profiles/traffic.json; absent when that file is stale).
-        "roofline": dict({"bound": "hbm", "kernel": ("k_raster_backward_fm_ag (shared render: d alpha -> vertices, d rgb -> texels)" if args.share_mask_render else
+        "roofline": dict({"bound": "hbm", "kernel": ("k_raster_backward_fm_agp (shared render, packed saved state: d alpha -> vertices, d rgb -> texels)" if args.share_mask_render else
                                      "k_raster_backward_fm (textured render, texel gradients only)"), "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_note, "valu": valu.get("backward")},
                          **kernel_line(1),

@@ -80,7 +80,8 @@ try:
     rep["build_id"] = _lib.build_id()          # bench.py attaches these figures only to the library they were measured on
 except Exception as ex:                        # noqa: BLE001
     rep["build_id"] = "unknown (%s)" % ex
-bw = [v for k, v in rep["kernels"].items() if "k_raster_backward_fm_ag<1" in k] or \
+bw = [v for k, v in rep["kernels"].items() if "k_raster_backward_fm_agp<1" in k] or \
+     [v for k, v in rep["kernels"].items() if "k_raster_backward_fm_ag<1" in k] or \
      [v for k, v in rep["kernels"].items() if "k_raster_backward_fm<1" in k]      # the step's dominant backward launch
 rep["raster_backward_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in bw) / max(1, sum(v["launches"] for v in bw)) if bw else None
 rep["workload"] = [16, 256, 3, model]

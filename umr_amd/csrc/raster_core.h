@@ -18,6 +18,9 @@
 #endif
 #define SB_SLOTS 256  // super-block slots per mesh in the workspace layout (<= 16 x 16 super-blocks of >= 64^2 pixels)
 #define SB_CAP 1024   // list capacity per slot (entries); a slot that more faces touch is scanned in full (superblock_list)
+#ifndef UMR_EDGE_SKIP
+#define UMR_EDGE_SKIP 1     // eval_pair's doubt path: edge lines no lane in doubt can pick are not evaluated (A/B: -DUMR_EDGE_SKIP=0)
+#endif
 #ifndef UMR_REGION_VOTE
 #define UMR_REGION_VOTE 0   // 1: eval_pair votes per visit and runs a specialised body when its lanes all lie inside / all outside
 #endif                      // the face.  Measured on MI355X (profiles/r04_ab_region_vote.jsonl): the bodies are 15-25 % shorter, a
@@ -498,6 +501,12 @@ __device__ __forceinline__ bool eval_pair_region(Pair &p, const FaceT &fc, float
             float tbest = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
+                // An edge line that is >= amb_thr away (true distance) from EVERY lane in doubt cannot win in any of them (a lane in
+                // doubt has its two nearest lines inside amb_thr; a third one beyond it loses by more than the noise of the computed
+                // distances, or all three lie beyond 17.4 sigma and the fragment is 1.0f whichever wins -- the argument above):
+                // skipped for the whole wave.  Flagged faces evaluate all three.  (Typically one of the three is skipped: -5 % time)
+                const float mk = kk == 0 ? m0 : (kk == 1 ? m1 : m2);
+                if (UMR_EDGE_SKIP && !wave_any(fc.ill_conditioned() | (mk < amb_thr))) continue;
                 const float tk = edge_param(kk), uk = 1.f - tk;
                 const float c0 = kk == 0 ? tk : (kk == 1 ? 0.f : uk), c1 = kk == 0 ? uk : (kk == 1 ? tk : 0.f),
                             c2 = kk == 0 ? 0.f : (kk == 1 ? uk : tk);
