@@ -589,6 +589,7 @@ def main(device=None, backend="nccl"):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": dict({"workload": wl, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                         "includes_network": use_model, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+                        "lib_build_id": _lib.build_id(),      # source hash of the libumr_hip.so that ran (umr_amd/build.py)
                         # host time to enqueue ONE eager step (Python + dispatcher + ~1000 launches), measured before the capture:
                         # what the timed region would be bound by without the graph
                         "eager_host_enqueue_ms_per_step": eager_host_ms,

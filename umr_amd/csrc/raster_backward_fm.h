@@ -146,10 +146,12 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const float4 i2 = make_float4(fc.template g<R_I8>(), fc.template g<R_K2>(), fc.template g<R_K0>(), fc.template g<R_K1>());
             const float thr_cull = A.thr + A.rec[((size_t)n * F + f) * REC + R_CULL];   // band of the cull: + the reference's noise
             const int sub = lane / (FM_TW * FM_TH), sl = lane % (FM_TW * FM_TH);   // sub-tile slot of this lane, lane in it
+            (void)sub; (void)sl;
 #if FM_QUADS
             const int qsub = lane >> 2, qlx = lane & 1, qly = (lane >> 1) & 1;
             const float qlxf = (float)(2 * qlx) * inv_is, qlyf = (float)(2 * qly) * inv_is;
             const unsigned qlo_pn = (unsigned)(qly * IS + qlx) * 4u;
+            (void)qlo_pn;
 #if FM_PACKED
             const unsigned qlo_st = (unsigned)(qly * 4 + qlx) * 4u;      // this lane's place in its quad, in a tile record
 #endif
