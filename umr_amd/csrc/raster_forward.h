@@ -137,7 +137,8 @@ __global__ __launch_bounds__(BLK_THREADS) FWD_WPE_ATTR void k_raster_forward(con
                 }
                 if (RGB == 1 && P2F) {  // :427-430, reduced over the 8x8 tile first
                     if (__any(wgt != 0.f)) {
-                        const float sx = wave_sum_full(wgt * gx), sy = wave_sum_full(wgt * gy), sw = wave_sum_full(wgt);
+                        float sx = wgt * gx, sy = wgt * gy, sw = wgt;
+                        wave_sum_full3(sx, sy, sw);
                         if (t.lane < 4) {
                             const size_t o = ((size_t)t.n * F + f) * 2;
                             float *dst = t.lane < 2 ? A.p2f_info + o + t.lane : A.p2f_sum + o + (t.lane - 2);

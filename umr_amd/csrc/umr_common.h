@@ -50,6 +50,27 @@ __device__ __forceinline__ float wave_sum_full(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Three sums at once, step by step: a DPP read needs two wait states after the VALU write of its source, so ONE chain costs an
+// s_nop between its steps; three interleaved chains fill those slots with each other's work (the forward's p2f accumulators:
+// 3 x (12 VALU + 7 s_nop) -> 36 VALU + 0).  Same lanes, same order of additions per value as wave_sum_full.
+__device__ __forceinline__ void wave_sum_full3(float &a, float &b, float &c) {
+#define UMR_DPP_ADD3(ctrl, rowmask)                                                                          \
+    { const float ta = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), ctrl, rowmask, 0xf, false)); \
+      const float tb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), ctrl, rowmask, 0xf, false)); \
+      const float tc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), ctrl, rowmask, 0xf, false)); \
+      a += ta; b += tb; c += tc; }
+    UMR_DPP_ADD3(0xB1, 0xf);
+    UMR_DPP_ADD3(0x4E, 0xf);
+    UMR_DPP_ADD3(0x124, 0xf);
+    UMR_DPP_ADD3(0x128, 0xf);
+    UMR_DPP_ADD3(0x142, 0xa);
+    UMR_DPP_ADD3(0x143, 0xc);
+#undef UMR_DPP_ADD3
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+    c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, UMR_WAVE));
