@@ -96,6 +96,12 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = restype
         _lib = h
+        # debugging / A-B aid: UMR_DEBUG_SET="key=value,key=value" applies umr_debug_set switches at load (tools/r5/*.sh)
+        for kv in os.environ.get("UMR_DEBUG_SET", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                if h.umr_debug_set(k.strip().encode(), int(v)) != 0:
+                    raise RuntimeError("umr_amd: UMR_DEBUG_SET names an unknown switch: %r" % kv)
     return _lib
 
 
