@@ -118,7 +118,7 @@ def cpu_baseline(args, n_images):
                       "side" % (n_images, dt)}
 
 
-def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9)):
+def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9), N=16):
     """The four raster launches of one train_s1 step (bs 16) on a FIXED synthetic scene -- SURVEY.md 8d's: 1280-face icospheres with
     0.05 vertex noise, camera scale U(0.6, 0.9), translation U(-0.1, 0.1), random rotation, seed 0 -- timed with the library's HIP
     events: the per-kernel figures of `roofline` come from the live training state (meshes of steps 41-45 of THIS run's
@@ -127,13 +127,13 @@ def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9)):
     from umr_amd import _lib, functional as UF
     from umr_amd.mesh import create_sphere
     g = torch.Generator().manual_seed(0)
-    N, IS, TS = 16, 512, 36
+    IS, TS = 512, 36
     v, f = create_sphere(3)
     verts = torch.from_numpy(v).float()[None].repeat(2 * N, 1, 1)
     verts = verts + 0.05 * torch.randn(verts.shape, generator=g)
     faces = torch.from_numpy(f).long()[None].repeat(2 * N, 1, 1)
     sc_ = scale[0] + (scale[1] - scale[0]) * torch.rand(2 * N, 1, generator=g)   # (drawn in the order of tests/helpers.py:scene -- the geometry
-    tr_ = -0.1 + 0.2 * torch.rand(2 * N, 2, generator=g)         # tools/r4/step_kernels.py times)
+    tr_ = -0.1 + 0.2 * torch.rand(2 * N, 2, generator=g)         # tools/kernels.py times)
     q = torch.randn(2 * N, 4, generator=g)
     cams = torch.cat([sc_, tr_, q / q.norm(dim=1, keepdim=True)], 1)
     _, fv, _ = UF.project_faces(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732)
@@ -155,8 +155,8 @@ def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9)):
             sc.backward(g_tex)
             a.backward(g_sil)
         torch.cuda.synchronize()
-    for name, k in (("textured_forward_p2f_vis_pool_N16", 0), ("texel_gradient_backward_N16", 1), ("silhouette_forward_N32", 2),
-                    ("silhouette_backward_N32", 3)):
+    for name, k in (("textured_forward_p2f_vis_pool_N%d" % N, 0), ("texel_gradient_backward_N%d" % N, 1),
+                    ("silhouette_forward_N%d" % (2 * N), 2), ("silhouette_backward_N%d" % (2 * N), 3)):
         ms, n, _ = _lib.profile_collect(k)
         out[name] = round(1e3 * ms / max(n, 1), 1)
     # the shared mask / texture render of the same 16 views: its ONE backward pass (alpha gradient -> vertices, rgb -> texels),
@@ -173,10 +173,10 @@ def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9)):
                                   pool=True, need_p2f=True, want_visibility=True, detach_rgb_geometry=True, lean_state=lean)[0].backward(g_tex)
             torch.cuda.synchronize()
         ms, n, _ = _lib.profile_collect(1)
-        out["shared_render_backward_one_pass%s_N16" % tag] = round(1e3 * ms / max(n, 1), 1)
+        out["shared_render_backward_one_pass%s_N%d" % (tag, N)] = round(1e3 * ms / max(n, 1), 1)
         if lean:
             ms, n, _ = _lib.profile_collect(0)
-            out["shared_render_forward_packed_state_N16"] = round(1e3 * ms / max(n, 1), 1)
+            out["shared_render_forward_packed_state_N%d" % N] = round(1e3 * ms / max(n, 1), 1)
     _lib.profile_enable(False)
     return out
 

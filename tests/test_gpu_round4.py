@@ -79,7 +79,7 @@ def test_config4_training_soak_stays_finite(seed):
     step -- MeshNet, all 12 + 19 raster launches per image, every loss, Adam -- for 70 optimizer steps per seed at bs 4 (840
     image-steps over the three seeds, different network initialisations and data).  Every loss term of every step must be
     finite; on a failure the first offending step and term are reported (the terms are kept on the device, one read at the end).
-    Round 3's early builds ended ~2 in 1000 steps of this shape on a non-finite loss (HISTORY.md 5); see tools/r4/nan_hunt.sh for
+    Round 3's early builds ended ~2 in 1000 steps of this shape on a non-finite loss (HISTORY.md 5); see tools/nan/nan_hunt.sh for
     the instrumented hunt."""
     import argparse
     from umr_amd.model import build_training_step_s2

@@ -308,7 +308,7 @@ def test_reference_order_geometry_carries_rounding_noise(host_lib):
 def test_tile_culls_of_both_directions_agree_where_a_pixel_is_included(host_lib):
     """The cause of round 3's non-finite training runs at BASELINE configs[3] (HISTORY.md 10), on the geometry two tripwire runs
     on the MI355X captured (tests/golden/nan_cfg4_faces.npz: the faces around the offender of the blamed view, written by
-    tools/r4/make_nan_fixture.py).  The forward culls per 8x8 wave tile, the face-major backward per 4x4 sub-tile, then both decide
+    tools/nan/make_nan_fixture.py).  The forward culls per 8x8 wave tile, the face-major backward per 4x4 sub-tile, then both decide
     per pixel with eval_pair.  With the cull band at the EXACT threshold (round 3's early builds: noise_scale 0) a thin face's
     corner pixel of a tile -- included by the reference's own noisy distance with the smallest possible fragment, 1.03e-10 -- was
     dropped by the 8x8 test and kept by the 4x4 test (the two evaluate the same maximum through different tile centres and round

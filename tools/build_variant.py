@@ -1,7 +1,7 @@
 """Build an experimental copy of the library with extra compiler flags: umr_amd/lib/exp/libumr_hip_<tag>.so
 usage: build_variant.py <tag> [flags...]"""
 import os, subprocess, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from umr_amd import build as B
 tag, flags = sys.argv[1], sys.argv[2:]
 out = os.path.join(B.LIBDIR, "exp", "libumr_hip_%s.so" % tag)

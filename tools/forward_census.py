@@ -1,7 +1,7 @@
 """How many of the textured forward's wave visits could stop after the alpha product: the product's forward source (scratch copy)
 with counters, on the emulator, fixed SURVEY 8d scene.  A visit is 'colour-dead' when every live lane's soft-max weight of the face
 is exactly 0 (the face's nearest depth >= 89 gamma behind the lane's running maximum), 'z-dead' when the face cannot win the
-z-buffer plane of any live lane either.  usage: python tools/r4/forward_census.py [n_meshes=2]"""
+z-buffer plane of any live lane either.  usage: python tools/forward_census.py [n_meshes=2]"""
 import ctypes
 import os
 import shutil
@@ -12,7 +12,7 @@ import tempfile
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

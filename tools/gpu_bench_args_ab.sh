@@ -2,7 +2,7 @@
 # GPU box: A/B of extra bench.py arguments on the default line (alternating runs).  usage: gpu_cl.sh "<args A>" "<args B>" [repeats]
 set -u
 export TMPDIR=/tmp
-R="$(cd "$(dirname "$0")/../.." && pwd)"; cd "$R"
+R="$(cd "$(dirname "$0")/.." && pwd)"; cd "$R"
 A="$1"; B="$2"; N="${3:-2}"
 for i in $(seq 1 "$N"); do
   for X in "$A" "$B"; do

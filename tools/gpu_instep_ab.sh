@@ -3,7 +3,7 @@
 # per-kernel HIP-event averages of the raster launches inside the training step (bench.py's roofline pass) and step times.
 set -u
 export TMPDIR=/tmp
-R="$(cd "$(dirname "$0")/../.." && pwd)"
+R="$(cd "$(dirname "$0")/.." && pwd)"
 O="$R/gpurun_out/r5_instep"; mkdir -p "$O"
 for rep in 1 2; do
   (cd "$R/gpurun_scratch/r4" && python bench.py --steps 20 --warmup 5 --cpu-baseline 0 --fixed-scene 0 > "$O/r4_$rep.json" 2> "$O/r4_$rep.err")

@@ -3,7 +3,7 @@
 # switch list of AB_SETS ("a=1;b=2"), alternating with the default.   usage: AB_SETS="face_order_group=8" gpu_instep_sets.sh [repeats]
 set -u
 export TMPDIR=/tmp
-R="$(cd "$(dirname "$0")/../.." && pwd)"; cd "$R"
+R="$(cd "$(dirname "$0")/.." && pwd)"; cd "$R"
 N="${1:-2}"
 IFS=';' read -ra SETS <<< "${AB_SETS:-}"
 show() { python -c "

@@ -2,7 +2,7 @@
 # GPU box: train_s2 (BASELINE configs[2] per-GPU shape) and the configs[3] raster shape from one HIP graph; one line each
 set -u
 export TMPDIR=/tmp
-R="$(cd "$(dirname "$0")/../.." && pwd)"; cd "$R"
+R="$(cd "$(dirname "$0")/.." && pwd)"; cd "$R"
 O="$R/gpurun_out/r5_s2"; mkdir -p "$O"
 timeout 900 python bench.py --workload s2 --steps 10 --warmup 3 --cpu-baseline 0 --fixed-scene 0 > "$O/bench_s2.json" 2> "$O/bench_s2.err"
 timeout 900 python bench.py --workload s2 --image-size 512 --subdivide 4 --steps 5 --warmup 2 --cpu-baseline 0 --fixed-scene 0 > "$O/bench_s2_cfg4.json" 2> "$O/bench_s2_cfg4.err"

@@ -12,9 +12,9 @@ import os
 import re
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ubench"))
-from tools.r5.regs import kernel_table  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench"))
+from tools.regs import kernel_table  # noqa: E402
 import isa_cost  # noqa: E402
 
 COST = {"trans": 8.3, "half": 4.2, "full_s": 4.3, "full_v": 2.4, "pk": 4.4}

@@ -1,9 +1,9 @@
-"""GPU box: bench.py on the tripwire build of the library (-DUMR_TRAP=1, built by tools/r4/nan_hunt.sh into umr_amd/lib/exp/):
+"""GPU box: bench.py on the tripwire build of the library (-DUMR_TRAP=1, built by tools/nan/nan_hunt.sh into umr_amd/lib/exp/):
 every kernel of libumr_hip.so reports the first non-finite value it reads or writes (site ids: umr_amd/csrc/umr_common.h) without
 adding a launch or a synchronisation.  After bench's own output one line on stderr names the earliest report of the process.
 The geometry inputs of EVERY step (vertices, cameras: ~130 KB per step) and its loss terms are kept on the device; if a site fired or
 a term went non-finite, the first step with a non-finite term and its predecessor go to gpurun_out/nan/repro_<pid>.pt for an offline
-replay of the failing render on the CPU emulation (tools/r4/replay_nan.py)."""
+replay of the failing render on the CPU emulation (tools/nan/replay_nan.py)."""
 import ctypes, math, os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

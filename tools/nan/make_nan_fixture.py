@@ -1,4 +1,4 @@
-"""From the tripwire captures of tools/r4/nan_hunt.sh (gpurun_out/nan/repro_<pid>.pt: geometry of the step whose raster backward wrote
+"""From the tripwire captures of tools/nan/nan_hunt.sh (gpurun_out/nan/repro_<pid>.pt: geometry of the step whose raster backward wrote
 the first non-finite value, + the offending (view, face)) to tests/golden/nan_cfg4_faces.npz: per case the projected faces of that
 view whose dilated bounding box meets the offending face's window, the offender's index among them, image size.
 usage: make_nan_fixture.py repro_a.pt repro_b.pt ..."""

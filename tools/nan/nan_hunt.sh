@@ -10,13 +10,13 @@ N=${1:-20}; STEPS=${2:-60}
 # route, nearest edge by true distance everywhere (exact_edges off): the configuration the non-finite runs were seen on
 if [ "${OLD:-0}" = "1" ]; then
   export TRAP_LIB=trap_old UMR_DEBUG_SET=exact_edges=0
-  python tools/r4/build_variant.py trap_old -DUMR_TRAP=1 -DTILE_CULL_NOISE=0.f -DTHIN_FACE_H=0.f > $O/build.log 2>&1 || { echo "trap build failed"; tail -5 $O/build.log; exit 1; }
+  python tools/build_variant.py trap_old -DUMR_TRAP=1 -DTILE_CULL_NOISE=0.f -DTHIN_FACE_H=0.f > $O/build.log 2>&1 || { echo "trap build failed"; tail -5 $O/build.log; exit 1; }
   echo "== OLD settings (no cull widening, no thin-face route, exact_edges 0)" | tee -a $O/summary.log
 else
-  python tools/r4/build_variant.py trap -DUMR_TRAP=1 > $O/build.log 2>&1 || { echo "trap build failed"; tail -5 $O/build.log; exit 1; }
+  python tools/build_variant.py trap -DUMR_TRAP=1 > $O/build.log 2>&1 || { echo "trap build failed"; tail -5 $O/build.log; exit 1; }
 fi
 for i in $(seq 1 $N); do
-  timeout 600 python tools/r4/bench_trap.py --workload s2 --image-size 512 --subdivide 4 --steps $STEPS --warmup 2 --profile-steps 1 --cpu-baseline 0 > $O/run_$i.json 2> $O/run_$i.err
+  timeout 600 python tools/nan/bench_trap.py --workload s2 --image-size 512 --subdivide 4 --steps $STEPS --warmup 2 --profile-steps 1 --cpu-baseline 0 > $O/run_$i.json 2> $O/run_$i.err
   rc=$?
   d=$(grep -o '"discarded_nonfinite_runs": [0-9]*' $O/run_$i.json | head -1)
   s=$(grep -h "bench_trap: earliest\|bench_trap: first raster" $O/run_$i.err | tr '\n' ' ')

@@ -1,4 +1,4 @@
-"""CPU: replay the face a tripwire run blamed (tools/r4/bench_trap.py -> gpurun_out/nan/repro_<pid>.pt) through the arithmetic of
+"""CPU: replay the face a tripwire run blamed (tools/nan/bench_trap.py -> gpurun_out/nan/repro_<pid>.pt) through the arithmetic of
 both raster directions, compiled for the host from the kernel source (tests/host_kernel/pair_host.cpp::host_replay_face): the
 forward's saved soft-max state at every pixel of the face's window and the weight the backward gives the face there.
 usage: replay_nan.py repro.pt [noise_scale=0] [exact_edges=0] [thin_h=0]      (defaults: round 3's early settings)"""

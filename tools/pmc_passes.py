@@ -1,4 +1,4 @@
-"""GPU box: rocprofv3 PMC passes (one counter group per run, --kernel-trace only) over tools/r4/step_kernels.py, restricted to
+"""GPU box: rocprofv3 PMC passes (one counter group per run, --kernel-trace only) over tools/kernels.py, restricted to
 the counters `rocprofv3 -L` lists on this box, and a per-kernel summary.  usage: pmc_passes.py <outdir> [step_kernels args...]"""
 import collections
 import csv
@@ -9,7 +9,7 @@ import re
 import subprocess
 import sys
 
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.abspath(sys.argv[1])
 extra = sys.argv[2:]
 os.makedirs(out, exist_ok=True)
@@ -37,7 +37,7 @@ for g, names in GROUPS.items():
         continue
     used[g] = ok
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ok + ["--output-format", "csv", "-d", os.path.join(out, g), "-o", "t", "--",
-           sys.executable, os.path.join(R, "tools/r4/step_kernels.py")] + (extra or ["3"])
+           sys.executable, os.path.join(R, "tools/kernels.py")] + (extra or ["3"])
     r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env)
     open(os.path.join(out, g + ".log"), "w").write(r.stdout[-4000:] + "\n---\n" + r.stderr[-4000:])
 d = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -1,5 +1,5 @@
 """GPU box: raster kernel timings (library-owned HIP events around the main kernels, umr_profile_*) at the bench's
-launch sizes for a compile-time variant of the library (built by tools/r4/build_variant.py <tag> -DFLAG...; UMR_LIB_VARIANT=<tag>).
+launch sizes for a compile-time variant of the library (built by tools/build_variant.py <tag> -DFLAG...; UMR_LIB_VARIANT=<tag>).
 One JSON line tagged argv[1]."""
 import json
 import os
@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.microbench import bench, bench_alpha  # noqa: E402
 from umr_amd import _lib  # noqa: E402
 
-if os.environ.get("UMR_LIB_VARIANT"):   # a library built by tools/r4/build_variant.py
+if os.environ.get("UMR_LIB_VARIANT"):   # a library built by tools/build_variant.py
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "variants", os.environ["UMR_LIB_VARIANT"], "libumr_hip.so")
 
 

@@ -2,7 +2,7 @@
 scratch directory -- the product tree is not touched) with event counters injected at the stations of a visit, compiled for the
 wave64 emulator and run on meshes of the fixed SURVEY 8d scene (bench.py:fixed_scene_kernel_times).  Prints, per variant,
 lanes at each station per mesh:  candidates culled -> wanted sub-tiles -> lanes handed a pixel -> not state-dead -> inside the
-band (eval_pair) -> depth in range -> non-zero weight.  Usage: python tools/r4/visit_census.py [n_meshes=2]"""
+band (eval_pair) -> depth in range -> non-zero weight.  Usage: python tools/visit_census.py [n_meshes=2]"""
 import ctypes
 import os
 import shutil
@@ -13,7 +13,7 @@ import tempfile
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -96,7 +96,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = restype
         _lib = h
-        # debugging / A-B aid: UMR_DEBUG_SET="key=value,key=value" applies umr_debug_set switches at load (tools/r5/*.sh)
+        # debugging / A-B aid: UMR_DEBUG_SET="key=value,key=value" applies umr_debug_set switches at load (tools/gpu_*.sh)
         for kv in os.environ.get("UMR_DEBUG_SET", "").split(","):
             if "=" in kv:
                 k, v = kv.split("=", 1)

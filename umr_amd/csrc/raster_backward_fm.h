@@ -9,7 +9,7 @@
 //               whose rgb gradient goes to the texels only (UMR_BWD_ALPHA_GEOMETRY)
 //   ... + FM_PACKED 1  k_raster_backward_fm_agp   the same reading the forward's PACKED saved state (RasterArgs::state: one
 //               256-byte record per 4x4 tile with per-quad cull summaries) instead of the planes (UMR_BWD_PACKED_STATE)
-// Why quads (tools/r4/visit_census.py: this source with counters on the emulator): of the lanes a 4x4 hand-out carries 66 % lie
+// Why quads (tools/visit_census.py: this source with counters on the emulator): of the lanes a 4x4 hand-out carries 66 % lie
 // inside the face's band; by 2x2 pieces it is 89 %.  Wave visits per mesh of the SURVEY 8d scene: silhouette 12 694 -> 8 878,
 // texel-only 14 266 -> 12 140, vertex + texel 17 520 -> 14 956.  Measured on MI355X (us, N = 16): silhouette (N = 32) 158 -> 136,
 // texel-only 134 -> 126.5 (only with FM_VREC 0: at the 72-VGPR budget its allocation swings between 126 and 141 with

@@ -113,7 +113,7 @@ static inline bool umr_zero_async(void *p, size_t bytes, hipStream_t st) {
 }
 #endif
 
-// ---- non-finite tripwire (debug builds only: -DUMR_TRAP=1, tools/r4/bench_trap.py) -----------------------------------
+// ---- non-finite tripwire (debug builds only: -DUMR_TRAP=1, tools/nan/bench_trap.py) -----------------------------------
 // Kernels report the FIRST non-finite value they read or write without adding a launch or a host synchronisation: one
 // 64-bit word per translation unit holds min over reports of (device wall clock << 8 | site id); umr_debug_trap() returns
 // the earliest site of all translation units.  Compiled out of the product build (UMR_TRAP undefined).
