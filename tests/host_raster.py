@@ -16,7 +16,7 @@ SO = os.path.join(SRC_DIR, "libumr_host.so")
 TUS = ["raster", "geometry", "losses", "perceptual", "edt", "atlas", "regs", "eval"]     # umr_amd/build.py SOURCES
 
 NO_P2F, ALPHA_ONLY, FACE_ID_ONLY = 1, 2, 4      # UMR_RASTER_* (include/umr_hip.h)
-BWD_GRAD_POOLED, BWD_ALPHA_ONLY, BWD_ALPHA_GEOMETRY = 1, 2, 4          # UMR_BWD_*
+BWD_GRAD_POOLED, BWD_ALPHA_ONLY, BWD_ALPHA_GEOMETRY, BWD_PACKED_STATE = 1, 2, 4, 8          # UMR_BWD_*
 
 
 def available():
@@ -179,7 +179,7 @@ def backward(faces, textures, soft_colors, aggrs_info, grad_soft_colors, image_s
     IS = int(image_size)
     tex = None if textures is None else np.ascontiguousarray(textures, np.float32)
     TS = 1 if tex is None else tex.shape[2]
-    sc = np.ascontiguousarray(soft_colors, np.float32)
+    sc = None if soft_colors is None else np.ascontiguousarray(soft_colors, np.float32)     # (None: UMR_BWD_PACKED_STATE)
     ag = None if aggrs_info is None else np.ascontiguousarray(aggrs_info, np.float32)
     g = np.ascontiguousarray(grad_soft_colors, np.float32)
     gf = np.zeros((N, F, 9), np.float32) if need_gf else None
@@ -193,6 +193,27 @@ def backward(faces, textures, soft_colors, aggrs_info, grad_soft_colors, image_s
     if rc != 0:
         raise RuntimeError("umr_raster_backward (host emulation) rc=%d" % rc)
     return gf, gt
+
+
+def pack_state(ssum, smax, alpha):
+    """The packed saved state of UMR_RASTER_PACKED_STATE (include/umr_hip.h) built from the planes [N,IS,IS] a planar forward -- or
+    the oracle -- wrote: per 4x4 tile a record of 64 floats = [1 / sum][maximum][alpha][per 2x2 quad: smallest maximum, NaN if one
+    of its pixels is NaN][per quad: 1.0 iff all four alphas == 1.0][8 unused].  An independent restatement of the layout, in numpy."""
+    ssum, smax, alpha = (np.asarray(a, np.float32) for a in (ssum, smax, alpha))
+    N, IS = ssum.shape[0], ssum.shape[1]
+    T = IS // 4
+    tiles = lambda p: p.reshape(N, T, 4, T, 4).transpose(0, 1, 3, 2, 4).reshape(N, T, T, 16)
+    quads = lambda p: p.reshape(N, T, 2, 2, T, 2, 2).transpose(0, 1, 4, 2, 5, 3, 6).reshape(N, T, T, 4, 4)
+    rec = np.zeros((N, T, T, 64), np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rec[..., 0:16] = tiles(np.float32(1.0) / ssum)
+    rec[..., 16:32] = tiles(smax)
+    rec[..., 32:48] = tiles(alpha)
+    q = quads(smax)
+    with np.errstate(invalid="ignore"):
+        rec[..., 48:52] = np.where(np.isnan(q).any(-1), np.float32(np.nan), np.nanmin(np.where(np.isnan(q), np.float32(np.inf), q), -1))
+    rec[..., 52:56] = (quads(alpha) == 1).all(-1).astype(np.float32)
+    return rec.reshape(N, -1)
 
 
 def stats(L=None):

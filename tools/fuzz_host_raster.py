@@ -113,8 +113,13 @@ def run_one(rng, kind, IS, L, stats):
     # the one-pass backward of a shared mask / texture render: its vertex gradient is the alpha term alone, its texel gradient
     # the full one
     gf1p, gt1p = HR.backward(faces, tex, ref["soft_colors"], ref["aggrs_info"], gsc, IS, grad_flags=HR.BWD_ALPHA_GEOMETRY, L=L, **cfg)
+    # ... and the same from the PACKED saved state (UMR_BWD_PACKED_STATE: what the training steps run), built here from the
+    # reference's planes by the numpy restatement of the layout
+    state = HR.pack_state(ref["aggrs_info"][:, 0], ref["aggrs_info"][:, 1], ref["soft_colors"][:, 3])
+    gf1k, gt1k = HR.backward(faces, tex, None, state, gsc, IS, grad_flags=HR.BWD_ALPHA_GEOMETRY | HR.BWD_PACKED_STATE, L=L, **cfg)
     bad = []
-    for name, a, r in (("gf", gf, rgf), ("gt", gt, rgt), ("gt", gt1, rgt), ("gfa", gfa, rgfa), ("gfa", gf1p, rgfa), ("gt", gt1p, rgt)):
+    for name, a, r in (("gf", gf, rgf), ("gt", gt, rgt), ("gt", gt1, rgt), ("gfa", gfa, rgfa), ("gfa", gf1p, rgfa), ("gt", gt1p, rgt),
+                       ("gfa", gf1k, rgfa), ("gt", gt1k, rgt)):
         fr = np.isfinite(r).all()
         if fr and not np.isfinite(a).all():
             rec["nonfinite_host_only"] += 1

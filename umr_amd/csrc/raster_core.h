@@ -120,12 +120,11 @@ struct RasterArgs {
 #define STATE_O_QOPAQUE 52
 
 // ---- per-face preprocessing (:223-282) + packed record for the raster kernels ----------------
-__global__ void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
-                             float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
-                             float near_, float far_, unsigned short *__restrict__ cost = nullptr, int IS = 0,
-                             float thin_h = 0.f) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// (one face: everything but the record goes straight to memory; the record's 64 floats go to `r`, which the kernel below
+// points at a row of LDS)
+__device__ __forceinline__ void face_setup_one(int i, const float *__restrict__ faces, float *__restrict__ faces_info,
+                                               float4 *__restrict__ bbox, float *r, float thr, float near_, float far_,
+                                               unsigned short *__restrict__ cost, int IS, float thin_h) {
     const float *f = faces + (size_t)i * 9;
     const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
     UMR_TRAP_IF(umr_bad(x0) | umr_bad(y0) | umr_bad(z0) | umr_bad(x1) | umr_bad(y1) | umr_bad(z1) | umr_bad(x2) | umr_bad(y2) | umr_bad(z2), 1);
@@ -174,7 +173,6 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         cost[i] = (unsigned short)(key | (front ? 0x8000 : 0));
     }
     // ---- packed record ----
-    float *r = rec + (size_t)i * REC;
 #pragma unroll
     for (int k = 0; k < REC; ++k) r[k] = 0.f;
     r[R_XLO] = xlo; r[R_XHI] = xhi; r[R_YLO] = ylo; r[R_YHI] = yhi;
@@ -271,6 +269,24 @@ __global__ void k_face_setup(const float *__restrict__ faces, float *__restrict_
         p2_max = fmaxf(p2_max, px[c] * px[c] + py[c] * py[c]);
     }
     r[R_CULL] = TILE_CULL_NOISE * (1.f + p2_max) * (1.f + thr / sqrtf(k_min)) / sqrtf(l2_min);
+}
+
+// One thread per face, 64 faces per workgroup.  A thread that wrote its 256-byte record itself issued 64 dword stores 256 bytes
+// apart from its neighbours' (7.7 us per 20 480 faces, four such launches per train_s1 step); the records are staged in LDS
+// instead (row stride 65 floats: thread i's k-th word lands in bank (i + k) % 64) and the workgroup writes them out as 64 rows of
+// 256 contiguous bytes.
+#define FACE_SETUP_THREADS 64
+__global__ __launch_bounds__(FACE_SETUP_THREADS) void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
+                             float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
+                             float near_, float far_, unsigned short *__restrict__ cost = nullptr, int IS = 0,
+                             float thin_h = 0.f) {
+    __shared__ float s_rec[FACE_SETUP_THREADS][REC + 1];
+    const int base = blockIdx.x * FACE_SETUP_THREADS, i = base + (int)threadIdx.x;
+    if (i < total) face_setup_one(i, faces, faces_info, bbox, s_rec[threadIdx.x], thr, near_, far_, cost, IS, thin_h);
+    __syncthreads();
+    const int rows = min(FACE_SETUP_THREADS, total - base);
+    float *out = rec + (size_t)base * REC;
+    for (int row = 0; row < rows; ++row) out[(size_t)row * REC + threadIdx.x] = s_rec[row][threadIdx.x];
 }
 
 __device__ __forceinline__ float ndc_coord(int i, int IS) {  // (2i + 1 - IS) / IS, evaluated in double (:325-326)
