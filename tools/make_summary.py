@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from umr_amd import build as B  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-FAST, SLOW, P = (os.path.join(ROOT, "gpurun_out", d) for d in ("refresh_fast", "refresh_slow")) + (os.path.join(ROOT, "profiles"),)
+FAST, SLOW, P = os.path.join(ROOT, "gpurun_out", "refresh_fast"), os.path.join(ROOT, "gpurun_out", "refresh_slow"), os.path.join(ROOT, "profiles")
 HASH = B.source_hash()
 refused = []
 
@@ -68,9 +68,9 @@ for extra in ("cold_cache.json", "concurrency.json", "kernel_only.log"):
     if os.path.exists(os.path.join(SLOW, extra)) and os.path.getsize(os.path.join(SLOW, extra)) > 0 and kern:
         keep(os.path.join(SLOW, extra), extra)
 
-rows = list(csv.DictReader(open(os.path.join(FAST, "stats", "t_kernel_stats.csv"))))
-steps = 13.0          # tools/refresh_fast.sh: --steps 10 --warmup 3 --profile-steps 0, eager
-total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+keep(os.path.join(FAST, "steady_kernel_stats.csv"), "bench_kernel_stats_steady.csv")
+rows = list(csv.DictReader(open(os.path.join(FAST, "steady_kernel_stats.csv"))))
+tot = json.load(open(os.path.join(FAST, "steady_totals.json")))
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").replace("(RasterArgs)", "")[:96]
 ours = [r for r in rows if short(r["Name"]).startswith(("k_", "umr_k"))]
 L = ["# Round %s profile summary (1x MI355X)\n" % tag.lstrip("r0"),
@@ -115,22 +115,22 @@ for name, key, kp in (("shared render's one-pass backward (packed state), N = 16
             "%.2f" % v["lane_use"] if v.get("lane_use") else "-", "%.3f" % v["frac_of_peak"] if v else "-",
             "%.2f" % v["wave_wait_frac"] if v.get("wave_wait_frac") is not None else "-"))
 L.append("\nSummed raster main kernels: %.0f us per step (%s launches).\n" % (rf.get("raster_kernels_us_per_step", float("nan")), rf.get("raster_launches_per_step")))
-L.append("## Kernel trace (`rocprofv3 --kernel-trace --stats`, `profiles/%s_bench_kernel_stats.csv`)\n" % tag)
-L.append("Command: `bench.py --steps 10 --warmup 3 --profile-steps 0 --graph 0` (eager: every kernel a dispatch of its own; 13 training "
-         "steps from initialisation, the first of which runs MIOpen's solver search). Total GPU kernel time %.1f ms = %.2f ms/step.\n"
-         % (total_ns / 1e6, total_ns / 1e6 / steps))
+L.append("## Kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
+L.append("Command: `bench.py --steps 10 --warmup 3 --profile-steps 0 --graph 0` (eager: every kernel a dispatch of its own; 13 training steps "
+         "from initialisation). `profiles/%s_bench_kernel_stats.csv` is rocprofv3's own table over the whole process -- its first steps hold "
+         "MIOpen's solver search (seconds of naive reference convolutions); `profiles/%s_bench_kernel_stats_steady.csv` and the tables below "
+         "are the LAST %d steps from the per-dispatch trace: %.2f ms of kernel time per step in %.0f launches (%.2f ms wall per eager step).\n"
+         % (tag, tag, tot["steps"], tot["kernel_us_per_step"] / 1e3, tot["launches_per_step"], tot["wall_us_per_step"] / 1e3))
 L.append("| libumr_hip.so kernel | calls/step | avg us | us/step |\n|---|---|---|---|")
-osum = 0.0
-for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
-    us = float(r["TotalDurationNs"]) / 1e3 / steps
-    osum += us
-    if us >= 2.0:
-        L.append("| `%s` | %.1f | %.1f | %.1f |" % (short(r["Name"]), int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, us))
+osum = sum(float(r["UsPerStep"]) for r in ours)
+for r in ours:
+    if float(r["UsPerStep"]) >= 4.0:
+        L.append("| `%s` | %s | %s | %s |" % (short(r["Name"]), r["CallsPerStep"], r["AverageUs"], r["UsPerStep"]))
 L.append("\nlibumr_hip.so kernels: %.2f ms/step of %.2f (%.0f %%); the rest is the networks (MIOpen fp32 convolutions, batch-norm, GEMMs), "
-         "Adam and torch elementwise kernels (SURVEY 2 row 13: out of scope).\n" % (osum / 1e3, total_ns / 1e6 / steps, 100 * osum / 1e3 / (total_ns / 1e6 / steps)))
-L.append("Top 10 kernels overall:\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:10]:
-    L.append("| `%s` | %s | %.2f | %.1f | %.1f |" % (short(r["Name"])[:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+         "Adam and torch elementwise kernels (SURVEY 2 row 13: out of scope).\n" % (osum / 1e3, tot["kernel_us_per_step"] / 1e3, 100 * osum / tot["kernel_us_per_step"]))
+L.append("Top 10 kernels overall (steady state):\n\n| kernel | calls/step | avg us | us/step | % |\n|---|---|---|---|---|")
+for r in rows[:10]:
+    L.append("| `%s` | %s | %s | %s | %.1f |" % (short(r["Name"])[:70], r["CallsPerStep"], r["AverageUs"], r["UsPerStep"], 100 * float(r["UsPerStep"]) / tot["kernel_us_per_step"]))
 if kern:
     L.append("\n## Fixed SURVEY 8d scene, kernel only (`tools/kernels.py`, library-owned HIP events; `profiles/%s_fixed_scene_kernels.jsonl`)\n" % tag)
     L.append("Identical data every run and every round -- the comparable figures. us per launch.\n")

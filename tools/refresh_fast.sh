@@ -19,15 +19,30 @@ cp "$O/traffic/traffic.json" profiles/traffic.json
 python bench.py > "$O/bench_full.json" 2> "$O/bench_full.err"
 python bench.py --model 0 --cpu-baseline 0 --fixed-scene 0 > "$O/bench_hotpath_only.json" 2> "$O/bench_hot.err"
 python - "$O" <<'PY'
+# steady state from the per-dispatch trace: the LAST 8 of the 13 steps (the first steps hold MIOpen's solver search -- seconds of
+# naive reference convolutions -- and the allocator warm-up), steps delimited by the textured forward's dispatches
 import csv, glob, json, sys, collections
 out = sys.argv[1]
 rows = []
-for fn in glob.glob(out + "/stats/*kernel_stats.csv"):
+for fn in glob.glob(out + "/stats/*kernel_trace.csv"):
     rows += list(csv.DictReader(open(fn)))
-ours = {r["Name"].replace("(anonymous namespace)::", ""): {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
-        for r in rows if "k_raster" in r["Name"]}
-json.dump(ours, open(out + "/raster_kernel_stats.json", "w"), indent=1)
-print(json.dumps(ours, indent=1))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "k_raster_forward<1" in r["Kernel_Name"]]
+n = 8
+sel = rows[marks[-n - 1]:marks[-1]] if len(marks) > n else rows
+agg = collections.defaultdict(lambda: [0, 0])
+for r in sel:
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+    agg[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); agg[k][1] += 1
+with open(out + "/steady_kernel_stats.csv", "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["Name", "CallsPerStep", "AverageUs", "UsPerStep"])
+    for k, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        w.writerow([k, "%.2f" % (c / n), "%.2f" % (ns / c / 1e3), "%.2f" % (ns / n / 1e3)])
+span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / n / 1e3 if sel else 0
+json.dump({"steps": n, "kernel_us_per_step": sum(v[0] for v in agg.values()) / n / 1e3, "wall_us_per_step": span, "launches_per_step": len(sel) / n},
+          open(out + "/steady_totals.json", "w"))
+print(open(out + "/steady_totals.json").read())
 PY
 find "$O" -name "*counter_collection.csv" -delete; find "$O" -name "*kernel_trace.csv" -delete; find "$O" -name "*.csv" -size +3M -delete
 tail -2 "$O/bench_full.json" | cut -c1-1500

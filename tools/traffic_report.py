@@ -69,7 +69,10 @@ for k, e in rep["kernels"].items():
                      "lane_use": lane_use, "useful_lane_instr": issued * 64.0 * lane_use if lane_use else None,
                      "kernel_us_in_pmc_pass": ns / 1e3, "wave_instr_per_s": issued / (ns * 1e-9),
                      "frac_of_peak": issued / (ns * 1e-9) / VALU_PEAK, "peak_wave_instr_per_s": VALU_PEAK,
-                     "waves": mean(a.get("SQ_WAVES", []))}
+                     "waves": mean(a.get("SQ_WAVES", [])),
+                     # SQ_ACTIVE_INST_VALU counts quad-cycles (guide, PMC section): x 4 = SIMD cycles with a VALU instruction in the pipe
+                     "busy_cycles_per_instr": (4.0 * act_valu / issued) if act_valu else None,
+                     "busy_frac": (4.0 * act_valu / (1024.0 * ns * 1e-9 * 2.4e9)) if act_valu else None}
         wa, wi, ac = mean(b.get("SQ_WAIT_ANY", [])), mean(b.get("SQ_WAIT_INST_ANY", [])), mean(b.get("SQ_ACTIVE_INST_ANY", []))
         if wa is not None and wi is not None and ac is not None and (wa + wi + ac) > 0:
             tot = wa + wi + ac                                     # disjoint buckets of a wave's life (guide, PMC section)
