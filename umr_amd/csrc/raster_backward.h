@@ -313,6 +313,10 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #ifndef FM_AGP_SLOT16
 #define FM_AGP_SLOT16 1   // packed-state one-pass kernel (COMMON): 16-byte quad slots {x, y, state offset, gradient offset} as floats
 #endif
+#ifndef FM_PREFETCH
+#define FM_PREFETCH 0     // packed-state one-pass kernel: 1 = the next visit's state words, 2 = + its pooled gradients requested a visit ahead.
+                          // Measured (r5): 135.2 / 134.9 vs 136.1 us warm, 147.2 vs 147.3 cold -- the 6 waves / SIMD hide those loads already; off
+#endif
 #ifndef FM_DEAD_EAGER
 #define FM_DEAD_EAGER 1   // packed-state one-pass kernel: the visit's two dead-test words are loaded together
 #endif

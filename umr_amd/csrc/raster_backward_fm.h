@@ -350,6 +350,25 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                 unsigned qe_next = (QSLOT16 || PK) ? 0u : qslot[0];
                 uint2 q2_next = PK2 ? qslot2[0] : make_uint2(0u, 0u);
                 float4 q4_next = QSLOT16 ? qslot4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+#if FM_PACKED
+                // Software prefetch (FM_PREFETCH; packed-state kernel with 16-byte slots): the NEXT visit's state words [and pooled
+                // gradients] are requested at the top of the current visit -- its slot is in registers by then -- and waited for one
+                // visit later, instead of at the top of the visit that needs them (the one-pass kernel issues VALU in only ~53 % of
+                // its SIMD cycles: its waves sit at those waits)
+                constexpr bool PF = QSLOT16 && FM_PREFETCH != 0, PFG = QSLOT16 && FM_PREFETCH >= 2;
+                float pf_rs = 0.f, pf_mx = 0.f, pf_al = 0.f, pf_g0 = 0.f, pf_g1 = 0.f, pf_g2 = 0.f, pf_g3 = 0.f;
+                auto prefetch = [&](const float4 &slot, bool on) {
+                    if (on) {
+                        const unsigned o = (unsigned)__float_as_int(slot.z) + qlo_st;
+                        pf_mx = ld_ui<STATE_O_MAX * 4u>(st_n, o); pf_al = ld_ui<STATE_O_ALPHA * 4u>(st_n, o); pf_rs = ld_u(st_n, o);
+                        if constexpr (PFG) {
+                            const unsigned g = (unsigned)__float_as_int(slot.w);
+                            pf_g0 = ld_u(gc_n, g); pf_g1 = ld_u(gc_n, g + gps); pf_g2 = ld_u(gc_n, g + 2 * gps); pf_g3 = ld_u(gc_n, g + 3 * gps);
+                        }
+                    }
+                };
+                if constexpr (PF) prefetch(q4_next, qsub < nq);
+#endif
                 for (int v0 = 0; v0 < nq; v0 += 16) {
                     const int mine = v0 + qsub < nq ? 0 : -1;
                     const unsigned qe = PK2 ? q2_next.x : qe_next;
@@ -359,6 +378,11 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     else if constexpr (PK2) q2_next = qslot2[v0 + 16];
                     else qe_next = qslot[v0 + 16];     // (past the last quad: stale or unwritten words of the array, never used)
                     (void)qst;
+#if FM_PACKED
+                    const float c_rs = pf_rs, c_mx = pf_mx, c_al = pf_al, c_g0 = pf_g0, c_g1 = pf_g1, c_g2 = pf_g2, c_g3 = pf_g3;
+                    if constexpr (PF) prefetch(q4_next, v0 + 16 + qsub < nq);
+                    (void)c_rs; (void)c_mx; (void)c_al; (void)c_g0; (void)c_g1; (void)c_g2; (void)c_g3;
+#endif
 #else
                 while (tm) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
@@ -434,10 +458,13 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                             dead = false;
                             if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
 #if FM_PACKED
+                                if constexpr (PF) { smx = c_mx; sal = c_al; }
+                                else {
                                 smx = ld_ui<STATE_O_MAX * 4u>(st_n, pn4);
 #if FM_DEAD_EAGER
                                 sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);    // both words in flight before the first is tested
 #endif
+                                }
 #else
                                 smx = ld_u(ag_n, pn4 + pst);
 #endif
@@ -447,7 +474,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #if FM_PACKED && FM_DEAD_EAGER
                                 dead = dead & (sal == 1.f);
 #elif FM_PACKED
-                                sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);
+                                if constexpr (!PF) sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);
                                 dead = dead & (sal == 1.f);
 #else
                                 if (AG) { sal = ld_u(sc_n, pn4 + 3 * pst); dead = dead & (sal == 1.f); }
@@ -481,12 +508,18 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         continue;
                     }
                     const float gscale = pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
+#if FM_PACKED
+                    const float g0 = gscale * (PFG ? c_g0 : ld_u(gc_n, gp4)), g1 = gscale * (PFG ? c_g1 : ld_u(gc_n, gp4 + gps)),
+                                g2 = gscale * (PFG ? c_g2 : ld_u(gc_n, gp4 + 2 * gps));
+                    const float g3 = gscale * (PFG ? c_g3 : ld_u(gc_n, gp4 + 3 * gps));
+#else
                     const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
                                 g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
                     const float g3 = NEED_GF ? gscale * ld_u(gc_n, gp4 + 3 * gps) : 0.f;
+#endif
                     UMR_TRAP_IF(umr_bad(g0) | umr_bad(g1) | umr_bad(g2) | umr_bad(g3), 3);
 #if FM_PACKED
-                    const float rsum = ld_u(st_n, pn4), smax = smx;   // (rsum: the sum's v_rcp_f32, taken by the forward)
+                    const float rsum = PF ? c_rs : ld_u(st_n, pn4), smax = smx;   // (rsum: the sum's v_rcp_f32, taken by the forward)
                     float c_xy = g3 * ((1.f - sal) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
 #else
                     const float ssum = ld_u(ag_n, pn4), smax = (!NEED_GF || AG) ? smx : ld_u(ag_n, pn4 + pst);
