@@ -104,7 +104,7 @@ struct RasterArgs {
     // UMR_RASTER_PACKED_STATE / UMR_BWD_PACKED_STATE: the soft-max render's saved state as ONE tiled buffer instead of the planes
     // soft_colors[:, 3] + aggrs_info -- per mesh (IS/4)^2 records of 64 floats (256 B), one per 4x4 pixel tile, row-major over
     // tiles; in a record, pixel (x, y) of the tile sits at i = 4 y + x:
-    //   [0,16)  RN-free v_rcp_f32 of the soft-max sum  (the backward's only use of the sum is that reciprocal, :608)
+    //   [0,16)  v_rcp_f32 of the soft-max sum  (the backward uses the sum only through that reciprocal, :608)
     //   [16,32) soft-max maximum          [32,48) alpha
     //   [48,52) per 2x2 quad q = 2 (y / 2) + x / 2: smallest maximum of its four pixels (NaN if any of them is NaN)
     //   [52,56) per quad: 1.0f when all four alphas are exactly 1.0f, else 0.0f          [56,64) unused

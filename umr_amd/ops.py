@@ -22,6 +22,9 @@ SoftRenderer route through these ops.
             soft_colors [N,4,IS,IS] (saved state; == image when not pool), visibility [N,2,IS,IS] | empty)
   umr::soft_rasterize_backward(face_vertices, textures, soft_colors, aggrs_info, grad_image, <same scalars>,
                                need_grad_faces, need_grad_textures) -> (grad_face_vertices, grad_textures)
+  umr::soft_rasterize_alpha_geometry(<same arguments>, lean) / umr::soft_rasterize_alpha_geometry_backward(..., lean): the one
+        render the training steps make for the mask AND the texture term (below); lean = its saved state as ONE packed buffer
+        in the one-pass backward's layout (UMR_RASTER_PACKED_STATE / UMR_BWD_PACKED_STATE), returned in the aggrs_info slot
   umr::silhouette(face_vertices, image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, pool)
         -> (alpha_out [N,S,S], alpha [N,IS,IS] (saved state))
   umr::silhouette_backward(face_vertices, alpha, grad_alpha_out, <same scalars>) -> grad_face_vertices
