@@ -448,6 +448,7 @@ def build_training_step(tv, faces, args, dev, world):
         return total.detach()
 
     step.model = model
+    step.opt, step.it_dev = opt, it_dev          # (tests: snapshot / restore the optimizer state around a graph replay)
     return step
 
 
@@ -510,5 +511,6 @@ def build_training_step_s2(args, dev, world):
         return total.detach()
 
     step.model = model
+    step.opt, step.it_dev = opt, it_dev          # (tests: snapshot / restore the optimizer state around a graph replay)
     step.watch = watch
     return step
