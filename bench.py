@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--share-mask-render", type=int, default=1,
                     help="1: the mask render is the alpha channel of the textured render of the same views (one render where the "
                          "reference makes two); 0: both renders, for A/B")
+    ap.add_argument("--capture-scene", default="", help="write the inputs of the FIRST profile step's shared render and unseen-view silhouette "
+                    "(projected face vertices, texels, upstream gradient) to this .npz: how profiles/scenes/*.npz were frozen")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="capture the step in ONE HIP graph and time graph replays instead of eager launches: with --model 0 the "
@@ -118,16 +120,71 @@ def cpu_baseline(args, n_images):
                       "side" % (n_images, dt)}
 
 
-def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9), N=16):
-    """The four raster launches of one train_s1 step (bs 16) on a FIXED synthetic scene -- SURVEY.md 8d's: 1280-face icospheres with
-    0.05 vertex noise, camera scale U(0.6, 0.9), translation U(-0.1, 0.1), random rotation, seed 0 -- timed with the library's HIP
-    events: the per-kernel figures of `roofline` come from the live training state (meshes of steps 41-45 of THIS run's
-    trajectory, which float-atomic summation order makes differ from run to run by +-20 % in raster work); these do not move
-    and are comparable across builds and rounds.  us per launch."""
+def raster_launch_times(dev, fv, fv_sil, iters=20, tex=None, g_tex=None, seed=0, two_render_forms=True):
+    """us per launch (library-owned HIP events) of the raster launches of one train_s1 step on GIVEN projected face vertices:
+    `fv` [N,F,3,3] = the views of the shared mask / texture render, `fv_sil` [M,F,3,3] = the views of the silhouette launch.
+    Texels and upstream gradients steer no branch of these kernels (values only), so they are seeded noise unless given
+    (`tex` [N,F,36,3], `g_tex` [N,4,IS/2,IS/2]: a captured step's own, tools/scene_times.py compares the two)."""
     from umr_amd import _lib, functional as UF
+    g = torch.Generator().manual_seed(seed)
+    IS, TS = 512, 36
+    N, M, F = fv.shape[0], fv_sil.shape[0], fv.shape[1]
+    fv = fv.detach().to(dev)
+    tex = (torch.rand(N, F, TS, 3, generator=g) if tex is None else tex.detach().float().cpu()).to(dev).requires_grad_(True)
+    fv_sil = fv_sil.detach().to(dev).clone().requires_grad_(True)
+    g_tex = (torch.randn(N, 4, IS // 2, IS // 2, generator=g) if g_tex is None else g_tex.detach().float().cpu()).to(dev)
+    g_sil = torch.randn(M, IS // 2, IS // 2, generator=g).to(dev)
+    out = {}
+    for phase in range(2):
+        if phase:
+            _lib.profile_enable(True)
+            for k in range(4):
+                _lib.profile_collect(k)
+        for _ in range(iters if phase else 2):
+            tex.grad = None; fv_sil.grad = None
+            if two_render_forms:
+                sc = UF.soft_rasterize(fv, tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
+                                       pool=True, need_p2f=True, want_visibility=True)[0]
+            a = UF.silhouette(fv_sil, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, True)
+            if two_render_forms:
+                sc.backward(g_tex)
+            a.backward(g_sil)
+        torch.cuda.synchronize()
+    for name, k in (("textured_forward_p2f_vis_pool_N%d" % N, 0), ("texel_gradient_backward_N%d" % N, 1),
+                    ("silhouette_forward_N%d" % M, 2), ("silhouette_backward_N%d" % M, 3)):
+        ms, n, _ = _lib.profile_collect(k)
+        if n:
+            out[name] = round(1e3 * ms / n, 1)
+    # the shared mask / texture render of the same views: its ONE backward pass (alpha gradient -> vertices, rgb -> texels),
+    # which replaces a texel-gradient backward + a silhouette backward -- with the saved state packed (lean_state: what
+    # the training steps run; its forward writes nothing else at full resolution) and with the reference's planes
+    fv_sh = fv.clone().requires_grad_(True)
+    for lean, tag in ((True, ""), (False, "_planar_state")) if two_render_forms else ((True, ""),):
+        for phase in range(2):
+            if phase:
+                _lib.profile_collect(0); _lib.profile_collect(1)
+            for _ in range(iters if phase else 2):
+                tex.grad = None; fv_sh.grad = None
+                UF.soft_rasterize(fv_sh, tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
+                                  pool=True, need_p2f=True, want_visibility=True, detach_rgb_geometry=True, lean_state=lean)[0].backward(g_tex)
+            torch.cuda.synchronize()
+        ms, n, nbytes = _lib.profile_collect(1)
+        out["shared_render_backward_one_pass%s_N%d" % (tag, N)] = round(1e3 * ms / max(n, 1), 1)
+        if lean:
+            out["_one_pass_alg_bytes_per_launch"] = nbytes / max(n, 1)
+            ms, n, _ = _lib.profile_collect(0)
+            out["shared_render_forward_packed_state_N%d" % N] = round(1e3 * ms / max(n, 1), 1)
+    _lib.profile_enable(False)
+    return out
+
+
+def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9), N=16):
+    """The raster launches of one train_s1 step (bs 16) on a FIXED synthetic scene -- SURVEY.md 8d's: 1280-face icospheres with
+    0.05 vertex noise, camera scale U(0.6, 0.9), translation U(-0.1, 0.1), random rotation, seed 0 -- identical every run and
+    comparable across builds and rounds.  us per launch."""
+    from umr_amd import functional as UF
     from umr_amd.mesh import create_sphere
     g = torch.Generator().manual_seed(0)
-    IS, TS = 512, 36
     v, f = create_sphere(3)
     verts = torch.from_numpy(v).float()[None].repeat(2 * N, 1, 1)
     verts = verts + 0.05 * torch.randn(verts.shape, generator=g)
@@ -138,47 +195,55 @@ def fixed_scene_kernel_times(dev, iters=20, scale=(0.6, 0.9), N=16):
     cams = torch.cat([sc_, tr_, q / q.norm(dim=1, keepdim=True)], 1)
     _, fv, _ = UF.project_faces(verts.to(dev), cams.to(dev), faces.int().to(dev), 5.0, -2.732)
     fv = fv.detach()
-    tex = torch.rand(N, faces.shape[1], TS, 3, generator=g).to(dev).requires_grad_(True)
-    fv_sil = fv.clone().requires_grad_(True)
-    g_tex, g_sil = torch.randn(N, 4, IS // 2, IS // 2, generator=g).to(dev), torch.randn(2 * N, IS // 2, IS // 2, generator=g).to(dev)
-    out = {}
-    for phase in range(2):
-        if phase:
-            _lib.profile_enable(True)
-            for k in range(4):
-                _lib.profile_collect(k)
-        for _ in range(iters if phase else 2):
-            tex.grad = None; fv_sil.grad = None
-            sc = UF.soft_rasterize(fv[:N], tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
-                                   pool=True, need_p2f=True, want_visibility=True)[0]
-            a = UF.silhouette(fv_sil, IS, 1., 100., True, 1e-3, 1e-5, 1e-10, 1e-4, True)
-            sc.backward(g_tex)
-            a.backward(g_sil)
-        torch.cuda.synchronize()
-    for name, k in (("textured_forward_p2f_vis_pool_N%d" % N, 0), ("texel_gradient_backward_N%d" % N, 1),
-                    ("silhouette_forward_N%d" % (2 * N), 2), ("silhouette_backward_N%d" % (2 * N), 3)):
-        ms, n, _ = _lib.profile_collect(k)
-        out[name] = round(1e3 * ms / max(n, 1), 1)
-    # the shared mask / texture render of the same 16 views: its ONE backward pass (alpha gradient -> vertices, rgb -> texels),
-    # which replaces a texel-gradient backward + a 16-view silhouette backward -- with the saved state packed (lean_state: what
-    # the training steps run; its forward writes nothing else at full resolution) and with the reference's planes
-    fv_sh = fv[:N].clone().requires_grad_(True)
-    for lean, tag in ((True, ""), (False, "_planar_state")):
-        for phase in range(2):
-            if phase:
-                _lib.profile_collect(0); _lib.profile_collect(1)
-            for _ in range(iters if phase else 2):
-                tex.grad = None; fv_sh.grad = None
-                UF.soft_rasterize(fv_sh, tex, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
-                                  pool=True, need_p2f=True, want_visibility=True, detach_rgb_geometry=True, lean_state=lean)[0].backward(g_tex)
-            torch.cuda.synchronize()
-        ms, n, _ = _lib.profile_collect(1)
-        out["shared_render_backward_one_pass%s_N%d" % (tag, N)] = round(1e3 * ms / max(n, 1), 1)
-        if lean:
-            ms, n, _ = _lib.profile_collect(0)
-            out["shared_render_forward_packed_state_N%d" % N] = round(1e3 * ms / max(n, 1), 1)
-    _lib.profile_enable(False)
-    return out
+    return raster_launch_times(dev, fv[:N], fv, iters, seed=1)
+
+
+SCENE_DIR = os.path.join(ROOT, "profiles", "scenes")
+
+
+def frozen_scenes():
+    """[(name, path)] of the frozen captures of what the training step really renders (bench.py --capture-scene: projected face
+    vertices of the shared render's and the unseen-view silhouette's 16 views, written at the profile pass of a default run)."""
+    if not os.path.isdir(SCENE_DIR):
+        return []
+    return [(f[:-4], os.path.join(SCENE_DIR, f)) for f in sorted(os.listdir(SCENE_DIR)) if f.endswith(".npz")]
+
+
+def frozen_scene_kernel_times(dev, path, iters=20, real_values=False):
+    import numpy as np
+    z = np.load(path)
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(z[k]))
+    real = real_values and "textures" in z.files and "grad_image" in z.files
+    return raster_launch_times(dev, t("fv_shared"), t("fv_unseen"), iters, tex=t("textures") if real else None,
+                               g_tex=t("grad_image") if real else None, seed=1, two_render_forms=False)
+
+
+class SceneCapture:
+    """_lib.TAP collector of ONE eager training step: the shared render's views (face vertices, texels, upstream gradient) and the
+    unseen-view silhouette's."""
+
+    def __init__(self):
+        self.got = {}
+
+    def __call__(self, name, d):
+        if name == "raster_forward" and d.get("lean") and "fv_shared" not in self.got:
+            self.got["fv_shared"] = d["face_vertices"].detach().clone()
+            self.got["textures"] = d["textures"].detach().clone()
+        elif name == "silhouette_forward" and "fv_unseen" not in self.got:
+            self.got["fv_unseen"] = d["face_vertices"].detach().clone()
+        elif name == "raster_backward_alpha_geometry" and "grad_image" not in self.got:
+            self.got["grad_image"] = d["grad_image"].detach().clone()
+
+    def save(self, path, meta):
+        import numpy as np
+        need = ("fv_shared", "fv_unseen", "textures", "grad_image")
+        if any(k not in self.got for k in need):
+            raise SystemExit("--capture-scene: the step made no shared render (got %s)" % sorted(self.got))
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+        # geometry exact (fp32: it decides every branch of the raster kernels); texels and the upstream gradient -- values only --
+        # as fp16, to keep two captures inside gpurun's 64 MiB return limit
+        np.savez_compressed(path, meta=json.dumps(meta), **{k: self.got[k].float().cpu().numpy().astype("float32" if k.startswith("fv") else "float16")
+                                                            for k in need})
 
 
 def build_hot_path_step(args, dev, world, tv, faces, outputs, batch):
@@ -479,8 +544,16 @@ def main(device=None, backend="nccl"):
         _lib.profile_collect(k)
     # (graph replays do not pass through the C ABI's event scope: the eager form of the same step is profiled)
     prof_step = eager_step if whole_graph is not None else getattr(step_fn, "eager", step_fn)
-    for _ in range(max(0, args.profile_steps)):
+    capture = SceneCapture() if (args.capture_scene and rank == 0) else None
+    for i_ in range(max(0, args.profile_steps)):
+        if capture is not None and i_ == 0:
+            _lib.TAP = capture
         prof_step()
+        _lib.TAP = None
+    if capture is not None:
+        torch.cuda.synchronize()
+        capture.save(args.capture_scene, {"bench_args": vars(args), "lib_build_id": _lib.build_id(),
+                                          "taken_at": "first step of the profile pass, after %d warm-up + %d timed steps" % (args.warmup, args.steps)})
     barrier()
     _lib.profile_enable(False)
     prof = {k: _lib.profile_collect(k) for k in range(4)}   # 0 fwd, 1 bwd, 2 silhouette/id fwd, 3 silhouette bwd

@@ -328,3 +328,64 @@ def test_exactness_switches_change_what_they_say(L, oracle_built):
     assert max(brute["gf_err_max"], brute["gfa_err_max"]) <= 1e-5 and brute["alpha_err_max"] <= 1e-6
     assert max(fast["gf_err_max"], fast["gfa_err_max"]) > 1e-3          # the fast pick is measurably not the reference's choice (1.3 - 5.4 % here) ...
     assert fast["alpha_err_max"] <= 2e-2 and fast["membership_pixels"] == 0   # ... within the bounds HISTORY.md 4.4 states
+
+
+def _subtiles_under_bbox(faces, IS):
+    """k_face_setup's work estimate: 4x4 sub-tiles under the bbox dilated by sqrt(threshold) (raster_core.h, `cost`)."""
+    thr = np.float32(np.sqrt(np.float32(np.log(1. / 1e-10 - 1.)) * np.float32(1e-5)))
+    x, y = faces.reshape(faces.shape[0], -1, 3, 3)[..., 0], faces.reshape(faces.shape[0], -1, 3, 3)[..., 1]
+    h = 0.5 * IS
+    px0 = np.maximum(np.floor((x.min(-1) - thr) * h + h - 0.5) - 1, 0); px1 = np.minimum(np.ceil((x.max(-1) + thr) * h + h - 0.5) + 1, IS - 1)
+    py0 = np.maximum(np.floor((y.min(-1) - thr) * h + h - 0.5) - 1, 0); py1 = np.minimum(np.ceil((y.max(-1) + thr) * h + h - 0.5) + 1, IS - 1)
+    return np.where((px0 <= px1) & (py0 <= py1), ((px1 // 4) - (px0 // 4) + 1) * ((py1 // 4) - (py0 // 4) + 1), 0)
+
+
+@pytest.mark.parametrize("variant", ["one_pass", "one_pass_packed", "texel_only", "silhouette"])
+def test_split_faces_sum_to_the_unsplit_result(L, variant):
+    """k_face_order splits a face whose estimated work exceeds umr_debug_set("face_split", T) into several work items, each a
+    share of the face's culling passes; the last item to arrive adds the parts' partial sums in part order.  An 80-face mesh at
+    IS = 256 (faces of ~300 sub-tiles = 5 culling passes) with T = 16: most faces split.  Against T = 0 (one wave per face):
+    faces of a single culling pass cannot split and must come out bit-identical; split faces differ by summation order only;
+    the split result repeats bit for bit."""
+    import torch
+    IS, TS = 256, 9
+    faces, gen = _scene_faces(2, 1, seed=77, scale=(0.7, 0.9))
+    faces[1] *= np.array([2.5, 2.5, 1.0] * 3, np.float32)      # second mesh larger than the frame: faces clipped by the image
+    F = faces.shape[1]
+    tex = torch.rand(2, F, TS, 3, generator=gen).numpy()
+    gp = torch.randn(2, 4, IS // 2, IS // 2, generator=gen).numpy()
+    cfg = dict(CFG, func_id_rgb=1)
+    o = HR.forward(faces, tex, IS, pooled=True, L=L, **cfg)
+
+    def run():
+        if variant == "texel_only":
+            return HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, need_gf=False, grad_flags=HR.BWD_GRAD_POOLED, L=L, **cfg)
+        if variant == "silhouette":
+            return HR.backward(faces, None, np.ascontiguousarray(o["soft_colors"][:, 3]), None, np.ascontiguousarray(gp[:, 3]), IS,
+                               need_gt=False, grad_flags=HR.BWD_ALPHA_ONLY | HR.BWD_GRAD_POOLED, L=L, **cfg)
+        if variant == "one_pass_packed":
+            st = HR.pack_state(o["aggrs_info"][:, 0], o["aggrs_info"][:, 1], o["soft_colors"][:, 3])
+            return HR.backward(faces, tex, None, st, gp, IS, grad_flags=HR.BWD_GRAD_POOLED | HR.BWD_ALPHA_GEOMETRY | HR.BWD_PACKED_STATE, L=L, **cfg)
+        return HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, grad_flags=HR.BWD_GRAD_POOLED | HR.BWD_ALPHA_GEOMETRY, L=L, **cfg)
+
+    L.umr_debug_set(b"face_order", 2)          # (the silhouette variant takes the item lists only with face_order 2)
+    try:
+        L.umr_debug_set(b"face_split", 0)
+        ref = run()
+        L.umr_debug_set(b"face_split", 16)
+        got, again = run(), run()
+    finally:
+        L.umr_debug_set(b"face_split", -1)
+        L.umr_debug_set(b"face_order", 1)
+    single_pass = _subtiles_under_bbox(faces, IS) <= 64
+    assert single_pass.any() and (~single_pass).sum() > F // 2
+    differs = 0
+    for a, b, c in zip(ref, got, again):
+        if a is None:
+            continue
+        np.testing.assert_array_equal(b, c)                                     # deterministic
+        np.testing.assert_array_equal(b[single_pass], a[single_pass])           # unsplit faces: today's path, bit for bit
+        s = np.abs(a).max()
+        assert_close_frac(b, a, atol=2e-6 * s, rtol=1e-5, frac=1.0, name="host split vs unsplit (%s)" % variant)
+        differs += int((a != b).any(axis=tuple(range(2, a.ndim))).sum())
+    assert differs > 0, "no face was split: the test exercises nothing"

@@ -145,6 +145,11 @@ def stream_ptr(device=None):
     return torch._C._cuda_getCurrentRawStream(idx)
 
 
+# Measurement aid: when set to a callable, the raster operators hand it (name, dict of their input tensors) right before their
+# C-ABI call -- how bench.py --capture-scene freezes the geometry the training step really renders (profiles/scenes/).  None in
+# every other run; the operators do nothing else with it.
+TAP = None
+
 _TRACE = bool(os.environ.get("UMR_TRACE_SYNC"))   # debugging aid: name every C-ABI call and synchronise after it
 
 

@@ -40,9 +40,35 @@ size_t ws_rec_bytes(int N, int F) { return (size_t)N * F * REC * sizeof(float); 
 size_t ws_sbcount_bytes(int N, int slots) { return (((size_t)N * slots * sizeof(int)) + 255) & ~(size_t)255; }
 int sb_cap_for(int F) { return F < SB_CAP ? F : SB_CAP; }
 size_t ws_sblist_bytes(int N, int F, int slots) { return (size_t)N * slots * sb_cap_for(F) * sizeof(int); }
-size_t ws_order_bytes(int N, int F) {   // start order in whole groups of <= 16 meshes + the per-face work estimates
-    return (size_t)(N + 15) * F * sizeof(int) + (((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255);
+// Work-item lists of the face-major backward (k_face_order): per (mesh group, XCD) a list of gsz = G x F / 8 faces' items plus
+// up to order_extra(gsz) more from split faces, the slab pool of the split faces' partial sums (2 x extra units of SPLIT_UNIT
+// floats per list: extras + split faces <= 2 x extras) and their arrival counters.  Sized for the worst group size G (the
+// "face_order_group" debug switch can only shrink G).
+int order_extra(int gsz) { return gsz / 4 + 16; }
+int order_group_for(int N, int F) { return std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / std::max(1, F / 8))); }
+struct OrderLayout { int G, groups, stride, extra, slabs_per_list; size_t order_bytes, ctr_bytes, slab_bytes, cost_bytes; };
+OrderLayout order_layout(int N, int F, int G) {
+    OrderLayout L;
+    L.G = G; L.groups = (N + G - 1) / G;
+    const int gsz = G * (F / 8);
+    L.extra = order_extra(gsz); L.stride = gsz + L.extra; L.slabs_per_list = 2 * L.extra;
+    const size_t lists = (size_t)L.groups * 8;
+    L.order_bytes = (lists * L.stride * sizeof(uint2) + 255) & ~(size_t)255;
+    L.ctr_bytes = (lists * L.slabs_per_list * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    L.slab_bytes = lists * L.slabs_per_list * SPLIT_UNIT * sizeof(float);
+    L.cost_bytes = ((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255;
+    return L;
 }
+size_t ws_order_bytes(int N, int F) {
+    size_t worst = 0;
+    for (int G = 1; G <= order_group_for(N, F); ++G) {
+        const OrderLayout L = order_layout(N, F, G);
+        worst = std::max(worst, L.order_bytes + L.ctr_bytes + L.slab_bytes + L.cost_bytes);
+    }
+    return worst;
+}
+int g_face_split = SPLIT_T0;     // umr_debug_set("face_split", T): estimated work (4x4 sub-tiles) beyond which k_face_order splits a face
+                                 // into several work items; 0 = never (one wave per face, round 5's form)
 int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping of the pixel-major kernels.  2 (default): XCD x takes
                                  // block rows x, x + 8, ... of every mesh; 1: each XCD a contiguous run of (mesh, block) items
                                  // (forward 3-7 % slower than 2 at N = 16: two whole meshes per XCD balance worse); 0: plain
@@ -144,6 +170,7 @@ int umr_debug_set(const char *key, int value) {
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
     if (std::string(key) == "exact_edges") { g_exact_edges = value != 0; return UMR_OK; }
     if (std::string(key) == "thin_face_h_1e6") { g_thin_face_h = value < 0 ? THIN_FACE_H : 1e-6f * (float)value; return UMR_OK; }
+    if (std::string(key) == "face_split") { g_face_split = value < 0 ? SPLIT_T0 : std::min(1 << 14, value); return UMR_OK; }   // (< 0: the default)
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
     return UMR_ERR_ARG;
 }
@@ -359,18 +386,36 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     const int order_mode = alpha_only ? 2 : (((!need_grad_faces || alpha_geom) && func_id_rgb == 1) ? 1 : 0);
     const bool ordered = face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 &&
                          F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
-    int *order = (int *)((char *)workspace + ws_order_offset(N, F, image_size));
-    unsigned short *cost = (unsigned short *)(order + (size_t)(N + 15) * F);
+    int G = order_group_for(N, F);
+    if (g_face_order_group) G = std::min(G, g_face_order_group);
+    const OrderLayout OL = order_layout(N, F, G);
+    char *op = (char *)workspace + ws_order_offset(N, F, image_size);
+    uint2 *order = (uint2 *)op;
+    unsigned long long *slab_ctr = (unsigned long long *)(op + OL.order_bytes);
+    float *slab = (float *)(op + OL.order_bytes + OL.ctr_bytes);
+    unsigned short *cost = (unsigned short *)(op + OL.order_bytes + OL.ctr_bytes + OL.slab_bytes);
     UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
                                                    sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size, g_thin_face_h);
     // light variants at small N: four runs of faces per XCD instead of one (fm_owned_face)
     A.fm_split = (face_major && N <= 16 && (alpha_only || !need_grad_faces || alpha_geom) && F % 32 == 0) ? 4 : 1;
+    int fm_blocks = N * ((F + FM_WAVES - 1) / FM_WAVES);
     if (ordered) {
-        int G = std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / (F / 8)));
-        if (g_face_order_group) G = std::min(G, g_face_order_group);
-        UMR_LAUNCH(k_face_order, dim3(8, (N + G - 1) / G), ORDER_THREADS, 0, st, cost, A.rec, soft_colors, order, N, F, image_size, G, order_mode, A.fm_split);
-        A.order = order; A.order_group = G;
+        // a part's partial sums: 9 vertex gradients at [0, 9), 3 TS texel gradients from 16 -- in whole slab units
+        const int part_floats = need_grad_textures ? 16 + 3 * TS : 16;
+        const int units = (part_floats + SPLIT_UNIT - 1) / SPLIT_UNIT;
+        OrderArgs O = {};
+        O.cost = cost; O.rec = A.rec; O.alpha = soft_colors; O.order = order; O.ctr = slab_ctr;
+        O.N = N; O.F = F; O.IS = image_size; O.G = G; O.mode = order_mode; O.run_split = A.fm_split;
+        O.stride = OL.stride; O.units_per_part = units;
+        O.X = OL.extra / units;                        // extra items this launch's lists may hold (its parts take `units` slab units each)
+        O.slabs_per_list = OL.slabs_per_list / units;
+        O.T0 = g_face_split;
+        UMR_LAUNCH(k_face_order, dim3(8, OL.groups), ORDER_THREADS, 0, st, O);
+        A.order = order; A.order_group = G; A.order_stride = OL.stride;
+        A.slab = slab; A.slab_ctr = slab_ctr; A.slab_stride = units * SPLIT_UNIT;
+        fm_blocks = OL.groups * 8 * OL.stride;
     }
+    A.fm_blocks = fm_blocks;
     {
         // Algorithmic bytes of one backward launch, per VARIANT, by SURVEY.md 8d's rule (every op-boundary buffer the variant
         // touches, once; fp32): per pixel -- the gradient planes it reads (4 B per plane per COARSE pixel when the gradient

@@ -131,38 +131,64 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 }
 
 // ------------------------------------------------------------------------------------------------
-// Start order of the face-major backward's waves.  A wave owns one face for its whole life and faces differ ~50x in
-// work (a front face under a texel-gradient launch walks ~13 visits of ~900 issue cycles, a back face is culled after one
-// pass), so with waves started in index order the launch ends on a few heavy faces running alone on otherwise empty SIMDs:
-// N = 16 meshes cost 8.6 us per mesh against 6.2 us at N = 128.  This kernel sorts, per XCD (each XCD keeps its contiguous
-// eighth of every mesh's faces -- the L2 locality of the saved state) and per group of `G` meshes, the faces by DESCENDING
-// estimated work (counting sort, 1024 buckets), so the heavy faces of all meshes of the group start first and the launch
-// drains on cheap ones.  Work estimate: 4x4 sub-tiles under the dilated bbox; / 8 for faces the state cull will remove --
-// mode 1 (texel gradients only): back faces; mode 2 (silhouette): faces whose corners and centroid all sit on alpha == 1.
-// The order changes no result (every face is still reduced by one wave in its own fixed order).
+// Work items of the face-major backward and their start order.  A wave owns one item for its whole life and faces differ
+// enormously in work: on a regular mesh a front face under a texel-gradient launch walks ~13 visits of ~900 issue cycles while
+// a back face is culled after one pass (50x), and the meshes a training step really renders (profiles/scenes/live_s1_*.npz:
+// step ~57 of a GAN-driven trajectory) carry a few faces of 1000 - 1500 candidate sub-tiles against a median of 63 -- ONE such
+// wave then runs for the whole launch on an otherwise empty chip (one-pass backward: 212 - 273 us on the live scenes against
+// 137 us on the regular SURVEY 8d scene, with fewer instructions issued).  This kernel, per XCD (each XCD keeps its contiguous
+// share of every mesh's faces -- the L2 locality of the saved state) and per group of `G` meshes,
+//   1. estimates every face's work: 4x4 sub-tiles under the dilated bbox; / 8 for faces the state cull will remove -- mode 1
+//      (texel gradients / one pass): back faces; mode 2 (silhouette): faces whose corners and centroid all sit on alpha == 1;
+//   2. SPLITS a face whose estimate exceeds T into parts = ceil(estimate / T) items (<= SPLIT_MAX_PARTS, <= its culling passes),
+//      each a contiguous share of the face's culling passes.  T = T0 << k with the smallest k whose extra items fit the list's
+//      budget X (so the launch grid and the slab pool have fixed sizes);
+//   3. sorts the ITEMS by descending work (counting sort, 1024 buckets; a part's key = the face's estimate / parts), so the
+//      heavy items of all meshes of the group start first and the launch drains on cheap ones; the list is padded with
+//      0xffffffff to its fixed length;
+//   4. zeroes the arrival counters of its slab range.
+// Neither order nor split changes WHICH pairs contribute; a split face's sum is formed part by part in part order by whichever
+// item arrives last (raster_backward_fm.h), so results do not depend on scheduling.
 #define ORDER_KEYS 1024
 #define ORDER_MAX_ENTRIES 16384
 #define ORDER_THREADS 1024
-__global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned short *__restrict__ cost, const float *__restrict__ rec,
-                                                              const float *__restrict__ alpha, int *__restrict__ order, int N,
-                                                              int F, int IS, int G, int mode, int split) {
+#define SPLIT_MAX_PARTS 32
+#define SPLIT_LEVELS 8          // thresholds tried: T0 << 0 .. T0 << 7, then "no split"
+#define SPLIT_UNIT 128          // floats per slab unit (a part of the BASELINE variants -- 9 + 3 x 36 sums -- takes one)
+#ifndef SPLIT_T0
+#define SPLIT_T0 128            // estimated work (sub-tiles) one item may carry before its face is split
+#endif
+struct OrderArgs {
+    const unsigned short *cost; const float *rec; const float *alpha; uint2 *order; unsigned long long *ctr;
+    int N, F, IS, G, mode, run_split, stride, X, slabs_per_list, units_per_part, T0;
+};
+__global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O) {
     __shared__ int s_hist[ORDER_KEYS];
     __shared__ int s_wsum[ORDER_THREADS / 64];
     __shared__ unsigned short s_key[ORDER_MAX_ENTRIES];
-    const int xcd = blockIdx.x, g = blockIdx.y, per = F >> 3;
-    const int m0 = g * G, gl = min(G, N - m0), E = gl * per;
+    __shared__ unsigned char s_np[ORDER_MAX_ENTRIES];
+    __shared__ int s_ex[SPLIT_LEVELS];
+    __shared__ int s_slab, s_level;
+    const int xcd = blockIdx.x, g = blockIdx.y, F = O.F, IS = O.IS, per = F >> 3;
+    const int m0 = g * O.G, gl = min(O.G, O.N - m0), E = gl * per;
     for (int k = threadIdx.x; k < ORDER_KEYS; k += ORDER_THREADS) s_hist[k] = 0;
+    if (threadIdx.x < SPLIT_LEVELS) s_ex[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_slab = 0;
     __syncthreads();
     const float h = 0.5f * IS;
+    int ex[SPLIT_LEVELS];
+#pragma unroll
+    for (int k = 0; k < SPLIT_LEVELS; ++k) ex[k] = 0;
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
-        const int ml = e / per, f = fm_owned_face(xcd, e % per, per, split);
+        const int ml = e / per, f = fm_owned_face(xcd, e % per, per, O.run_split);
         const size_t fi = (size_t)(m0 + ml) * F + f;
-        const unsigned c = cost[fi];                       // k_face_setup: sub-tiles under the bbox | front << 15
-        int nt = (int)(c & 0x7fffu);
-        if (mode == 1 && !(c & 0x8000u)) nt >>= 3;
-        if (mode == 2 && nt > 0) {
-            const float *r = rec + fi * REC;
-            const float *ap = alpha + (size_t)(m0 + ml) * IS * IS;
+        const unsigned c = O.cost[fi];                     // k_face_setup: sub-tiles under the bbox | front << 15
+        const int raw = (int)(c & 0x7fffu);
+        int nt = raw;
+        if (O.mode == 1 && !(c & 0x8000u)) nt >>= 3;
+        if (O.mode == 2 && nt > 0) {
+            const float *r = O.rec + fi * REC;
+            const float *ap = O.alpha + (size_t)(m0 + ml) * IS * IS;
             const float cx[4] = {r[R_X0], r[R_X1], r[R_X2], (r[R_X0] + r[R_X1] + r[R_X2]) * (1.f / 3.f)};
             const float cy[4] = {r[R_Y0], r[R_Y1], r[R_Y2], (r[R_Y0] + r[R_Y1] + r[R_Y2]) * (1.f / 3.f)};
             bool opaque = true;
@@ -173,9 +199,39 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
             }
             if (opaque) nt >>= 3;
         }
-        const int key = min(nt, ORDER_KEYS - 1);
+        // a face cannot have more parts than culling passes (64 candidate sub-tiles each)
+        const int lim = max(1, min(SPLIT_MAX_PARTS, (raw + 63) >> 6));
+        s_key[e] = (unsigned short)nt;
+        s_np[e] = (unsigned char)lim;
+#pragma unroll
+        for (int k = 0; k < SPLIT_LEVELS; ++k) {
+            const int T = max(O.T0, 1) << k;
+            ex[k] += min(max((nt + T - 1) / T, 1), lim) - 1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SPLIT_LEVELS; ++k) {
+        int v = ex[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_ex[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0;
+        while (k < SPLIT_LEVELS && s_ex[k] > O.X) ++k;      // SPLIT_LEVELS: nothing fits -- one item per face
+        s_level = O.T0 > 0 ? k : SPLIT_LEVELS;
+    }
+    __syncthreads();
+    const int level = s_level;
+    for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
+        const int nt = s_key[e], lim = s_np[e];
+        int np = 1;
+        if (level < SPLIT_LEVELS) { const int T = O.T0 << level; np = min(max((nt + T - 1) / T, 1), lim); }
+        const int key = min((nt + np - 1) / np, ORDER_KEYS - 1);
         s_key[e] = (unsigned short)key;
-        atomicAdd(&s_hist[key], 1);
+        s_np[e] = (unsigned char)np;
+        atomicAdd(&s_hist[key], np);
     }
     __syncthreads();
     // exclusive prefix over DESCENDING keys: thread t owns key 1023 - t
@@ -195,11 +251,20 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const unsigned sho
     __syncthreads();
     s_hist[kb] = base;
     __syncthreads();
-    int *out = order + ((size_t)g * 8 + xcd) * ((size_t)G * per);
+    const size_t list = (size_t)g * 8 + xcd;
+    uint2 *out = O.order + list * (size_t)O.stride;
+    const unsigned slab0 = (unsigned)(list * (size_t)O.slabs_per_list);
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
-        const int pos = atomicAdd(&s_hist[s_key[e]], 1);
-        out[pos] = ((e / per) << 16) | fm_owned_face(xcd, e % per, per, split);
+        const int np = s_np[e];
+        const int pos = atomicAdd(&s_hist[s_key[e]], np);
+        const unsigned code = ((unsigned)(np - 1) << 21) | ((unsigned)(e / per) << 16) | (unsigned)fm_owned_face(xcd, e % per, per, O.run_split);
+        unsigned slab = 0;
+        if (np > 1) slab = slab0 + (unsigned)atomicAdd(&s_slab, np);
+        for (int p = 0; p < np; ++p) out[pos + p] = make_uint2(code | ((unsigned)p << 26), slab);
     }
+    const int items = E + (level < SPLIT_LEVELS ? s_ex[level] : 0);
+    for (int i = items + (int)threadIdx.x; i < O.stride; i += ORDER_THREADS) out[i] = make_uint2(0xffffffffu, 0u);
+    for (int i = threadIdx.x; i < O.slabs_per_list; i += ORDER_THREADS) O.ctr[slab0 + i] = 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,7 +433,7 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 
 template <int RGB, bool COMMON>
 void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
-    const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
+    const int blocks = A.fm_blocks;
     const size_t lds = (A.need_gt && A.TS > 1) ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
     if constexpr (RGB == 2) {
         if constexpr ((FM_QUADS_MASK & 1) != 0) UMR_LAUNCH((k_raster_backward_fm_quads<2, true, false, COMMON>), blocks, FM_WAVES * 64, 0, st, A);
@@ -386,7 +451,7 @@ void launch_backward_fm2(const RasterArgs &A, hipStream_t st) {
 }
 // d alpha -> vertices and d rgb -> texels of a soft-max render in one pass (UMR_BWD_ALPHA_GEOMETRY)
 void launch_backward_fm_ag(const RasterArgs &A, hipStream_t st) {
-    const int blocks = A.N * ((A.F + FM_WAVES - 1) / FM_WAVES);
+    const int blocks = A.fm_blocks;
     const size_t lds = A.TS > 1 ? (size_t)FM_WAVES * FM_TEXCOPY * FM_TEX_STRIDE(A.TS) * sizeof(float) : 0;
     const bool common = A.grad_pooled && A.double_side && (A.IS & (A.IS - 1)) == 0;
     if (A.state) {    // packed saved state (UMR_BWD_PACKED_STATE)

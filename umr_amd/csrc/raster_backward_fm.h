@@ -81,12 +81,18 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
         fb = __builtin_amdgcn_readfirstlane(fm_owned_face(xcd, slot % per, per, A.fm_split));   // (uniform; the division hides it)
     }
     int fidx = fb * FM_WAVES + wave;
-    if (FM_WAVES == 1 && A.order) {   // cost-ordered start (k_face_order): same XCD ownership, heavy faces first
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gsz = A.order_group * (F >> 3);
-        const int g = slot / gsz;
-        const int e = A.order[((size_t)g * 8 + xcd) * gsz + slot % gsz];
-        nb = g * A.order_group + (e >> 16);
-        fidx = e & 0xffff;
+    // this wave's work item (k_face_order): a whole face, or part `part` of the `nparts` a heavy face was split into.  Only the
+    // item word itself stays live across the walk (the epilogue decodes it again): every wave-uniform value more is an SGPR
+    // spill in the visit loop
+    unsigned item = 0u;          // part << 26 | (nparts - 1) << 21 | ...
+    if (FM_WAVES == 1 && A.order) {   // work items in cost order: same XCD ownership, heavy items first
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int g = slot / A.order_stride;
+        const unsigned ex = A.order[((size_t)g * 8 + xcd) * A.order_stride + slot % A.order_stride].x;
+        if ((int)ex < 0) return;      // padding of the list (whole workgroup = this wave)
+        nb = g * A.order_group + (int)((ex >> 16) & 31u);
+        fidx = (int)(ex & 0xffffu);
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)ex);
     }
     const bool live = fidx < F;
     // (explicitly wave-uniform: the record's address below feeds scalar loads)
@@ -156,10 +162,18 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
             const unsigned qlo_st = (unsigned)(qly * 4 + qlx) * 4u;      // this lane's place in its quad, in a tile record
 #endif
 #endif
+            // this item's culling passes: a contiguous share of the face's ceil(ntiles / 64) (all of them for an unsplit face)
+            int tb_begin = 0, tb_end = ntiles;
+            if (item >> 21) {
+                const int nparts = (int)((item >> 21) & 31u) + 1, part = (int)(item >> 26);
+                const int ppp = (((ntiles + 63) >> 6) + nparts - 1) / nparts;
+                tb_begin = min(part * ppp * 64, ntiles);
+                tb_end = min(tb_begin + ppp * 64, ntiles);
+            }
 #ifdef FM_NO_CULL            // time-split experiment (-DFM_NO_CULL, HISTORY.md 4.2): per-face set-up and reductions only
-            for (int tb = ntiles; tb < ntiles; tb += 64) {
+            for (int tb = tb_end; tb < tb_end; tb += 64) {
 #else
-            for (int tb = 0; tb < ntiles; tb += 64) {
+            for (int tb = tb_begin; tb < tb_end; tb += 64) {
 #endif
                 // one lane per sub-tile: drop those no pixel of which can survive (conservative), then walk the rest
                 const int ti = tb + lane;
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #if FM_QUADS
                 unsigned qm = 0;   // surviving 2x2 quads of the candidate: bit q = quad (q & 1, q >> 1)
 #endif
-                if (ti < ntiles) {
+                if (ti < tb_end) {
                     const int ttx = tx0 + ti % ntx, tty = ty0 + ti / ntx;
                     tpk = ttx | (tty << 16);
                     const int px0 = ttx * FM_TW, px1 = min(px0 + FM_TW - 1, IS - 1), pr0 = tty * FM_TH, pr1 = min(pr0 + FM_TH - 1, IS - 1);
@@ -578,6 +592,67 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #ifndef FM_SKIP_EMPTY
 #define FM_SKIP_EMPTY 1   // a face none of whose sub-tiles survived the culling pass (half the mesh under a texel-gradient
 #endif                    // launch) adds exact zeros: skip its lane reductions, LDS read-out and read-modify-write stores
+    if (FM_WAVES == 1 && (item >> 21)) {
+        const int nparts = (int)((item >> 21) & 31u) + 1, part = (int)(item >> 26);
+        const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
+        const unsigned slab0 = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)A.order[((size_t)(slot_ / A.order_stride) * 8 + xcd_) * A.order_stride + slot_ % A.order_stride].y);
+        // One part of a split face: leave this item's partial sums in its slab, arrive, and -- as the LAST of the face's items to
+        // arrive -- add the parts' sums in part order and store.  The sum a face gets is a function of its parts' sums and their
+        // fixed order alone, whichever wave forms it.
+        float *sl = A.slab + (size_t)(slab0 + (unsigned)part) * A.slab_stride;
+        if (visited) {
+            if (NEED_GF) {
+                float mine = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float sv = wave_sum_full(gv[k]);
+                    if (lane == k) mine = sv;
+                }
+                if (lane < 9) sl[lane] = mine;
+            }
+            if (NEED_GT) {
+                if (TS == 1) {
+                    const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
+                    if (lane < 3) sl[16 + lane] = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+                } else {
+                    __syncthreads();
+                    for (int j = lane; j < TS * 3; j += 64) {
+                        float acc = wave_tex[j];
+#pragma unroll
+                        for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
+                        sl[16 + j] = acc;
+                    }
+                }
+            }
+        }
+        UMR_DEVICE_FENCE();
+        unsigned long long seen = 0ull;
+        if (lane == 0) seen = atomicAdd(A.slab_ctr + slab0, (1ull << 32) | (visited ? 1ull << part : 0ull));
+        const unsigned arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)(seen >> 32));
+        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)seen) | (visited ? 1u << part : 0u);
+        if (arrived != (unsigned)(nparts - 1) || !mask) return;
+        UMR_DEVICE_FENCE();
+        const float *s0p = A.slab + (size_t)slab0 * A.slab_stride;
+        if (NEED_GF && lane < 9) {
+            float acc = 0.f;
+            for (int q = 0; q < nparts; ++q)
+                if ((mask >> q) & 1u) acc += umr_ld_device(s0p + (size_t)q * A.slab_stride + lane);
+            UMR_TRAP_AT(umr_bad(acc), 4 | (RGB == 2 ? 0x40 : (RGB == 0 ? 0x80 : 0)), ((unsigned)(A.N > 32) << 23) | ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
+            A.grad_faces[((size_t)n * F + f) * 9 + lane] += acc;
+        }
+        if (NEED_GT) {
+            float *dst = A.grad_textures + ((size_t)n * F + f) * TS * 3;
+            for (int j = lane; j < TS * 3; j += 64) {
+                float acc = 0.f;
+                for (int q = 0; q < nparts; ++q)
+                    if ((mask >> q) & 1u) acc += umr_ld_device(s0p + (size_t)q * A.slab_stride + 16 + j);
+                UMR_TRAP_AT(umr_bad(acc), 5 | (RGB == 0 ? 0x80 : 0), ((unsigned)(A.N > 32) << 23) | ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
+                dst[j] += acc;
+            }
+        }
+        return;
+    }
     if (FM_SKIP_EMPTY && FM_WAVES == 1 && !visited) return;
     if (NEED_GF) {
         float mine = 0.f;

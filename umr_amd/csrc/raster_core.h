@@ -86,10 +86,19 @@ struct RasterArgs {
     const int *sb_count;
     const int *sb_list;
     int sb_size, sb_nx, sb_cap, sb_slots;   // sb_slots = sb_nx^2: slots per mesh in sb_count / sb_list
-    // face-major backward: start order of the faces (k_face_order).  order[((g * 8 + xcd) * order_group * (F / 8)) + i] =
-    // (mesh - g * order_group) << 16 | face for the i-th wave XCD `xcd` starts within mesh group g; NULL = index order.
-    const int *order;
-    int order_group;
+    // face-major backward: the work items of the launch in start order (k_face_order).  order[(g * 8 + xcd) * order_stride + i] =
+    // the i-th wave XCD `xcd` starts within mesh group g: .x = part << 26 | (parts - 1) << 21 | (mesh - g * order_group) << 16 |
+    // face (0xffffffff: padding, the wave exits), .y = first slab of the face's partial sums (parts > 1).  A face whose estimated
+    // work exceeds the split threshold is `parts` items -- each walks a contiguous share of the culling passes under the face's
+    // bounding box and leaves its partial sums in slab .y + part; the item that arrives last (slab_ctr) adds them up IN PART ORDER
+    // and stores the face's gradient: no wave owns more than a bounded share of a heavy face, results stay deterministic, no
+    // float atomics.  NULL = one wave per face in index order.
+    const uint2 *order;
+    int order_group, order_stride;
+    int fm_blocks;                  // workgroups of the face-major launch: N x F, or the lists' total length
+    float *slab;                    // [slabs][slab_stride]: vertex gradients at [0, 9), texel gradients at [16, 16 + 3 TS)
+    unsigned long long *slab_ctr;   // per split face (indexed by its first slab): arrivals << 32 | mask of the parts that visited a pixel
+    int slab_stride;
     int fm_split;      // runs of faces per XCD and mesh in the face-major backward (fm_owned_face); 0 / 1 = one
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
     float amb_thr;    // eval_pair: 0, or 20 sigma with umr_debug_set("exact_edges", 1)
@@ -159,15 +168,15 @@ __device__ __forceinline__ void face_setup_one(int i, const float *__restrict__ 
     bbox[i] = make_float4(xlo, xhi, ylo, yhi);
     if (cost) {
         // work estimate for the face-major backward's start order (k_face_order): 4x4 sub-tiles under the dilated bbox
-        // (the window of raster_backward.h), bit 15 = front-facing.  NaN bounds: the wave walks the whole image.
-        int key = 1023;
+        // (the window of raster_backward.h; 15 bits), bit 15 = front-facing.  NaN bounds: the wave walks the whole image.
+        int key = 0x7fff;
         if (xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) {
             const float h = 0.5f * IS;
             const int px0 = max((int)floorf(xlo * h + h - 0.5f) - 1, 0), px1 = min((int)ceilf(xhi * h + h - 0.5f) + 1, IS - 1);
             const int py0 = max((int)floorf(ylo * h + h - 0.5f) - 1, 0), py1 = min((int)ceilf(yhi * h + h - 0.5f) + 1, IS - 1);
             int nt = 0;
             if (px0 <= px1 && py0 <= py1) nt = ((px1 >> 2) - (px0 >> 2) + 1) * ((py1 >> 2) - (py0 >> 2) + 1);
-            key = min(nt, 1023);
+            key = min(nt, 0x7fff);
         }
         const bool front = (y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0);
         cost[i] = (unsigned short)(key | (front ? 0x8000 : 0));

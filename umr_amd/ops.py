@@ -94,7 +94,12 @@ def _raster_forward(face_vertices, textures, image_size, background, near, far, 
     if lean:
         if not lean_state_ok(IS, TS, modes, pool):
             raise RuntimeError("soft_rasterize_alpha_geometry(lean): needs pool, image_size %% 8 == 0, UMR's modes, TS <= %d" % ONE_PASS_MAX_TS)
-        aggrs_info = torch.empty(N, IS * IS * 4, device=dev, dtype=torch.float32)      # umr_raster_state_bytes(N, IS): 16 B / pixel
+        # the packed state's size is the LIBRARY's to say (16 B / pixel today): a layout change on the C side then fails here,
+        # not as a write past the tensor
+        state_bytes = L.umr_raster_state_bytes(N, IS)
+        if state_bytes == 0 or state_bytes % (4 * N):
+            raise RuntimeError("soft_rasterize_alpha_geometry(lean): umr_raster_state_bytes(%d, %d) = %d" % (N, IS, state_bytes))
+        aggrs_info = torch.empty(N, state_bytes // (4 * N), device=dev, dtype=torch.float32)
         soft_colors = None
     else:
         aggrs_info = torch.empty(N, 2, IS, IS, device=dev, dtype=torch.float32)
@@ -112,6 +117,8 @@ def _raster_forward(face_vertices, textures, image_size, background, near, far, 
     flags = (0 if need_p2f else 1) | (G << 8)
     if lean:
         flags |= RASTER_PACKED_STATE | (RASTER_VIS_IDS_ONLY if want_visibility else 0)
+    if getattr(_lib, "TAP", None) is not None:
+        _lib.TAP("raster_forward", dict(face_vertices=fv, textures=tex, lean=lean, image_size=IS))
     rc = L.umr_raster_forward_vis(ptr(fv), ptr(tex), None, ptr(aggrs_info), ptr(grid), ptr(p2f_acc[0]), ptr(p2f_acc[1]),
                                   ptr(soft_colors), ptr(pooled), N, F, TS, *sc, flags, bg, ptr(ws),
                                   ws_bytes, _lib.stream_ptr(dev), ptr(vis))
@@ -219,6 +226,8 @@ def silhouette_op(face_vertices: torch.Tensor, image_size: int, near: float, far
     ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(IS, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, 1)
+    if getattr(_lib, "TAP", None) is not None:
+        _lib.TAP("silhouette_forward", dict(face_vertices=fv, image_size=IS))
     rc = L.umr_raster_forward(ptr(fv), None, None, None, None, None, None, ptr(alpha), ptr(pooled), N, F, 1, *sc, 2 | 1, None,
                               ptr(ws), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "umr_raster_forward(alpha only)")
@@ -322,6 +331,8 @@ def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textu
     ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
+    if getattr(_lib, "TAP", None) is not None:
+        _lib.TAP("raster_backward_alpha_geometry", dict(face_vertices=fv, textures=tex, grad_image=g, lean=lean, image_size=int(image_size)))
     # lean: aggrs_info is the forward's packed saved state, soft_colors an empty placeholder
     rc = L.umr_raster_backward(ptr(fv), ptr(tex), None if lean else ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
                                ptr(grad_textures), ptr(g),
