@@ -63,11 +63,14 @@ def parse():
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="capture the step in ONE HIP graph and time graph replays instead of eager launches: with --model 0 the "
-                         "render-and-compare step (every raster / loss kernel, forward and backward), otherwise (1 GPU) "
-                         "the whole training step incl. MeshNet, backward and Adam.  Default (-1): on for --gpus 1 -- the eager "
-                         "step's wall time is its Python / dispatcher enqueue time (config.eager_host_enqueue_ms_per_step), which "
-                         "depends on the box's host more than on the GPU; falls back to the eager step if the capture fails.  "
-                         "N > 1 runs eager (DDP's bucketed all-reduce is driven from autograd hooks)")
+                         "render-and-compare step (every raster / loss kernel, forward and backward; one GPU), otherwise "
+                         "the whole training step incl. MeshNet, backward, the bucketed RCCL gradient all-reduce (N > 1) and Adam.  "
+                         "Default (-1): on, at EVERY --gpus N -- the eager step's wall time is its Python / dispatcher enqueue time "
+                         "(config.eager_host_enqueue_ms_per_step), which depends on the box's host more than on the GPU; falls "
+                         "back to the eager step if the capture fails (all ranks together; the line then says hip_graph: false)")
+    ap.add_argument("--grad-sync", default="buckets", choices=["buckets", "ddp"],
+                    help="N > 1: `buckets` = umr_amd.parallel.BucketedGradSync (64 MB buckets all-reduced from gradient hooks while "
+                         "backward runs; capturable); `ddp` = torch DistributedDataParallel (eager only: implies --graph 0)")
     ap.add_argument("--hot-path-sub", type=int, default=-1,
                     help="1: also time the render-and-compare step alone (the --model 0 --graph 1 measurement) in this process and "
                          "attach it as config.hot_path_images_per_s / hot_path_ms_per_step; default: on for the --gpus 1 train_s1 "
@@ -150,11 +153,13 @@ def raster_launch_times(dev, fv, fv_sil, iters=20, tex=None, g_tex=None, seed=0,
                 sc.backward(g_tex)
             a.backward(g_sil)
         torch.cuda.synchronize()
+    alg = out.setdefault("_alg_bytes", {})       # algorithmic bytes per launch, as the library accounts them (raster.hip: ProfScope)
     for name, k in (("textured_forward_p2f_vis_pool_N%d" % N, 0), ("texel_gradient_backward_N%d" % N, 1),
                     ("silhouette_forward_N%d" % M, 2), ("silhouette_backward_N%d" % M, 3)):
-        ms, n, _ = _lib.profile_collect(k)
+        ms, n, nbytes = _lib.profile_collect(k)
         if n:
             out[name] = round(1e3 * ms / n, 1)
+            alg[name] = nbytes / n
     # the shared mask / texture render of the same views: its ONE backward pass (alpha gradient -> vertices, rgb -> texels),
     # which replaces a texel-gradient backward + a silhouette backward -- with the saved state packed (lean_state: what
     # the training steps run; its forward writes nothing else at full resolution) and with the reference's planes
@@ -170,10 +175,25 @@ def raster_launch_times(dev, fv, fv_sil, iters=20, tex=None, g_tex=None, seed=0,
             torch.cuda.synchronize()
         ms, n, nbytes = _lib.profile_collect(1)
         out["shared_render_backward_one_pass%s_N%d" % (tag, N)] = round(1e3 * ms / max(n, 1), 1)
+        alg["shared_render_backward_one_pass%s_N%d" % (tag, N)] = nbytes / max(n, 1)
         if lean:
-            out["_one_pass_alg_bytes_per_launch"] = nbytes / max(n, 1)
-            ms, n, _ = _lib.profile_collect(0)
+            ms, n, nbytes = _lib.profile_collect(0)
             out["shared_render_forward_packed_state_N%d" % N] = round(1e3 * ms / max(n, 1), 1)
+            alg["shared_render_forward_packed_state_N%d" % N] = nbytes / max(n, 1)
+    # the vertex-gradient-only backward of a textured render (train_s2's unseen-view and part renders: textures detached)
+    tex_d = tex.detach()
+    for phase in range(2):
+        if phase:
+            _lib.profile_collect(0); _lib.profile_collect(1)
+        for _ in range(iters if phase else 2):
+            fv_sh.grad = None
+            UF.soft_rasterize(fv_sh, tex_d, IS, [0, 0, 0], 1, 100, True, 1e-3, 1e-5, 'euclidean', 1e-10, 1e-4, 'softmax', 'prod', 'surface',
+                              pool=True, need_p2f=False)[0].backward(g_tex)
+        torch.cuda.synchronize()
+    ms, n, nbytes = _lib.profile_collect(1)
+    out["vertex_gradient_backward_N%d" % N] = round(1e3 * ms / max(n, 1), 1)
+    alg["vertex_gradient_backward_N%d" % N] = nbytes / max(n, 1)
+    _lib.profile_collect(0)
     _lib.profile_enable(False)
     return out
 
@@ -390,6 +410,9 @@ def main(device=None, backend="nccl"):
             else:                       # several ranks cannot agree on a random port by themselves
                 raise SystemExit("bench.py: WORLD_SIZE=%d but no MASTER_PORT in the environment: start the ranks with torchrun / "
                                  "`python bench.py --gpus N` (which picks a free port), or pass --master-port" % world)
+        # (graph capture of the step's collectives: no asynchronous error handling from the watchdog thread, as torch's notes on
+        # CUDA graphs with NCCL ask for)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 device_id=(dev if dev.type == "cuda" else None))   # "nccl" = RCCL on ROCm
 
@@ -408,8 +431,10 @@ def main(device=None, backend="nccl"):
         from umr_amd.model import build_training_step
         return build_training_step(tv, faces, args, dev, 2 if args.force_ddp else world)
 
-    if args.graph < 0:          # default: graph replay on one GPU (device runs only: the CPU suite's emulator has no graphs)
-        args.graph = 1 if (world == 1 and dev.type == "cuda" and not args.force_ddp) else 0
+    if args.grad_sync == "ddp" and (world > 1 or args.force_ddp):
+        args.graph = 0
+    if args.graph < 0:          # default: graph replay at every N (device runs only: the CPU suite's emulator has no graphs)
+        args.graph = 1 if dev.type == "cuda" else 0
     step_fn = None
     check_replay = None
     if args.workload == "s2":
@@ -422,7 +447,7 @@ def main(device=None, backend="nccl"):
     whole_graph = None
     eager_host_ms = None
     early_prof = None
-    if args.graph and use_model and world == 1:
+    if args.graph and use_model:
         # The WHOLE training step -- distance transform, MeshNet forward, every raster / loss kernel, backward, fused Adam with its
         # on-device learning-rate schedule -- captured once into one HIP graph and replayed: the eager step's host enqueue time
         # (config.eager_host_enqueue_ms_per_step) leaves the timed region.  Same recipe as the hot-path capture
@@ -433,8 +458,13 @@ def main(device=None, backend="nccl"):
         side.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(side):
-                for _ in range(max(3, args.warmup)):
+                n_w = max(3, args.warmup)
+                for i_ in range(n_w):
+                    if i_ == n_w - 3:                    # what the eager step costs the HOST (enqueue only), over the last three
+                        torch.cuda.synchronize()         # warm-up steps: profiling off, queue empty at the start
+                        t_e = time.perf_counter()
                     eager_step()
+                eager_host_ms = 1e3 * (time.perf_counter() - t_e) / 3
                 torch.cuda.synchronize()
                 # ... these five eager steps are also a FIRST roofline pass (the library's HIP events around the raster main
                 # kernels): training has barely moved the meshes yet, so the figures repeat from run to run, which the pass after
@@ -442,15 +472,16 @@ def main(device=None, backend="nccl"):
                 _lib.profile_enable(True)
                 for k in range(4):
                     _lib.profile_collect(k)
-                t_e = time.perf_counter()            # what the eager step costs the HOST (enqueue only; drained afterwards)
                 for _ in range(5):
                     eager_step()
-                eager_host_ms = 1e3 * (time.perf_counter() - t_e) / 5
                 torch.cuda.synchronize()
                 _lib.profile_enable(False)
                 early_prof = {k: _lib.profile_collect(k) for k in range(4)}
                 whole_graph = torch.cuda.CUDAGraph()
-                with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(whole_graph, stream=side):
+                # (with a process group: its watchdog thread polls events of earlier collectives -- only THIS thread's calls
+                # belong to the capture)
+                mode = {"capture_error_mode": "thread_local"} if (world > 1 or args.force_ddp) else {}
+                with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(whole_graph, stream=side, **mode):
                     static_loss = eager_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
@@ -467,6 +498,14 @@ def main(device=None, backend="nccl"):
             sys.stderr.write("bench.py: whole-step HIP-graph capture failed (%s: %s); timing the eager step\n" % (type(ex).__name__, ex))
             whole_graph = None
             torch.cuda.synchronize()
+        if world > 1:               # every rank replays, or none does
+            import torch.distributed as dist
+            ok_all = torch.tensor([1.0 if whole_graph is not None else 0.0], device=dev)
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+            if whole_graph is not None and not bool(ok_all.item()):
+                sys.stderr.write("bench.py: another rank could not capture the step; rank %d times the eager step too\n" % rank)
+                whole_graph = None
+        if whole_graph is None:
             args.graph = 0
             step_fn = build_step()
 
@@ -626,7 +665,7 @@ def main(device=None, backend="nccl"):
             traffic = tj.get("raster_backward_bytes_per_launch")
             traffic_note = "PMC FETCH_SIZE (x%.2f calibrated) + WRITE_SIZE per launch, tools/collect_traffic.sh on build %s" % (
                 tj.get("calibration", {}).get("fetch_correction_factor", 2.0), tj.get("build_id"))
-            for kname, key in (("k_raster_backward_fm<1", "backward"), ("k_raster_backward_fm_ag<1", "backward"),
+            for kname, key in (("k_raster_backward_fm<1", "backward"), ("k_raster_backward_fm_ag<1", "backward"), ("k_raster_backward_fm_agp<1", "backward"),
                                ("k_raster_forward<1", "forward_kernel"), ("k_raster_forward<2", "silhouette_forward"),
                                ("k_raster_backward_fm<2", "silhouette_backward"), ("k_raster_backward_fm_quads<2", "silhouette_backward")):
                 for kn, e in tj.get("kernels", {}).items():
@@ -684,21 +723,60 @@ def main(device=None, backend="nccl"):
                         "hip_graph_scope": ("whole training step (network + losses + Adam)" if whole_graph is not None else
                                             ("render-and-compare step" if (args.graph and not use_model and world == 1) else None)),
                         "hot_path_loss_spread": loss_spread}, **rccl),
-        # dominant raster-backward kernel of the step: the ONE backward pass of the shared mask / texture render (alpha gradient ->
-        # vertices, rgb gradient -> texels, pooled gradient in; with --share-mask-render 0 the texel-gradient-only backward).
-        # `achieved` = algorithmic bytes of THAT variant (HISTORY.md 4.6: SURVEY 8d's rule -- each op-boundary buffer the
-        # variant touches, once) / its mean HIP-event duration over the profile pass.
-        # `valu`: the resource that actually binds these kernels (HISTORY.md 4.6) -- issued wave64 VALU instructions per launch,
-        # the share of their lanes that was active, and the issue rate against the fp32 vector peak (1228.9 G wave-instr/s),
-        # from SQ PMC passes of this command on this build (profiles/traffic.json; absent when that file is stale).
-        "roofline": dict({"bound": "hbm", "kernel": ("k_raster_backward_fm_agp (shared render, packed saved state: d alpha -> vertices, d rgb -> texels)" if args.share_mask_render else
-                                     "k_raster_backward_fm (textured render, texel gradients only)"), "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_note, "valu": valu.get("backward")},
-                         **kernel_line(1),
-                         forward_kernel=dict(kernel_line(0), valu=valu.get("forward_kernel")),
-                         silhouette_forward=dict(kernel_line(2), valu=valu.get("silhouette_forward")),
-                         silhouette_backward=dict(kernel_line(3), valu=valu.get("silhouette_backward"))),
     }
+    # ---- roofline -------------------------------------------------------------------------------------------------------------
+    # Dominant raster-backward kernel of the step: the ONE backward pass of the shared mask / texture render (alpha gradient ->
+    # vertices, rgb gradient -> texels, pooled gradient in; with --share-mask-render 0 the texel-gradient-only backward).
+    # `achieved` = algorithmic bytes of THAT variant (HISTORY.md 4.6: SURVEY 8d's rule -- each op-boundary buffer the variant
+    # touches, once) / its mean HIP-event duration.  Round 6: the durations `avg_us / achieved / frac` are built from come from
+    # a DETERMINISTIC pass -- the same kernel, 20 launches, on the frozen captures of what the training step really renders
+    # (profiles/scenes/live_s1_*.npz, mean over the scenes; per scene and for the regular SURVEY 8d scene under `scenes`) -- and
+    # repeat from run to run; what THIS run's trajectory happened to render at its profile pass (+-40 % between runs of one build:
+    # float-atomic summation order steers a GAN-driven trajectory) stays on the line as `live`.
+    # `valu`: the resource that actually binds these kernels (HISTORY.md 4.6) -- issued wave64 VALU instructions per launch,
+    # the share of their lanes that was active, and the issue rate against the fp32 vector peak (1228.9 G wave-instr/s),
+    # from SQ PMC passes of this command on this build (profiles/traffic.json; absent when that file is stale).
+    scenes = {}
+    if dev.type == "cuda" and args.fixed_scene and args.workload == "s1" and args.image_size == 256 and args.subdivide == 3:
+        for name_, path_ in frozen_scenes():
+            scenes[name_] = frozen_scene_kernel_times(dev, path_)
+        scenes["survey_8d"] = fixed_scene_kernel_times(dev)
+    live_names = [n_ for n_ in scenes if n_ != "survey_8d"]
+    det_names = live_names or [n_ for n_ in scenes]
+
+    def det_line(prefix, live_k):
+        """Deterministic figure of the kernel whose scene-timing key starts with `prefix` (mean over the frozen live scenes, or the
+        8d scene when no capture is committed) + the in-step figure of library profile slot `live_k` as `live`."""
+        us, nbytes = [], []
+        for n_ in det_names:
+            for key_, v_ in scenes[n_].items():
+                if key_.startswith(prefix) and not key_.startswith("_") and "planar" not in key_:
+                    us.append(v_); nbytes.append(scenes[n_]["_alg_bytes"][key_])
+        line = {"live": kernel_line(live_k)}
+        if us:
+            avg, b_ = sum(us) / len(us), sum(nbytes) / len(nbytes)
+            gbs = b_ / 1e9 / (avg / 1e6)
+            line.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_us": avg, "alg_bytes_per_launch": b_,
+                         "launches": 20 * len(us), "source": "frozen scenes " + ", ".join(det_names)})
+        else:               # nothing deterministic to show (other workload / CPU emulation): the live figures
+            line.update(kernel_line(live_k), source="this run's profile pass (no frozen scene for this workload)")
+        return line
+
+    bwd_prefix = "shared_render_backward_one_pass" if args.share_mask_render else "texel_gradient_backward"
+    fwd_prefix = "shared_render_forward_packed_state" if args.share_mask_render else "textured_forward"
+    out["roofline"] = dict({"bound": "hbm", "kernel": ("k_raster_backward_fm_agp (shared render, packed saved state: d alpha -> vertices, d rgb -> texels)" if args.share_mask_render else
+                                     "k_raster_backward_fm (textured render, texel gradients only)"), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "traffic": traffic, "traffic_source": traffic_note, "valu": valu.get("backward")},
+                           **det_line(bwd_prefix, 1),
+                           forward_kernel=dict(det_line(fwd_prefix, 0), valu=valu.get("forward_kernel")),
+                           silhouette_forward=dict(det_line("silhouette_forward", 2), valu=valu.get("silhouette_forward")),
+                           silhouette_backward=dict(det_line("silhouette_backward", 3), valu=valu.get("silhouette_backward")))
+    if scenes:
+        out["roofline"]["scenes"] = {n_: {k_: v_ for k_, v_ in d_.items() if not k_.startswith("_")} for n_, d_ in scenes.items()}
+        out["roofline"]["scenes_note"] = ("us per launch, library-owned HIP events, 20 launches each; live_s1_*: projected face vertices of the "
+                                          "16 + 16 views a default bench.py run rendered at step ~57 (bench.py --capture-scene); survey_8d: "
+                                          "16 (32) x 1280-face icospheres, IS 512, TS 36, seed 0")
+
     # the step's raster launches together: summed HIP-event time of the raster main kernels per step of the profile pass
     n_prof = max(1, args.profile_steps)
     out["roofline"]["raster_kernels_us_per_step"] = round(1e3 * sum(prof[k][0] for k in range(4)) / n_prof, 1)
@@ -709,8 +787,8 @@ def main(device=None, backend="nccl"):
             out["config"].update(hot_path_submeasure(args, dev))
         except (Exception, SystemExit) as ex:     # noqa: BLE001 -- a sub-measurement: report, keep the headline
             out["config"]["hot_path_error"] = "%s: %s" % (type(ex).__name__, ex)
-    if dev.type == "cuda" and args.fixed_scene:
-        out["roofline"]["fixed_scene_us"] = dict(fixed_scene_kernel_times(dev),
+    if "survey_8d" in scenes:       # (kept under its round-5 name as well)
+        out["roofline"]["fixed_scene_us"] = dict(out["roofline"]["scenes"]["survey_8d"],
                                                  scene="SURVEY 8d: 16 (32) x 1280-face icospheres, IS 512, TS 36, seed 0 -- identical every run")
     want_cpu = (world == 1 and args.workload == "s1") if args.cpu_baseline < 0 else bool(args.cpu_baseline)
     if want_cpu:

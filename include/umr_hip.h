@@ -134,6 +134,9 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
 #define UMR_BWD_PACKED_STATE 8   /* with UMR_BWD_ALPHA_GEOMETRY: `aggrs_info` is the packed saved state a UMR_RASTER_PACKED_STATE
                                    forward wrote (see there); soft_colors is not read (may be NULL).  Same gradients, bit for bit,
                                    as the planar call on the same render */
+#define UMR_BWD_REUSE_WORKSPACE 16 /* `workspace` is the buffer the umr_raster_forward[_vis] call of the SAME faces, N, F, image_size
+                                   and scalars filled, untouched since: its face records and bounding boxes are read, not rebuilt
+                                   (one small launch less per backward; the ABI stays stateless without the flag) */
 
 /* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins, the backward's
  * start order).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst

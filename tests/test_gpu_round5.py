@@ -218,13 +218,16 @@ def test_lean_shared_render_step_equals_the_planar_one():
 
 @pytest.mark.parametrize("workload", ["s1", "s2"])
 def test_whole_training_step_replays_from_a_hip_graph(workload):
-    """What `bench.py --gpus 1` times by default: the WHOLE training step (distance transform, MeshNet, every raster / loss kernel,
+    """What `bench.py` times by default: the WHOLE training step (distance transform, MeshNet, every raster / loss kernel,
     backward, capturable fused Adam with its on-device learning-rate schedule) captured into one HIP graph and replayed, for
-    train_s1 and train_s2.  A replay must BE the training step: from one saved state (parameters, buffers, Adam moments and step
-    counters, schedule counter) the replay's loss is the eager step's up to the latent-noise sample (see below), the replay moves the parameters, and the next
-    replay is another step.
-    (Whole trajectories cannot be compared: Adam's first updates are +-lr whatever the gradient's size, so summation-order noise
-    flips update signs and two EAGER runs from one seed are 4 % apart in loss by step 2.)"""
+    train_s1 and train_s2.  A replay must BE the training step (nnutils/train_utils.py:172-194: forward, backward, Adam, schedule):
+    from ONE saved state -- parameters, buffers, Adam moments and step counters, schedule counter AND the device generator's
+    state, so that the encoder's latent noise (cub_mesh.py:103-107) and train_s2's camera sampling (:358-359) draw the same
+    numbers: a graph replay consumes the Philox stream from the generator's current offset exactly as the eager ops do -- a replay
+    and an eager step must leave the same loss, the same Adam moments and the same parameters, up to the summation-order noise
+    of the step's float atomics (p2f, IoU sums, MIOpen's backward-weight kernels).  A capture that dropped one term's backward,
+    froze Adam's moments or skipped the schedule fails the per-tensor comparisons; the next replay must be another step.
+    (Whole trajectories cannot be compared: two EAGER runs from one seed are 4 % apart in loss by step 2.)"""
     import argparse
     from umr_amd import model as M
     from umr_amd.synthetic import make_s1_inputs
@@ -238,13 +241,24 @@ def test_whole_training_step_replays_from_a_hip_graph(workload):
     else:
         tv, faces, _, _ = make_s1_inputs(a["batch"], a["image_size"], a["subdivide"], seed=100, device=dev)
         step = M.build_training_step(tv, faces, args, dev, 1)
+    replay_equals_eager(step, dev, workload)
+
+
+LOSS_BOUND, MOMENT_BOUND, PARAM_BOUND = 1e-3, 2e-2, 0.3    # (set from the figures the MI355X measured; see the test's print)
+
+
+def replay_equals_eager(step, dev, tag, graph_kwargs=None):
+    """Capture `step` (a build_training_step[_s2] closure) into one HIP graph after four eager steps and check that a replay and an
+    eager step from the same saved state (incl. the device generator's) leave the same loss, Adam moments and parameters."""
     model, opt = step.model, step.opt
 
-    def tensors():      # every piece of state a step reads and writes, in a fixed order
-        out = list(model.parameters()) + list(model.buffers()) + [step.it_dev]
-        for st in opt.state.values():
-            out += [v for _, v in sorted(st.items()) if torch.is_tensor(v)]
-        return out + [g["lr"] for g in opt.param_groups if torch.is_tensor(g["lr"])]
+    def named_state():      # every piece of state a step reads and writes, by name, in a fixed order
+        out = [("param:" + n, p) for n, p in model.named_parameters()] + [("buffer:" + n, b) for n, b in model.named_buffers()]
+        out.append(("schedule_counter", step.it_dev))
+        names = {id(p): n for n, p in model.named_parameters()}
+        for p, st in opt.state.items():
+            out += [("adam:%s:%s" % (names[id(p)], k), v) for k, v in sorted(st.items()) if torch.is_tensor(v)]
+        return out + [("lr:%d" % i, g["lr"]) for i, g in enumerate(opt.param_groups) if torch.is_tensor(g["lr"])]
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -252,25 +266,77 @@ def test_whole_training_step_replays_from_a_hip_graph(workload):
         warm = [float(step()) for _ in range(4)]
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, stream=side):
+        with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, stream=side, **(graph_kwargs or {})):
             static_loss = step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert all(math.isfinite(x) for x in warm)
-    saved = [t.detach().clone() for t in tensors()]
+    state = named_state()
+    saved = [t.detach().clone() for _, t in state]
+    rng = torch.cuda.get_rng_state(dev)
     g.replay()
     torch.cuda.synchronize()
     loss_replay = float(static_loss)
-    moved = max(float((t.detach() - s).abs().max()) for t, s in zip(list(model.parameters()), saved))
-    assert moved > 0                                   # the replay trained
+    after_replay = [t.detach().clone() for _, t in state]
     with torch.no_grad():
-        for t, s in zip(tensors(), saved):
-            t.copy_(s)
-    loss_eager = float(step())                         # the same step, eager, from the same state
-    # (not bit-level: the encoder draws its latent noise from the device generator, whose Philox offset a graph replay and an eager
-    # step advance differently -- another sample of the same distribution: measured 0.7 % apart; a broken capture is NaN, constant
-    # or far off)
-    assert math.isfinite(loss_replay) and abs(loss_replay - loss_eager) <= 5e-2 * max(abs(loss_eager), 1.0), (loss_replay, loss_eager)
+        for (_, t), s_ in zip(state, saved):
+            t.copy_(s_)
+    torch.cuda.set_rng_state(rng, dev)
+    loss_eager = float(step())                         # the same step, eager, from the same state and the same random stream
+    torch.cuda.synchronize()
+    after_eager = [t.detach().clone() for _, t in state]
+    worst, still, bad, noise = {}, 0, [], 0
+    # Gradient scale per parameter = its first moment after the eager step.  A parameter whose gradient is analytically zero -- the
+    # bias of a convolution / linear layer in front of a BatchNorm, 280 of the 700 state tensors here -- holds pure rounding noise
+    # (1e-10 of the largest gradient): its moments differ by O(1) RELATIVE between any two runs and Adam turns them into +-lr
+    # steps of random sign.  Such tensors (first moment below 1e-5 of the model's largest) are counted, not compared.
+    names = [n for n, _ in state]
+    idx = {n: i for i, n in enumerate(names)}
+    gscale = {n[len("adam:"):-len(":exp_avg")]: float(after_eager[i].abs().max()) for n, i in idx.items() if n.startswith("adam:") and n.endswith(":exp_avg")}
+    gmax = max(gscale.values())
+    assert gmax > 0
+    table = []
+    for (name, _), s_, r, e in zip(state, saved, after_replay, after_eager):
+        r, e, s_ = r.double(), e.double(), s_.double()
+        kind = name.split(":")[0] + (":" + name.split(":")[-1] if name.startswith("adam") else "")
+        pname = name[len("param:"):] if name.startswith("param:") else (name[len("adam:"):name.rindex(":")] if name.startswith("adam:") else None)
+        if pname is not None and gscale.get(pname, gmax) < 1e-5 * gmax and not name.endswith(":step"):
+            noise += 1
+            continue
+        if name.startswith("param"):
+            # the UPDATE the step made, as a vector (relative L2) per tensor
+            du_r, du_e = r - s_, e - s_
+            if float(du_e.abs().max()) == 0:      # frozen, or its gradient is identically zero (the unused probability head of the
+                assert float(du_r.abs().max()) == 0, name + ": moved by the replay, not by the eager step"   # single-camera net)
+                still += 1
+                continue
+            assert float(du_r.abs().max()) > 0, name + ": the replay did not move this parameter"
+            err = float((du_r - du_e).norm() / du_e.norm())
+            bound = PARAM_BOUND
+        elif name.startswith("adam") and name.endswith(("exp_avg", "exp_avg_sq")):
+            # the moments -- linear / quadratic in the gradient -- element by element against the tensor's scale
+            scale = float(e.abs().max())
+            err = float((r - e).abs().max()) / scale if scale > 0 else float((r - e).abs().max())
+            bound = MOMENT_BOUND
+            assert float((e - s_).abs().max()) > 0 or float(e.abs().max()) == 0, name + ": moment did not move"
+        else:       # step counters, schedule counter, learning rate, BatchNorm statistics: the same numbers
+            scale = max(float(e.abs().max()), 1e-30)
+            err = float((r - e).abs().max()) / scale
+            bound = 1e-5
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        table.append((err / bound, name, err))
+        if not err <= bound:
+            bad.append("%s: replay vs eager %.3e > %.1e" % (name, err, bound))
+    table.sort(reverse=True)
+    print("[replay-vs-eager] closest to their bounds: " + "; ".join("%s %.2e" % (n, e_) for _, n, e_ in table[:6]))
+    assert noise <= len(state) // 2, "%d of %d tensors hold rounding noise only" % (noise, len(state))
+    print("[replay-vs-eager] %s loss %.7f / %.7f, worst relative differences %s" % (tag, loss_replay, loss_eager,
+                                                                                      {k: "%.2e" % v for k, v in sorted(worst.items())}))
+    assert not bad, "%d of %d state tensors differ: %s" % (len(bad), len(state), "; ".join(bad[:8]))
+    assert math.isfinite(loss_replay) and abs(loss_replay - loss_eager) <= LOSS_BOUND * max(abs(loss_eager), 1.0), (loss_replay, loss_eager)
+    assert still <= len(state) // 10, "%d parameters did not move" % still
     g.replay(); torch.cuda.synchronize()
     nxt = float(static_loss)
     assert math.isfinite(nxt) and nxt != loss_replay   # ... and the next replay is another step
+
+

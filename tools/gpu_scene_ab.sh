@@ -18,7 +18,7 @@ import json, sys, re
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
 short = lambda k: {"textured_forward_p2f_vis_pool": "fwd", "texel_gradient_backward": "bwd_tex", "silhouette_forward": "sil_fwd", "silhouette_backward": "sil_bwd",
                    "shared_render_backward_one_pass": "AGP", "shared_render_forward_packed_state": "fwd_pk",
-                   "shared_render_backward_one_pass_planar_state": "AG_planar"}.get(re.sub(r"_N\d+$", "", k), k[:9])
+                   "shared_render_backward_one_pass_planar_state": "AG_planar", "vertex_gradient_backward": "bwd_vert"}.get(re.sub(r"_N\d+$", "", k), k[:9])
 print("%-26s %-30s %-10s %s" % ("lib", "set", "scene", "us per launch"))
 for r in rows:
     print("%-26s %-30s %-10s " % (r["lib"][:26], r["set"][:30], r["scene"]) + " ".join("%s %.1f" % (short(k), v) for k, v in r["us_per_launch"].items()))

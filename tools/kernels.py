@@ -23,6 +23,6 @@ if __name__ == "__main__":
     sc = tuple(float(x) for x in os.environ.get("UMR_SCALE", "0.6 0.9").split())
     n = int(os.environ.get("UMR_N", "16"))          # views per launch (16: a train_s1 step; 128: train_s2's hypothesis render)
     r = bench.fixed_scene_kernel_times(torch.device("cuda:0"), it, sc, n)
-    r.pop("_one_pass_alg_bytes_per_launch", None)
+    r = {k: v for k, v in r.items() if not k.startswith("_")}
     print(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "build": _lib.build_id()[:12], "set": os.environ.get("UMR_DEBUG_SET", ""),
                       "scale": sc, "N": n, "us_per_launch": r}), flush=True)

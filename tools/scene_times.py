@@ -28,9 +28,9 @@ if __name__ == "__main__":
     for name, path in scenes:
         for rv in ([False, True] if real else [False]):
             r = bench.frozen_scene_kernel_times(dev, path, iters, real_values=rv)
-            r.pop("_one_pass_alg_bytes_per_launch", None)
+            r = {k: v for k, v in r.items() if not k.startswith("_")}
             print(json.dumps(dict(base, scene=name, values="captured" if rv else "seeded noise", us_per_launch=r)), flush=True)
     if not files:
         r = bench.fixed_scene_kernel_times(dev, iters)
-        r.pop("_one_pass_alg_bytes_per_launch", None)
+        r = {k: v for k, v in r.items() if not k.startswith("_")}
         print(json.dumps(dict(base, scene="survey_8d", values="seeded noise", us_per_launch=r)), flush=True)

@@ -42,11 +42,11 @@ int sb_cap_for(int F) { return F < SB_CAP ? F : SB_CAP; }
 size_t ws_sblist_bytes(int N, int F, int slots) { return (size_t)N * slots * sb_cap_for(F) * sizeof(int); }
 // Work-item lists of the face-major backward (k_face_order): per (mesh group, XCD) a list of gsz = G x F / 8 faces' items plus
 // up to order_extra(gsz) more from split faces, the slab pool of the split faces' partial sums (2 x extra units of SPLIT_UNIT
-// floats per list: extras + split faces <= 2 x extras) and their arrival counters.  Sized for the worst group size G (the
+// floats per list: extras + split faces <= 2 x extras) and the list of the split faces.  Sized for the worst group size G (the
 // "face_order_group" debug switch can only shrink G).
 int order_extra(int gsz) { return gsz / 4 + 16; }
 int order_group_for(int N, int F) { return std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / std::max(1, F / 8))); }
-struct OrderLayout { int G, groups, stride, extra, slabs_per_list; size_t order_bytes, ctr_bytes, slab_bytes, cost_bytes; };
+struct OrderLayout { int G, groups, stride, extra, slabs_per_list; size_t order_bytes, ctr_bytes, slab_bytes; };
 OrderLayout order_layout(int N, int F, int G) {
     OrderLayout L;
     L.G = G; L.groups = (N + G - 1) / G;
@@ -54,19 +54,22 @@ OrderLayout order_layout(int N, int F, int G) {
     L.extra = order_extra(gsz); L.stride = gsz + L.extra; L.slabs_per_list = 2 * L.extra;
     const size_t lists = (size_t)L.groups * 8;
     L.order_bytes = (lists * L.stride * sizeof(uint2) + 255) & ~(size_t)255;
-    L.ctr_bytes = (lists * L.slabs_per_list * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    L.ctr_bytes = (lists * (L.extra + 1) * sizeof(uint2) + 255) & ~(size_t)255;          // the split-face lists (k_split_reduce)
     L.slab_bytes = lists * L.slabs_per_list * SPLIT_UNIT * sizeof(float);
-    L.cost_bytes = ((size_t)N * F * sizeof(unsigned short) + 255) & ~(size_t)255;
     return L;
 }
 size_t ws_order_bytes(int N, int F) {
     size_t worst = 0;
     for (int G = 1; G <= order_group_for(N, F); ++G) {
         const OrderLayout L = order_layout(N, F, G);
-        worst = std::max(worst, L.order_bytes + L.ctr_bytes + L.slab_bytes + L.cost_bytes);
+        worst = std::max(worst, L.order_bytes + L.ctr_bytes + L.slab_bytes);
     }
     return worst;
 }
+int g_fm_runs = 0;               // umr_debug_set("fm_runs", r): runs of faces per XCD and mesh (fm_owned_face) for every face-major launch; 0 = automatic
+int g_fm_rotate = -1;            // umr_debug_set("fm_rotate", 0 | 1): mesh m's runs go to XCD (x + m) % 8 instead of x (item lists only); -1 = automatic
+int g_split_budget_div = 16;     // umr_debug_set("face_split_budget", d >= 4): a list may hold gsz / d + 16 extra items (<= the gsz / 4 + 16 the workspace
+                                 // is sized for); the lists are padded to that length, i.e. the launch carries that many workgroups that exit at once
 int g_face_split = SPLIT_T0;     // umr_debug_set("face_split", T): estimated work (4x4 sub-tiles) beyond which k_face_order splits a face
                                  // into several work items; 0 = never (one wave per face, round 5's form)
 int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping of the pixel-major kernels.  2 (default): XCD x takes
@@ -74,8 +77,10 @@ int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping 
                                  // (forward 3-7 % slower than 2 at N = 16: two whole meshes per XCD balance worse); 0: plain
                                  // blockIdx order (12-25 % slower: one mesh's records then live in all eight L2s)
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
-int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts its waves in index order,
-                                 // 1 = cost order for the texel-gradient-only variant (the one it pays for), 2 = for all variants
+int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts one wave per face in index order,
+                                 // 1 = work-item lists (k_face_order: heavy faces split) -- in cost order, heavy items first, for the light
+                                 // variants (texel gradients only, one pass, silhouette), in index order for the others --, 2 = cost
+                                 // order for all variants
 float g_thin_face_h = THIN_FACE_H;   // umr_debug_set("thin_face_h_1e6", h * 1e6): faces with a height below h screen units evaluate
                                      // inside pixels the reference's way (k_face_setup, bit 4 of the record's flags)
 bool g_exact_edges = true;           // umr_debug_set("exact_edges", 0 | 1): eval_pair's amb_thr = 20 sigma (see there).  On by default:
@@ -170,6 +175,9 @@ int umr_debug_set(const char *key, int value) {
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
     if (std::string(key) == "exact_edges") { g_exact_edges = value != 0; return UMR_OK; }
     if (std::string(key) == "thin_face_h_1e6") { g_thin_face_h = value < 0 ? THIN_FACE_H : 1e-6f * (float)value; return UMR_OK; }
+    if (std::string(key) == "fm_runs") { g_fm_runs = std::max(0, value); return UMR_OK; }
+    if (std::string(key) == "fm_rotate") { g_fm_rotate = value < 0 ? -1 : (value != 0); return UMR_OK; }
+    if (std::string(key) == "face_split_budget") { g_split_budget_div = std::max(4, value); return UMR_OK; }
     if (std::string(key) == "face_split") { g_face_split = value < 0 ? SPLIT_T0 : std::min(1 << 14, value); return UMR_OK; }   // (< 0: the default)
     if (std::string(key) == "face_order_group") { g_face_order_group = std::max(0, std::min(16, value)); return UMR_OK; }
     return UMR_ERR_ARG;
@@ -206,7 +214,7 @@ size_t umr_raster_workspace_bytes_for(int N, int F, int image_size) {
 size_t umr_raster_workspace_bytes(int N, int F) { return umr_raster_workspace_bytes_for(N, F, 0); }
 
 size_t umr_raster_state_bytes(int N, int image_size) {   // the packed saved state: 16 B per pixel (RasterArgs::state)
-    if (N <= 0 || image_size <= 0 || (image_size & 7)) return 0;
+    if (N <= 0 || image_size <= 0 || (image_size & 7) || image_size > 8192) return 0;
     return (size_t)N * image_size * image_size * (STATE_REC / 16) * sizeof(float);
 }
 
@@ -241,7 +249,8 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (alpha_only && ids_only) return UMR_ERR_ARG;
     if (ids_only && (func_id_rgb != 0 || !aggrs_info)) return UMR_ERR_ARG;
-    if (packed && (alpha_only || ids_only || func_id_rgb != 1 || !pooled_out || !background || !aggrs_info || (image_size & 7)))
+    // (the packed state is addressed with 32-bit byte offsets per mesh: 16 B x image_size^2 < 2^32)
+    if (packed && (alpha_only || ids_only || func_id_rgb != 1 || !pooled_out || !background || !aggrs_info || (image_size & 7) || image_size > 8192))
         return UMR_ERR_ARG;
     if (vis_ids && !visibility) return UMR_ERR_ARG;
     if (!faces || (!soft_colors && !ids_only && !packed) || !workspace) return UMR_ERR_ARG;
@@ -277,7 +286,7 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
     A.no_xcd_remap = g_xcd_remap == 1 ? 0 : (g_xcd_remap == 0 ? 1 : 2);
     const int total = N * F;
     UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, faces_info, (float4 *)workspace, (float *)A.rec, total,
-                                                      sqrtf(A.threshold), near_, far_, nullptr, 0, g_thin_face_h);
+                                                      sqrtf(A.threshold), near_, far_, g_thin_face_h);
     setup_bins(A, workspace, N, F, image_size, st);
     const int blocks = N * A.tiles_x * A.tiles_y;
     {
@@ -336,11 +345,12 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     // train_s1 / train_s2 (silhouette backward on the render's alpha plane + texel-only backward) in ONE pass over the pairs
     const bool alpha_geom = (grad_is_pooled & UMR_BWD_ALPHA_GEOMETRY) != 0;
     const bool packed = (grad_is_pooled & UMR_BWD_PACKED_STATE) != 0;    // aggrs_info = the forward's packed saved state
+    const bool reuse_ws = (grad_is_pooled & UMR_BWD_REUSE_WORKSPACE) != 0;
     const int tex_group = ((grad_is_pooled >> 8) & 0xffff) ? ((grad_is_pooled >> 8) & 0xffff) : 1;
     grad_is_pooled &= UMR_BWD_GRAD_POOLED;
     if (N > 0 && N % tex_group) return UMR_ERR_ARG;
     if (!faces || (!soft_colors && !packed) || !grad_soft_colors || !workspace) return UMR_ERR_ARG;
-    if (packed && (!alpha_geom || !aggrs_info || (image_size & 7))) return UMR_ERR_ARG;   // the one-pass kernel reads it, no other
+    if (packed && (!alpha_geom || !aggrs_info || (image_size & 7) || image_size > 8192)) return UMR_ERR_ARG;   // the one-pass kernel reads it, no other
     if (!alpha_only && (!textures || !aggrs_info)) return UMR_ERR_ARG;
     if (alpha_only && (need_grad_textures || !need_grad_faces)) return UMR_ERR_ARG;
     if ((need_grad_faces && !grad_faces) || (need_grad_textures && !grad_textures)) return UMR_ERR_ARG;
@@ -378,42 +388,59 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     // "bwd_pixel_major", or TS beyond the LDS accumulators) would send the rgb gradient into grad_faces: rejected, nothing
     // enqueued (soft_rasterize_cuda.cpp:122-129 raises on what it cannot do, it never returns other data)
     if (alpha_geom && !face_major) return UMR_ERR_ARG;
-    // Cost-ordered wave start (k_face_order).  Measured on MI355X, us per launch at N = 16 / 128 (F = 1280, IS = 512), index
-    // order -> ordered in groups of 16 | 8 meshes: texel gradients only 137.6 -> 122.3 | 129.7 and 814 -> 838 | 798; vertex +
-    // texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel: with 16 meshes' heavy
-    // faces in flight an XCD's 4 MB L2 no longer holds their state); silhouette unchanged.  So: texel-only variant only,
-    // one group when the launch has <= 16 meshes, groups of 8 otherwise.
+    // Work-item lists in cost order (k_face_order).  Measured on MI355X, us per launch at N = 16 / 128 (F = 1280, IS = 512), index
+    // order -> ordered in groups of 16 | 8 meshes, regular SURVEY 8d scene (round 3): texel gradients only 137.6 -> 122.3 | 129.7 and
+    // 814 -> 838 | 798; vertex + texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel:
+    // with 16 meshes' heavy faces in flight an XCD's 4 MB L2 no longer holds their state); silhouette unchanged there, but on the
+    // frozen captures of a training step's own geometry (round 6, profiles/scenes) 96.7 -> 73.6 and 83.6 -> 71.4.  So: the light
+    // variants, one group when the launch has <= 16 meshes, groups of 8 otherwise.
     const int order_mode = alpha_only ? 2 : (((!need_grad_faces || alpha_geom) && func_id_rgb == 1) ? 1 : 0);
-    const bool ordered = face_major && (g_face_order == 2 || (g_face_order == 1 && order_mode == 1)) && FM_WAVES == 1 &&
+    const bool sorted_items = g_face_order == 2 || order_mode != 0;
+    const bool ordered = face_major && g_face_order >= 1 && FM_WAVES == 1 &&
                          F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
     int G = order_group_for(N, F);
     if (g_face_order_group) G = std::min(G, g_face_order_group);
     const OrderLayout OL = order_layout(N, F, G);
     char *op = (char *)workspace + ws_order_offset(N, F, image_size);
     uint2 *order = (uint2 *)op;
-    unsigned long long *slab_ctr = (unsigned long long *)(op + OL.order_bytes);
+    uint2 *split_list = (uint2 *)(op + OL.order_bytes);
     float *slab = (float *)(op + OL.order_bytes + OL.ctr_bytes);
-    unsigned short *cost = (unsigned short *)(op + OL.order_bytes + OL.ctr_bytes + OL.slab_bytes);
-    UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
-                                                   sqrtf(A.threshold), near_, far_, ordered ? cost : nullptr, image_size, g_thin_face_h);
+    // the face records and bounding boxes: rebuilt here (the ABI is stateless), unless the caller hands back the workspace its
+    // forward call of the SAME faces / N / F / image_size / scalars filled (UMR_BWD_REUSE_WORKSPACE)
+    if (!reuse_ws)
+        UMR_LAUNCH(k_face_setup, (total + 63) / 64, 64, 0, st, faces, nullptr, (float4 *)workspace, (float *)A.rec, total,
+                                                       sqrtf(A.threshold), near_, far_, g_thin_face_h);
     // light variants at small N: four runs of faces per XCD instead of one (fm_owned_face)
     A.fm_split = (face_major && N <= 16 && (alpha_only || !need_grad_faces || alpha_geom) && F % 32 == 0) ? 4 : 1;
+    // the one-pass kernel: eight runs, and mesh m's runs rotated to XCD (x + m) % 8 -- a batch of similar poses then loads the XCDs
+    // alike (frozen training scenes 121 / 116 -> 117 / 109 us, SURVEY 8d scene 142 -> 140; the silhouette variant loses 3 %: not taken)
+    int rotate = g_fm_rotate;
+    if (face_major && alpha_geom && N <= 16 && F % 64 == 0 && g_fm_rotate < 0) { A.fm_split = 8; rotate = 1; }
+    if (rotate < 0) rotate = 0;
+    if (g_fm_runs > 0 && face_major && (F / 8) % g_fm_runs == 0) A.fm_split = g_fm_runs;
     int fm_blocks = N * ((F + FM_WAVES - 1) / FM_WAVES);
     if (ordered) {
         // a part's partial sums: 9 vertex gradients at [0, 9), 3 TS texel gradients from 16 -- in whole slab units
         const int part_floats = need_grad_textures ? 16 + 3 * TS : 16;
         const int units = (part_floats + SPLIT_UNIT - 1) / SPLIT_UNIT;
         OrderArgs O = {};
-        O.cost = cost; O.rec = A.rec; O.alpha = soft_colors; O.order = order; O.ctr = slab_ctr;
-        O.N = N; O.F = F; O.IS = image_size; O.G = G; O.mode = order_mode; O.run_split = A.fm_split;
-        O.stride = OL.stride; O.units_per_part = units;
-        O.X = OL.extra / units;                        // extra items this launch's lists may hold (its parts take `units` slab units each)
+        O.bbox = A.bbox; O.rec = A.rec; O.order = order; O.split = split_list;
+        O.alpha = alpha_only ? soft_colors : nullptr; O.state = packed ? aggrs_info : nullptr;
+        O.aggrs = (!alpha_only && !packed && func_id_rgb == 1) ? aggrs_info : nullptr;
+        O.far_ = far_; O.r_range = A.r_range; O.inv_gamma = A.inv_gamma;
+        O.N = N; O.F = F; O.IS = image_size; O.G = G; O.mode = order_mode; O.sorted = sorted_items ? 1 : 0; O.run_split = A.fm_split; O.rotate = rotate;
+        const int gsz = G * (F / 8);
+        const int extra_run = std::min(OL.extra, g_face_split > 0 ? gsz / g_split_budget_div + 16 : 0);   // (no split: no padding)
+        const int stride_run = gsz + extra_run;
+        O.stride = stride_run; O.units_per_part = units;
+        O.X_alloc = OL.extra;
+        O.X = extra_run / units;                       // extra items this launch's lists may hold (its parts take `units` slab units each)
         O.slabs_per_list = OL.slabs_per_list / units;
         O.T0 = g_face_split;
         UMR_LAUNCH(k_face_order, dim3(8, OL.groups), ORDER_THREADS, 0, st, O);
-        A.order = order; A.order_group = G; A.order_stride = OL.stride;
-        A.slab = slab; A.slab_ctr = slab_ctr; A.slab_stride = units * SPLIT_UNIT;
-        fm_blocks = OL.groups * 8 * OL.stride;
+        A.order = order; A.order_group = G; A.order_stride = stride_run;
+        A.slab = slab; A.slab_stride = units * SPLIT_UNIT;
+        fm_blocks = OL.groups * 8 * stride_run;
     }
     A.fm_blocks = fm_blocks;
     {
@@ -448,6 +475,13 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         } else if (alpha_geom) launch_backward_fm_ag(A, st);
         else if (func_id_rgb == 0) launch_backward_fm<0>(A, st);
         else launch_backward_fm<1>(A, st);
+    }
+    if (A.order && g_face_split > 0) {     // the split faces' partial sums -> their gradients, in part order
+        SplitReduceArgs R = {};
+        R.split = split_list; R.slab = slab; R.grad_faces = grad_faces; R.grad_textures = grad_textures;
+        R.F = F; R.TS = TS; R.G = G; R.X = OL.extra; R.slab_stride = A.slab_stride;
+        R.need_gf = need_grad_faces; R.need_gt = need_grad_textures;
+        UMR_LAUNCH(k_split_reduce, dim3(SPLIT_REDUCE_BLOCKS, OL.groups * 8), 64, 0, st, R);
     }
     return umr_launch_status();
 }

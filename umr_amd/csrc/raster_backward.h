@@ -82,7 +82,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
                             }
                         } else if (fc.front() || A.double_side) {
                             const float zn = div_r(A.far_ - zp, A.far_ - A.near_, A.r_range);
-                            const float ps = p.frag * __expf(fminf((zn - smax) * A.inv_gamma, 0.f)) * __builtin_amdgcn_rcpf(ssum);  // :608 (clamp: raster_backward_fm.h)
+                            const float ex_ = (zn - smax) * A.inv_gamma;
+                            const float ps = p.frag * __expf(ex_ > 0.f ? 0.f : ex_) * __builtin_amdgcn_rcpf(ssum);  // :608 (NaN-preserving clamp: raster_backward_fm.h)
                             tix = texel_index(q0, q1, A.R);
                             const float *tx = tex_n + ((size_t)f * TS + tix) * 3;
                             gt0 = ps * g0; gt1 = ps * g1; gt2 = ps * g2;
@@ -138,29 +139,38 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 // wave then runs for the whole launch on an otherwise empty chip (one-pass backward: 212 - 273 us on the live scenes against
 // 137 us on the regular SURVEY 8d scene, with fewer instructions issued).  This kernel, per XCD (each XCD keeps its contiguous
 // share of every mesh's faces -- the L2 locality of the saved state) and per group of `G` meshes,
-//   1. estimates every face's work: 4x4 sub-tiles under the dilated bbox; / 8 for faces the state cull will remove -- mode 1
-//      (texel gradients / one pass): back faces; mode 2 (silhouette): faces whose corners and centroid all sit on alpha == 1;
+//   1. estimates every face's work: 4x4 sub-tiles under the dilated bbox; / 8 for faces the state cull will remove -- at their
+//      corners and centroid alpha == 1 (mode 2: silhouette) or, for back faces, a nearer face's soft-max weight (mode 1: colour);
 //   2. SPLITS a face whose estimate exceeds T into parts = ceil(estimate / T) items (<= SPLIT_MAX_PARTS, <= its culling passes),
-//      each a contiguous share of the face's culling passes.  T = T0 << k with the smallest k whose extra items fit the list's
-//      budget X (so the launch grid and the slab pool have fixed sizes);
+//      each a contiguous share of the face's culling passes.  T = the smallest of T0 x {1, 1.25, 1.5, 2, 3, 4, 8, 16} whose extra
+//      items fit the list's budget X (so the launch grid and the slab pool have fixed sizes);
 //   3. sorts the ITEMS by descending work (counting sort, 1024 buckets; a part's key = the face's estimate / parts), so the
-//      heavy items of all meshes of the group start first and the launch drains on cheap ones; the list is padded with
-//      0xffffffff to its fixed length;
-//   4. zeroes the arrival counters of its slab range.
-// Neither order nor split changes WHICH pairs contribute; a split face's sum is formed part by part in part order by whichever
-// item arrives last (raster_backward_fm.h), so results do not depend on scheduling.
+//      heavy items of all meshes of the group start first and the launch drains on cheap ones -- or, for the variants that
+//      prefer their faces' index order (`sorted` 0), keeps that order with the parts of a split face side by side; the list is
+//      padded with 0xffffffff to its fixed length;
+//   4. lists the split faces (split[list][0] = their number, then {item word, first slab} each) for k_split_reduce, which runs
+//      after the main kernel and adds each split face's partial sums in part order.
+// Neither order nor split changes WHICH pairs contribute, and a split face's sum is formed in a fixed order: results do not
+// depend on scheduling.
 #define ORDER_KEYS 1024
 #define ORDER_MAX_ENTRIES 16384
 #define ORDER_THREADS 1024
 #define SPLIT_MAX_PARTS 32
-#define SPLIT_LEVELS 8          // thresholds tried: T0 << 0 .. T0 << 7, then "no split"
+#define SPLIT_LEVELS 8          // thresholds tried: T0 x {1, 1.25, 1.5, 2, 3, 4, 8, 16}, then "no split"
+__device__ __forceinline__ int split_threshold(int T0, int k) {
+    const int num[SPLIT_LEVELS] = {4, 5, 6, 8, 12, 16, 32, 64};
+    return max((max(T0, 1) * num[k]) >> 2, 1);
+}
 #define SPLIT_UNIT 128          // floats per slab unit (a part of the BASELINE variants -- 9 + 3 x 36 sums -- takes one)
 #ifndef SPLIT_T0
 #define SPLIT_T0 128            // estimated work (sub-tiles) one item may carry before its face is split
 #endif
 struct OrderArgs {
-    const unsigned short *cost; const float *rec; const float *alpha; uint2 *order; unsigned long long *ctr;
-    int N, F, IS, G, mode, run_split, stride, X, slabs_per_list, units_per_part, T0;
+    const float4 *bbox; const float *rec; uint2 *order; uint2 *split;   // split: [lists][X + 1]
+    const float *alpha;                       // silhouette launch: the alpha plane [N, IS, IS]
+    const float *state, *aggrs;               // colour launches: the packed saved state, or aggrs_info [N, 2, IS, IS]
+    float far_, r_range, inv_gamma;
+    int N, F, IS, G, mode, sorted, run_split, rotate, stride, X, X_alloc, slabs_per_list, units_per_part, T0;   // X <= X_alloc: this launch's budget of extra items
 };
 __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O) {
     __shared__ int s_hist[ORDER_KEYS];
@@ -168,44 +178,69 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
     __shared__ unsigned short s_key[ORDER_MAX_ENTRIES];
     __shared__ unsigned char s_np[ORDER_MAX_ENTRIES];
     __shared__ int s_ex[SPLIT_LEVELS];
-    __shared__ int s_slab, s_level;
+    __shared__ int s_slab, s_level, s_nsplit;
     const int xcd = blockIdx.x, g = blockIdx.y, F = O.F, IS = O.IS, per = F >> 3;
     const int m0 = g * O.G, gl = min(O.G, O.N - m0), E = gl * per;
     for (int k = threadIdx.x; k < ORDER_KEYS; k += ORDER_THREADS) s_hist[k] = 0;
     if (threadIdx.x < SPLIT_LEVELS) s_ex[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_slab = 0;
+    if (threadIdx.x == 0) { s_slab = 0; s_nsplit = 0; }
     __syncthreads();
     const float h = 0.5f * IS;
     int ex[SPLIT_LEVELS];
 #pragma unroll
     for (int k = 0; k < SPLIT_LEVELS; ++k) ex[k] = 0;
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
-        const int ml = e / per, f = fm_owned_face(xcd, e % per, per, O.run_split);
+        const int ml = e / per, f = fm_owned_face((xcd + (m0 + ml) * O.rotate) & 7, e % per, per, O.run_split);
         const size_t fi = (size_t)(m0 + ml) * F + f;
-        const unsigned c = O.cost[fi];                     // k_face_setup: sub-tiles under the bbox | front << 15
-        const int raw = (int)(c & 0x7fffu);
+        // work estimate: 4x4 sub-tiles under the dilated bbox (the window the wave will walk; NaN bounds: the whole image)
+        const float4 bb = O.bbox[fi];
+        int raw = 0x7fff;
+        if (bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w) {
+            const int px0 = max((int)floorf(bb.x * h + h - 0.5f) - 1, 0), px1 = min((int)ceilf(bb.y * h + h - 0.5f) + 1, IS - 1);
+            const int py0 = max((int)floorf(bb.z * h + h - 0.5f) - 1, 0), py1 = min((int)ceilf(bb.w * h + h - 0.5f) + 1, IS - 1);
+            raw = (px0 <= px1 && py0 <= py1) ? min(((px1 >> 2) - (px0 >> 2) + 1) * ((py1 >> 2) - (py0 >> 2) + 1), 0x7fff) : 0;
+        }
+        const unsigned c = (__float_as_int(O.rec[fi * REC + R_FLAGS]) & 32) ? 0x8000u : 0u;      // front-facing (k_face_setup)
         int nt = raw;
-        if (O.mode == 1 && !(c & 0x8000u)) nt >>= 3;
-        if (O.mode == 2 && nt > 0) {
+        bool order_eighth = false;
+        // Faces the state cull will (mostly) remove, judged at the face's corners and centroid with the kernels' own tests:
+        //  * silhouette launch (mode 2): alpha == 1.0f at all five -- g (1 - alpha) = 0 there;
+        //  * colour launches (mode 1), back faces only: the face is depth-dead at all five -- even its nearest depth lies >= 89
+        //    gamma behind the pixel's soft-max maximum, i.e. a nearer face covers it and its weight is 0.0f.
+        // A back face that sticks OUT of the silhouette (a spike of a half-trained mesh) is its own nearest surface: it is
+        // walked in full.  (Round 5 discounted every back face; on the captured training scenes such faces were the launch's tail.)
+        if (nt > 0 && (O.mode == 2 || (O.mode == 1 && !(c & 0x8000u))) && (O.alpha || O.state || O.aggrs)) {
             const float *r = O.rec + fi * REC;
-            const float *ap = O.alpha + (size_t)(m0 + ml) * IS * IS;
             const float cx[4] = {r[R_X0], r[R_X1], r[R_X2], (r[R_X0] + r[R_X1] + r[R_X2]) * (1.f / 3.f)};
             const float cy[4] = {r[R_Y0], r[R_Y1], r[R_Y2], (r[R_Y0] + r[R_Y1] + r[R_Y2]) * (1.f / 3.f)};
-            bool opaque = true;
+            const float zq = (O.far_ - fminf(fminf(r[R_Z0], r[R_Z1]), r[R_Z2])) * O.r_range;
+            bool removed = true;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const int xi = min(max((int)(cx[c4] * h + h), 0), IS - 1), yi = min(max((int)(cy[c4] * h + h), 0), IS - 1);
-                opaque &= ap[(size_t)(IS - 1 - yi) * IS + xi] == 1.f;
+                const int xi = min(max((int)(cx[c4] * h + h), 0), IS - 1), row = IS - 1 - min(max((int)(cy[c4] * h + h), 0), IS - 1);
+                const size_t n_ = (size_t)(m0 + ml), pn = (size_t)row * IS + xi;
+                if (O.mode == 2) removed &= O.alpha[n_ * IS * IS + pn] == 1.f;
+                else {
+                    // the pixel's soft-max maximum: packed state, [16 + 4 (y & 3) + (x & 3)] of its 4x4 tile's record, or plane 1 of aggrs_info
+                    const float smax = O.state ? O.state[(n_ * (IS >> 2) * (IS >> 2) + (size_t)(row >> 2) * (IS >> 2) + (xi >> 2)) * STATE_REC +
+                                                         STATE_O_MAX + (row & 3) * 4 + (xi & 3)]
+                                               : O.aggrs[(n_ * 2 + 1) * IS * IS + pn];
+                    removed &= (zq - smax) * O.inv_gamma < -89.f;
+                }
             }
-            if (opaque) nt >>= 3;
+            if (removed) nt >>= 3;
+            // (a back face that is NOT removed at all five probes: split by its full estimate -- it may be a spike --, but started
+            // where round 5's rule puts it, an eighth: on regular meshes such faces sit near the silhouette's rim and the quad-level
+            // state cull still removes most of them; measured on the SURVEY 8d scene, one-pass backward: 142 -> 137 us)
+            else if (O.mode == 1) order_eighth = true;
         }
         // a face cannot have more parts than culling passes (64 candidate sub-tiles each)
         const int lim = max(1, min(SPLIT_MAX_PARTS, (raw + 63) >> 6));
-        s_key[e] = (unsigned short)nt;
+        s_key[e] = (unsigned short)(nt | (order_eighth ? 0x8000 : 0));
         s_np[e] = (unsigned char)lim;
 #pragma unroll
         for (int k = 0; k < SPLIT_LEVELS; ++k) {
-            const int T = max(O.T0, 1) << k;
+            const int T = split_threshold(O.T0, k);
             ex[k] += min(max((nt + T - 1) / T, 1), lim) - 1;
         }
     }
@@ -225,10 +260,13 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
     __syncthreads();
     const int level = s_level;
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
-        const int nt = s_key[e], lim = s_np[e];
+        const int nt = s_key[e] & 0x7fff, lim = s_np[e];
         int np = 1;
-        if (level < SPLIT_LEVELS) { const int T = O.T0 << level; np = min(max((nt + T - 1) / T, 1), lim); }
-        const int key = min((nt + np - 1) / np, ORDER_KEYS - 1);
+        if (level < SPLIT_LEVELS) { const int T = split_threshold(O.T0, level); np = min(max((nt + T - 1) / T, 1), lim); }
+        const int nt_order = (s_key[e] & 0x8000) ? nt >> 3 : nt;
+        // sorted: heavy items first (a part's key = its share of the face's estimate); else INDEX order, bucket by bucket (the
+        // variants whose waves read 28 B of state per pixel want their faces' spatial order more than a balanced drain)
+        const int key = O.sorted ? min((nt_order + np - 1) / np, ORDER_KEYS - 1) : ORDER_KEYS - 1 - (int)(((long long)e * ORDER_KEYS) / E);
         s_key[e] = (unsigned short)key;
         s_np[e] = (unsigned char)np;
         atomicAdd(&s_hist[key], np);
@@ -254,17 +292,61 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
     const size_t list = (size_t)g * 8 + xcd;
     uint2 *out = O.order + list * (size_t)O.stride;
     const unsigned slab0 = (unsigned)(list * (size_t)O.slabs_per_list);
+    uint2 *split_list = O.split + list * (size_t)(O.X_alloc + 1);
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
         const int np = s_np[e];
         const int pos = atomicAdd(&s_hist[s_key[e]], np);
-        const unsigned code = ((unsigned)(np - 1) << 21) | ((unsigned)(e / per) << 16) | (unsigned)fm_owned_face(xcd, e % per, per, O.run_split);
+        const unsigned code = ((unsigned)(np - 1) << 21) | ((unsigned)(e / per) << 16) | (unsigned)fm_owned_face((xcd + (m0 + e / per) * O.rotate) & 7, e % per, per, O.run_split);
         unsigned slab = 0;
-        if (np > 1) slab = slab0 + (unsigned)atomicAdd(&s_slab, np);
+        if (np > 1) {
+            slab = slab0 + (unsigned)atomicAdd(&s_slab, np);
+            split_list[1 + atomicAdd(&s_nsplit, 1)] = make_uint2(code, slab);
+        }
         for (int p = 0; p < np; ++p) out[pos + p] = make_uint2(code | ((unsigned)p << 26), slab);
     }
     const int items = E + (level < SPLIT_LEVELS ? s_ex[level] : 0);
     for (int i = items + (int)threadIdx.x; i < O.stride; i += ORDER_THREADS) out[i] = make_uint2(0xffffffffu, 0u);
-    for (int i = threadIdx.x; i < O.slabs_per_list; i += ORDER_THREADS) O.ctr[slab0 + i] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) split_list[0] = make_uint2((unsigned)s_nsplit, 0u);
+}
+
+// Second half of a split face (k_face_order): one wave per split face adds the partial sums its items left in their slabs, in
+// part order, and adds the total to the face's gradient -- the launch boundary is what orders the items' stores before these
+// loads.  Grid (SPLIT_REDUCE_BLOCKS, lists): block (b, l) takes entries b, b + SPLIT_REDUCE_BLOCKS, ... of list l.
+#define SPLIT_REDUCE_BLOCKS 32
+struct SplitReduceArgs {
+    const uint2 *split; const float *slab; float *grad_faces; float *grad_textures;
+    int F, TS, G, X, slab_stride, need_gf, need_gt;
+};
+__global__ __launch_bounds__(64) void k_split_reduce(const SplitReduceArgs R) {
+    const int list = blockIdx.y, g = list >> 3, lane = threadIdx.x;
+    const uint2 *sp = R.split + (size_t)list * (R.X + 1);
+    const int count = (int)sp[0].x;
+    for (int i = blockIdx.x; i < count; i += SPLIT_REDUCE_BLOCKS) {
+        const uint2 e = sp[1 + i];
+        const int nparts = (int)((e.x >> 21) & 31u) + 1, f = (int)(e.x & 0xffffu), n = g * R.G + (int)((e.x >> 16) & 31u);
+        const float *s0 = R.slab + (size_t)e.y * R.slab_stride;
+        unsigned mask = 0u;
+        for (int q = 0; q < nparts; ++q) mask |= s0[(size_t)q * R.slab_stride + 9] != 0.f ? 1u << q : 0u;
+        if (!mask) continue;
+        if (R.need_gf && lane < 9) {
+            float acc = 0.f;
+            for (int q = 0; q < nparts; ++q)
+                if ((mask >> q) & 1u) acc += s0[(size_t)q * R.slab_stride + lane];
+            UMR_TRAP_AT(umr_bad(acc), 4, ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
+            R.grad_faces[((size_t)n * R.F + f) * 9 + lane] += acc;
+        }
+        if (R.need_gt) {
+            float *dst = R.grad_textures + ((size_t)n * R.F + f) * R.TS * 3;
+            for (int j = lane; j < R.TS * 3; j += 64) {
+                float acc = 0.f;
+                for (int q = 0; q < nparts; ++q)
+                    if ((mask >> q) & 1u) acc += s0[(size_t)q * R.slab_stride + 16 + j];
+                UMR_TRAP_AT(umr_bad(acc), 5, ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
+                dst[j] += acc;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,7 +374,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
 #endif
 #ifndef FM_TEXMERGE
 #define FM_TEXMERGE 2   // DPP pre-merge steps before the LDS texel atomics: 0 none, 1 = x^1, 2 = x^1 then x^2
-                       // (a third, vertical step measured slower)
+                       // (a third step across quads -- row_shl:4 -- measured slower in round 5 and was removed)
+#endif
+#if FM_TEXMERGE > 2
+#error "FM_TEXMERGE: 0, 1 or 2"
 #endif
 #ifndef FM_VREC
 #define FM_VREC 1         // 1: the face's barycentric rows and corner coordinates as VGPR operands (FaceV)
@@ -324,29 +409,24 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
 #define UMR_DPP_DIVERGENT __builtin_amdgcn_update_dpp
 #endif
 __device__ __forceinline__ float dpp_f(float old, float v, const int ctrl_sel) {
-    // ctrl_sel: 0 -> quad_perm [1,0,3,2] (x^1), 1 -> quad_perm [2,3,0,1] (x^2), 2 -> row_shl:4, 3 -> row_shr:4
+    // ctrl_sel: 0 -> quad_perm [1,0,3,2] (x^1), 1 -> quad_perm [2,3,0,1] (x^2)
     const int o = __float_as_int(old), i = __float_as_int(v);
     int r;
     if (ctrl_sel == 0) r = UMR_DPP_DIVERGENT(o, i, 0xB1, 0xf, 0xf, false);
-    else if (ctrl_sel == 1) r = UMR_DPP_DIVERGENT(o, i, 0x4E, 0xf, 0xf, false);
-    else if (ctrl_sel == 2) r = UMR_DPP_DIVERGENT(o, i, 0x104, 0xf, 0xf, false);
-    else r = UMR_DPP_DIVERGENT(o, i, 0x114, 0xf, 0xf, false);
+    else r = UMR_DPP_DIVERGENT(o, i, 0x4E, 0xf, 0xf, false);
     return __int_as_float(r);
 }
 __device__ __forceinline__ int dpp_i(int old, int v, const int ctrl_sel) {
     if (ctrl_sel == 0) return UMR_DPP_DIVERGENT(old, v, 0xB1, 0xf, 0xf, false);
-    if (ctrl_sel == 1) return UMR_DPP_DIVERGENT(old, v, 0x4E, 0xf, 0xf, false);
-    if (ctrl_sel == 2) return UMR_DPP_DIVERGENT(old, v, 0x104, 0xf, 0xf, false);
-    return UMR_DPP_DIVERGENT(old, v, 0x114, 0xf, 0xf, false);
+    return UMR_DPP_DIVERGENT(old, v, 0x4E, 0xf, 0xf, false);
 }
 __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a, float b, float c, int lane) {
 #if FM_TEXMERGE >= 1
 #pragma unroll
-    for (int step = 0; step < (FM_TEXMERGE >= 3 ? 3 : (FM_TEXMERGE >= 2 ? 2 : 1)); ++step) {
+    for (int step = 0; step < (FM_TEXMERGE >= 2 ? 2 : 1); ++step) {
         // keeper = the lane of the pair with bit `step` clear.  The per-lane constants live in VGPRs (as 64-bit lane
         // masks they were SGPR spills, restored with v_readlane every visit); multiplying the partner's value by the
         // 0/1 weight lets the backend fuse the DPP read into one v_fmac_f32_dpp per channel.
-        // (step 2, FM_TEXMERGE 3: lane i takes lane i + 4 -- row_shl:4 -- the next quad of the hand-out)
         const bool keep = (lane & (1 << step)) == 0;
         const float keepf = keep ? 1.f : 0.f;
         const int dropm = keep ? 0 : -1;
@@ -377,10 +457,6 @@ __device__ __forceinline__ void texel_accumulate(float *my_tex, int tix, float a
 #endif
 #ifndef FM_AGP_SLOT16
 #define FM_AGP_SLOT16 1   // packed-state one-pass kernel (COMMON): 16-byte quad slots {x, y, state offset, gradient offset} as floats
-#endif
-#ifndef FM_PREFETCH
-#define FM_PREFETCH 0     // packed-state one-pass kernel: 1 = the next visit's state words, 2 = + its pooled gradients requested a visit ahead.
-                          // Measured (r5): 135.2 / 134.9 vs 136.1 us warm, 147.2 vs 147.3 cold -- the 6 waves / SIMD hide those loads already; off
 #endif
 #ifndef FM_DEAD_EAGER
 #define FM_DEAD_EAGER 1   // packed-state one-pass kernel: the visit's two dead-test words are loaded together

@@ -364,25 +364,6 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                 unsigned qe_next = (QSLOT16 || PK) ? 0u : qslot[0];
                 uint2 q2_next = PK2 ? qslot2[0] : make_uint2(0u, 0u);
                 float4 q4_next = QSLOT16 ? qslot4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-#if FM_PACKED
-                // Software prefetch (FM_PREFETCH; packed-state kernel with 16-byte slots): the NEXT visit's state words [and pooled
-                // gradients] are requested at the top of the current visit -- its slot is in registers by then -- and waited for one
-                // visit later, instead of at the top of the visit that needs them (the one-pass kernel issues VALU in only ~53 % of
-                // its SIMD cycles: its waves sit at those waits)
-                constexpr bool PF = QSLOT16 && FM_PREFETCH != 0, PFG = QSLOT16 && FM_PREFETCH >= 2;
-                float pf_rs = 0.f, pf_mx = 0.f, pf_al = 0.f, pf_g0 = 0.f, pf_g1 = 0.f, pf_g2 = 0.f, pf_g3 = 0.f;
-                auto prefetch = [&](const float4 &slot, bool on) {
-                    if (on) {
-                        const unsigned o = (unsigned)__float_as_int(slot.z) + qlo_st;
-                        pf_mx = ld_ui<STATE_O_MAX * 4u>(st_n, o); pf_al = ld_ui<STATE_O_ALPHA * 4u>(st_n, o); pf_rs = ld_u(st_n, o);
-                        if constexpr (PFG) {
-                            const unsigned g = (unsigned)__float_as_int(slot.w);
-                            pf_g0 = ld_u(gc_n, g); pf_g1 = ld_u(gc_n, g + gps); pf_g2 = ld_u(gc_n, g + 2 * gps); pf_g3 = ld_u(gc_n, g + 3 * gps);
-                        }
-                    }
-                };
-                if constexpr (PF) prefetch(q4_next, qsub < nq);
-#endif
                 for (int v0 = 0; v0 < nq; v0 += 16) {
                     const int mine = v0 + qsub < nq ? 0 : -1;
                     const unsigned qe = PK2 ? q2_next.x : qe_next;
@@ -392,11 +373,6 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     else if constexpr (PK2) q2_next = qslot2[v0 + 16];
                     else qe_next = qslot[v0 + 16];     // (past the last quad: stale or unwritten words of the array, never used)
                     (void)qst;
-#if FM_PACKED
-                    const float c_rs = pf_rs, c_mx = pf_mx, c_al = pf_al, c_g0 = pf_g0, c_g1 = pf_g1, c_g2 = pf_g2, c_g3 = pf_g3;
-                    if constexpr (PF) prefetch(q4_next, v0 + 16 + qsub < nq);
-                    (void)c_rs; (void)c_mx; (void)c_al; (void)c_g0; (void)c_g1; (void)c_g2; (void)c_g3;
-#endif
 #else
                 while (tm) {
                     // next FM_NQ wanted sub-tiles, one per lane group (groups past the last one idle this visit)
@@ -472,13 +448,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                             dead = false;
                             if (!NEED_GF || AG) {   // (with vertex gradients both terms must vanish: too rare to pay for)
 #if FM_PACKED
-                                if constexpr (PF) { smx = c_mx; sal = c_al; }
-                                else {
                                 smx = ld_ui<STATE_O_MAX * 4u>(st_n, pn4);
 #if FM_DEAD_EAGER
                                 sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);    // both words in flight before the first is tested
 #endif
-                                }
 #else
                                 smx = ld_u(ag_n, pn4 + pst);
 #endif
@@ -488,7 +461,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #if FM_PACKED && FM_DEAD_EAGER
                                 dead = dead & (sal == 1.f);
 #elif FM_PACKED
-                                if constexpr (!PF) sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);
+                                sal = ld_ui<STATE_O_ALPHA * 4u>(st_n, pn4);
                                 dead = dead & (sal == 1.f);
 #else
                                 if (AG) { sal = ld_u(sc_n, pn4 + 3 * pst); dead = dead & (sal == 1.f); }
@@ -523,9 +496,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                     }
                     const float gscale = pooled ? 0.25f : 1.f;   // 2x2 mean pool: each fine pixel gets a quarter
 #if FM_PACKED
-                    const float g0 = gscale * (PFG ? c_g0 : ld_u(gc_n, gp4)), g1 = gscale * (PFG ? c_g1 : ld_u(gc_n, gp4 + gps)),
-                                g2 = gscale * (PFG ? c_g2 : ld_u(gc_n, gp4 + 2 * gps));
-                    const float g3 = gscale * (PFG ? c_g3 : ld_u(gc_n, gp4 + 3 * gps));
+                    const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps), g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
+                    const float g3 = gscale * ld_u(gc_n, gp4 + 3 * gps);
 #else
                     const float g0 = gscale * ld_u(gc_n, gp4), g1 = gscale * ld_u(gc_n, gp4 + gps),
                                 g2 = gscale * ld_u(gc_n, gp4 + 2 * gps);
@@ -533,7 +505,7 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #endif
                     UMR_TRAP_IF(umr_bad(g0) | umr_bad(g1) | umr_bad(g2) | umr_bad(g3), 3);
 #if FM_PACKED
-                    const float rsum = PF ? c_rs : ld_u(st_n, pn4), smax = smx;   // (rsum: the sum's v_rcp_f32, taken by the forward)
+                    const float rsum = ld_u(st_n, pn4), smax = smx;   // (rsum: the sum's v_rcp_f32, taken by the forward)
                     float c_xy = g3 * ((1.f - sal) * __builtin_amdgcn_rcpf(fmaxf(1.f - p.frag, 1e-6f)));  // :584
 #else
                     const float ssum = ld_u(ag_n, pn4), smax = (!NEED_GF || AG) ? smx : ld_u(ag_n, pn4 + pst);
@@ -556,7 +528,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
                         // (exponent clamped at 0: zn <= smax for every pair the forward included, so this changes no bit of a legitimate
                         // pair; a pair only the backward's cull kept -- profiles/r04_nan_replay.md -- then weighs at most D / S
                         // instead of exp(9300) = inf)
-                        const float ps = p.frag * __expf(fminf((zn - smax) * c_ig, 0.f)) * rsum;  // :608
+                        const float ex_ = (zn - smax) * c_ig;                                     // (NaN stays NaN: fminf would swallow it)
+                        const float ps = p.frag * __expf(ex_ > 0.f ? 0.f : ex_) * rsum;  // :608
                         const int tix = texel_index(q0, q1, A.R);
                         if (NEED_GT) {
                             if (TS == 1) { FM_ACC(gt0, ps, g0); FM_ACC(gt1, ps, g1); FM_ACC(gt2, ps, g2); }
@@ -592,63 +565,45 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
 #ifndef FM_SKIP_EMPTY
 #define FM_SKIP_EMPTY 1   // a face none of whose sub-tiles survived the culling pass (half the mesh under a texel-gradient
 #endif                    // launch) adds exact zeros: skip its lane reductions, LDS read-out and read-modify-write stores
+    // (the item word is fetched again rather than kept across the walk: a wave-uniform value held through the visit loop is an
+    // SGPR spill there)
+    if (FM_WAVES == 1 && A.order)
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)A.order[((size_t)((blockIdx.x >> 3) / A.order_stride) * 8 + (blockIdx.x & 7)) * A.order_stride +
+                                                                     (blockIdx.x >> 3) % A.order_stride].x);
     if (FM_WAVES == 1 && (item >> 21)) {
-        const int nparts = (int)((item >> 21) & 31u) + 1, part = (int)(item >> 26);
+        // One part of a split face: leave this item's partial sums in its slab (vertex gradients at [0, 9), "visited a pixel" at
+        // [9], texel gradients from [16]).  k_split_reduce -- the next launch on the stream -- adds a face's parts in part order
+        // and stores: the sum a face gets is a function of its parts' sums and their fixed order alone.  (An in-kernel hand-over
+        // to the last arriving item was measured first: its device-scope fences write back / invalidate the XCD's L2 and cost
+        // 3x the kernel's time.)
+        const int part = (int)(item >> 26);
         const int xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
         const unsigned slab0 = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)A.order[((size_t)(slot_ / A.order_stride) * 8 + xcd_) * A.order_stride + slot_ % A.order_stride].y);
-        // One part of a split face: leave this item's partial sums in its slab, arrive, and -- as the LAST of the face's items to
-        // arrive -- add the parts' sums in part order and store.  The sum a face gets is a function of its parts' sums and their
-        // fixed order alone, whichever wave forms it.
         float *sl = A.slab + (size_t)(slab0 + (unsigned)part) * A.slab_stride;
-        if (visited) {
-            if (NEED_GF) {
-                float mine = 0.f;
+        if (lane == 9) sl[9] = visited ? 1.f : 0.f;
+        if (!visited) return;
+        if (NEED_GF) {
+            float mine = 0.f;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float sv = wave_sum_full(gv[k]);
-                    if (lane == k) mine = sv;
-                }
-                if (lane < 9) sl[lane] = mine;
+            for (int k = 0; k < 9; ++k) {
+                const float sv = wave_sum_full(gv[k]);
+                if (lane == k) mine = sv;
             }
-            if (NEED_GT) {
-                if (TS == 1) {
-                    const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
-                    if (lane < 3) sl[16 + lane] = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
-                } else {
-                    __syncthreads();
-                    for (int j = lane; j < TS * 3; j += 64) {
-                        float acc = wave_tex[j];
-#pragma unroll
-                        for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
-                        sl[16 + j] = acc;
-                    }
-                }
-            }
-        }
-        UMR_DEVICE_FENCE();
-        unsigned long long seen = 0ull;
-        if (lane == 0) seen = atomicAdd(A.slab_ctr + slab0, (1ull << 32) | (visited ? 1ull << part : 0ull));
-        const unsigned arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)(seen >> 32));
-        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)seen) | (visited ? 1u << part : 0u);
-        if (arrived != (unsigned)(nparts - 1) || !mask) return;
-        UMR_DEVICE_FENCE();
-        const float *s0p = A.slab + (size_t)slab0 * A.slab_stride;
-        if (NEED_GF && lane < 9) {
-            float acc = 0.f;
-            for (int q = 0; q < nparts; ++q)
-                if ((mask >> q) & 1u) acc += umr_ld_device(s0p + (size_t)q * A.slab_stride + lane);
-            UMR_TRAP_AT(umr_bad(acc), 4 | (RGB == 2 ? 0x40 : (RGB == 0 ? 0x80 : 0)), ((unsigned)(A.N > 32) << 23) | ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
-            A.grad_faces[((size_t)n * F + f) * 9 + lane] += acc;
+            if (lane < 9) sl[lane] = mine;
         }
         if (NEED_GT) {
-            float *dst = A.grad_textures + ((size_t)n * F + f) * TS * 3;
-            for (int j = lane; j < TS * 3; j += 64) {
-                float acc = 0.f;
-                for (int q = 0; q < nparts; ++q)
-                    if ((mask >> q) & 1u) acc += umr_ld_device(s0p + (size_t)q * A.slab_stride + 16 + j);
-                UMR_TRAP_AT(umr_bad(acc), 5 | (RGB == 0 ? 0x80 : 0), ((unsigned)(A.N > 32) << 23) | ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
-                dst[j] += acc;
+            if (TS == 1) {
+                const float s0 = wave_sum_full(gt0), s1 = wave_sum_full(gt1), s2 = wave_sum_full(gt2);
+                if (lane < 3) sl[16 + lane] = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+            } else {
+                __syncthreads();
+                for (int j = lane; j < TS * 3; j += 64) {
+                    float acc = wave_tex[j];
+#pragma unroll
+                    for (int c = 1; c < FM_TEXCOPY; ++c) acc += wave_tex[c * FM_TEX_STRIDE(TS) + j];
+                    sl[16 + j] = acc;
+                }
             }
         }
         return;

@@ -90,14 +90,13 @@ struct RasterArgs {
     // the i-th wave XCD `xcd` starts within mesh group g: .x = part << 26 | (parts - 1) << 21 | (mesh - g * order_group) << 16 |
     // face (0xffffffff: padding, the wave exits), .y = first slab of the face's partial sums (parts > 1).  A face whose estimated
     // work exceeds the split threshold is `parts` items -- each walks a contiguous share of the culling passes under the face's
-    // bounding box and leaves its partial sums in slab .y + part; the item that arrives last (slab_ctr) adds them up IN PART ORDER
-    // and stores the face's gradient: no wave owns more than a bounded share of a heavy face, results stay deterministic, no
-    // float atomics.  NULL = one wave per face in index order.
+    // bounding box and leaves its partial sums in slab .y + part; k_split_reduce (the next launch) adds them up IN PART ORDER and
+    // stores the face's gradient: no wave owns more than a bounded share of a heavy face, results stay deterministic, no float
+    // atomics.  NULL = one wave per face in index order.
     const uint2 *order;
     int order_group, order_stride;
     int fm_blocks;                  // workgroups of the face-major launch: N x F, or the lists' total length
-    float *slab;                    // [slabs][slab_stride]: vertex gradients at [0, 9), texel gradients at [16, 16 + 3 TS)
-    unsigned long long *slab_ctr;   // per split face (indexed by its first slab): arrivals << 32 | mask of the parts that visited a pixel
+    float *slab;                    // [slabs][slab_stride]: vertex gradients at [0, 9), visited flag at [9], texel gradients at [16, 16 + 3 TS)
     int slab_stride;
     int fm_split;      // runs of faces per XCD and mesh in the face-major backward (fm_owned_face); 0 / 1 = one
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
@@ -133,7 +132,7 @@ struct RasterArgs {
 // points at a row of LDS)
 __device__ __forceinline__ void face_setup_one(int i, const float *__restrict__ faces, float *__restrict__ faces_info,
                                                float4 *__restrict__ bbox, float *r, float thr, float near_, float far_,
-                                               unsigned short *__restrict__ cost, int IS, float thin_h) {
+                                               float thin_h) {
     const float *f = faces + (size_t)i * 9;
     const float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5], x2 = f[6], y2 = f[7], z2 = f[8];
     UMR_TRAP_IF(umr_bad(x0) | umr_bad(y0) | umr_bad(z0) | umr_bad(x1) | umr_bad(y1) | umr_bad(z1) | umr_bad(x2) | umr_bad(y2) | umr_bad(z2), 1);
@@ -166,21 +165,6 @@ __device__ __forceinline__ void face_setup_one(int i, const float *__restrict__ 
     const float xlo = fminf(fminf(x0, x1), x2) - thr, xhi = fmaxf(fmaxf(x0, x1), x2) + thr;
     const float ylo = fminf(fminf(y0, y1), y2) - thr, yhi = fmaxf(fmaxf(y0, y1), y2) + thr;
     bbox[i] = make_float4(xlo, xhi, ylo, yhi);
-    if (cost) {
-        // work estimate for the face-major backward's start order (k_face_order): 4x4 sub-tiles under the dilated bbox
-        // (the window of raster_backward.h; 15 bits), bit 15 = front-facing.  NaN bounds: the wave walks the whole image.
-        int key = 0x7fff;
-        if (xlo == xlo && xhi == xhi && ylo == ylo && yhi == yhi) {
-            const float h = 0.5f * IS;
-            const int px0 = max((int)floorf(xlo * h + h - 0.5f) - 1, 0), px1 = min((int)ceilf(xhi * h + h - 0.5f) + 1, IS - 1);
-            const int py0 = max((int)floorf(ylo * h + h - 0.5f) - 1, 0), py1 = min((int)ceilf(yhi * h + h - 0.5f) + 1, IS - 1);
-            int nt = 0;
-            if (px0 <= px1 && py0 <= py1) nt = ((px1 >> 2) - (px0 >> 2) + 1) * ((py1 >> 2) - (py0 >> 2) + 1);
-            key = min(nt, 0x7fff);
-        }
-        const bool front = (y2 - y0) * (x1 - x0) < (y1 - y0) * (x2 - x0);
-        cost[i] = (unsigned short)(key | (front ? 0x8000 : 0));
-    }
     // ---- packed record ----
 #pragma unroll
     for (int k = 0; k < REC; ++k) r[k] = 0.f;
@@ -287,11 +271,10 @@ __device__ __forceinline__ void face_setup_one(int i, const float *__restrict__ 
 #define FACE_SETUP_THREADS 64
 __global__ __launch_bounds__(FACE_SETUP_THREADS) void k_face_setup(const float *__restrict__ faces, float *__restrict__ faces_info,
                              float4 *__restrict__ bbox, float *__restrict__ rec, int total, float thr,
-                             float near_, float far_, unsigned short *__restrict__ cost = nullptr, int IS = 0,
-                             float thin_h = 0.f) {
+                             float near_, float far_, float thin_h = 0.f) {
     __shared__ float s_rec[FACE_SETUP_THREADS][REC + 1];
     const int base = blockIdx.x * FACE_SETUP_THREADS, i = base + (int)threadIdx.x;
-    if (i < total) face_setup_one(i, faces, faces_info, bbox, s_rec[threadIdx.x], thr, near_, far_, cost, IS, thin_h);
+    if (i < total) face_setup_one(i, faces, faces_info, bbox, s_rec[threadIdx.x], thr, near_, far_, thin_h);
     __syncthreads();
     const int rows = min(FACE_SETUP_THREADS, total - base);
     float *out = rec + (size_t)base * REC;

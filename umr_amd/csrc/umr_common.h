@@ -25,18 +25,6 @@
 #define UMR_WAVE_LDS_HANDOVER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
-// Waves of ONE launch handing data to each other through global memory (the split faces of the face-major backward: partial sums
-// -> the item that arrives last): the writer orders its stores before its arrival with a device-scope fence, the reader fences
-// again after seeing the last arrival and reads the slabs with device-scope loads (past the CU's L1, which may hold the slab's
-// lines of an earlier launch).  The emulation build runs one workgroup after the other on one thread.
-#ifdef UMR_HOST_SHIM
-#define UMR_DEVICE_FENCE() ((void)0)
-static inline float umr_ld_device(const float *p) { return *p; }
-#else
-#define UMR_DEVICE_FENCE() __threadfence()
-__device__ __forceinline__ float umr_ld_device(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
-
 static inline int umr_launch_status() { return hipGetLastError() == hipSuccess ? UMR_OK : UMR_ERR_LAUNCH; }
 
 // 64-lane butterfly sum; every lane ends with the total (ds_bpermute based, order fixed -> deterministic)

@@ -396,18 +396,30 @@ class MeshNet(nn.Module):
 
 
 # ------------------------------------------------------------------ training step (bench.py / examples)
+def _data_parallel(model, net, disc, args, dev, world):
+    """-> (net, disc, sync) of a data-parallel step over `world` ranks (nn.DataParallel's sites, train_s2.py:95-101).
+    Default (`args.grad_sync` absent or "buckets"): the modules as they are + parallel.BucketedGradSync over all their parameters
+    -- the bucketed, overlapped RCCL all-reduce written out, capturable into the step's HIP graph; "ddp": torch's
+    DistributedDataParallel wrappers (eager steps only), sync None.  One rank: (net, disc, None)."""
+    from .parallel import BucketedGradSync, wrap_ddp
+    if world <= 1:
+        return net, disc, None
+    if getattr(args, "grad_sync", "buckets") == "ddp":
+        return wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world), None
+    return net, disc, BucketedGradSync(model.parameters(), torch.distributed.get_world_size() if torch.distributed.is_initialized() else world)
+
+
 def build_training_step(tv, faces, args, dev, world):
     """One full train_s1 iteration on resident synthetic data: MeshNet fwd -> render-and-compare (HIP) -> bwd with
     bucketed RCCL all-reduce overlapped (DDP) -> Adam with the reference's lr schedule (train_utils.py:186-194)."""
     from .image_utils import compute_dt_barrier
-    from .parallel import wrap_ddp
     from .synthetic import make_s1_inputs
     from .train_step import RenderCompareS1
     opts = default_opts(subdivide=args.subdivide, batch_size=args.batch)
     net = MeshNet((args.image_size, args.image_size), opts, nz_feat=opts.nz_feat).to(dev)
     disc = Discriminator(opts.grl_wt, img_size=args.image_size).to(dev)
     model = nn.ModuleDict(dict(net=net, disc=disc))
-    ddp_net, ddp_disc = wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world)
+    ddp_net, ddp_disc, sync = _data_parallel(model, net, disc, args, dev, world)
     # train_s1.py:150: the texture term is the AlexNet perceptual distance (two feature passes over B images and one
     # backward per step); random weights offline, frozen (requires_grad False) and therefore not in the optimizer
     from .perceptual import PerceptualTextureLoss
@@ -434,13 +446,20 @@ def build_training_step(tv, faces, args, dev, world):
                 g['lr'].copy_(opts.learning_rate / (1 + it_dev * 5e-4))
             else:
                 g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)
-        opt.zero_grad(set_to_none=True)
+        if sync is None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            sync.begin()
         # the reference computes the barrier distance transform on the host in set_input (train_s1.py:171-174)
         batch["dts_barrier"] = compute_dt_barrier(batch["masks"]).unsqueeze(1)
         out = ddp_net(input_imgs)
         out["pred_vs"] = net.get_mean_shape()[None] + net.symmetrize(out["delta_v"])   # train_s1.py:183-192
         total, _ = rc(out, batch)
-        total.backward()
+        if sync is None:
+            total.backward()
+        else:       # bucket all-reduces start from the gradient hooks while backward runs; finish() waits for them
+            (total * sync.loss_scale).backward()
+            sync.finish()
         opt.step()
         state["it"] += 1
         if capt:
@@ -449,6 +468,7 @@ def build_training_step(tv, faces, args, dev, world):
 
     step.model = model
     step.opt, step.it_dev = opt, it_dev          # (tests: snapshot / restore the optimizer state around a graph replay)
+    step.sync = sync
     return step
 
 
@@ -457,15 +477,14 @@ def build_training_step_s2(args, dev, world):
     22 raster forwards + 21 backwards per image + mask / texture (AlexNet perceptual) / part / chamfer losses ->
     backward with DDP all-reduce -> Adam.  SCOPS data being absent, part labels / points are synthetic."""
     from .image_utils import compute_dt_barrier
-    from .parallel import wrap_ddp
     from .synthetic import make_s2_inputs
     from .train_step import RenderCompareS2
     opts = default_opts(subdivide=args.subdivide, batch_size=args.batch, multiple_cam_hypo=True)
     net = MeshNet((args.image_size, args.image_size), opts, nz_feat=opts.nz_feat).to(dev)
     disc = Discriminator(opts.grl_wt, in_dim=3, img_size=args.image_size).to(dev)     # train_s2.py:91-93: rgb input
     model = nn.ModuleDict(dict(net=net, disc=disc))
-    ddp_net, ddp_disc = wrap_ddp(net, dev, world), wrap_ddp(disc, dev, world)
-    rank = torch.distributed.get_rank() if world > 1 else 0
+    ddp_net, ddp_disc, sync = _data_parallel(model, net, disc, args, dev, world)
+    rank = torch.distributed.get_rank() if (world > 1 and torch.distributed.is_initialized()) else 0
     _, _, _, batch, ex = make_s2_inputs(args.batch, opts.num_hypo_cams, args.image_size, args.subdivide,
                                         seed=getattr(args, "data_seed", 100) + rank, device=dev)
     rc = RenderCompareS2(net.get_mean_shape().detach(), net.faces, ex["part_vertex_ids"], ex["uv_img"],
@@ -491,7 +510,10 @@ def build_training_step_s2(args, dev, world):
                 g['lr'].copy_(opts.learning_rate / (1 + it_dev * 5e-4))
             else:
                 g['lr'] = opts.learning_rate / (1 + state["it"] * 5e-4)
-        opt.zero_grad(set_to_none=True)
+        if sync is None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            sync.begin()
         batch["dts_barrier"] = compute_dt_barrier(batch["masks"]).unsqueeze(1)        # train_s2.py:196
         out = ddp_net(input_imgs)
         out["mean_shape"] = net.get_mean_shape()
@@ -501,7 +523,11 @@ def build_training_step_s2(args, dev, world):
             watch.append((sorted(terms), torch.stack([terms[k].detach().reshape(()) for k in sorted(terms)] +
                                                      [out["delta_v"].detach().abs().max(), out["cam_hypotheses"].detach().abs().max(),
                                                       out["tex_flow"].detach().abs().max()])))
-        total.backward()
+        if sync is None:
+            total.backward()
+        else:
+            (total * sync.loss_scale).backward()
+            sync.finish()
         opt.step()
         # :268 -- written IN PLACE: the next step (and the next replay of a captured step) reads this very buffer
         torch.mul(batch["imgs"], batch["masks"].unsqueeze(1), out=batch["random_imgs"])
@@ -513,4 +539,5 @@ def build_training_step_s2(args, dev, world):
     step.model = model
     step.opt, step.it_dev = opt, it_dev          # (tests: snapshot / restore the optimizer state around a graph replay)
     step.watch = watch
+    step.sync = sync
     return step

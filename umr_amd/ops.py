@@ -41,6 +41,7 @@ from ._lib import ptr
 
 BWD_ALPHA_GEOMETRY = 4      # UMR_BWD_ALPHA_GEOMETRY (include/umr_hip.h)
 BWD_PACKED_STATE = 8        # UMR_BWD_PACKED_STATE
+BWD_REUSE_WORKSPACE = 16    # UMR_BWD_REUSE_WORKSPACE
 RASTER_PACKED_STATE, RASTER_VIS_IDS_ONLY = 8, 16   # UMR_RASTER_PACKED_STATE, UMR_RASTER_VIS_IDS_ONLY
 ONE_PASS_MAX_TS = 1023      # texels per face the face-major backward's LDS accumulators take (4 copies x (3 TS | 1) floats <= 48 KB)
 
@@ -124,8 +125,9 @@ def _raster_forward(face_vertices, textures, image_size, background, near, far, 
                                   ws_bytes, _lib.stream_ptr(dev), ptr(vis))
     _lib.check(rc, "umr_raster_forward_vis")
     p2f = p2f_acc[0] / p2f_acc[1].clamp_min(1e-12)  # functional/soft_rasterize.py:73
-    if lean:
-        return pooled, p2f, aggrs_info, pooled.new_empty(0), (vis if want_visibility else pooled.new_empty(0))
+    if lean:    # 4th slot: the raster workspace this call filled (face records, bounding boxes) -- the backward reads it instead of
+        # rebuilding it (UMR_BWD_REUSE_WORKSPACE)
+        return pooled, p2f, aggrs_info, ws, (vis if want_visibility else pooled.new_empty(0))
     # custom-op outputs may not alias each other: without the fused pool the image IS the saved state, returned once more
     # as an empty placeholder in the 4th slot
     return ((pooled if pool else soft_colors), p2f, aggrs_info, (soft_colors if pool else soft_colors.new_empty(0)),
@@ -148,7 +150,9 @@ def _raster_fake(face_vertices, textures, image_size, background, near, far, fil
     S = IS // 2 if pool else IS
     f = lambda *s: face_vertices.new_empty(s, dtype=torch.float32)
     if lean:
-        return (f(N, 4, S, S), f(N, F, 2), f(N, IS * IS * 4), f(0), (f(N, IS, IS) if want_visibility else f(0)))
+        ws_bytes = _lib.lib().umr_raster_workspace_bytes_for(N, F, IS)       # (a host-side size query: no device work)
+        return (f(N, 4, S, S), f(N, F, 2), f(N, IS * IS * 4), face_vertices.new_empty((ws_bytes,), dtype=torch.uint8),
+                (f(N, IS, IS) if want_visibility else f(0)))
     return (f(N, 4, S, S), f(N, F, 2), f(N, 2, IS, IS), (f(N, 4, IS, IS) if pool else f(0)),
             (f(N, 2, IS, IS) if want_visibility else f(0)))
 
@@ -298,7 +302,8 @@ def soft_rasterize_alpha_geometry_op(face_vertices: torch.Tensor, textures: torc
                                      lean: bool = False
                                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """lean: for callers that consume the pooled image, p2f and the visible-face ids only (the training steps): outputs 3 - 5 are
-    then (packed saved state [N, 4 IS^2] -- opaque, the backward's input --, empty, face ids [N,IS,IS])."""
+    then (packed saved state [N, 4 IS^2] -- opaque, the backward's input --, the call's raster workspace (uint8, opaque: the
+    backward reads its face records instead of rebuilding them), face ids [N,IS,IS])."""
     if int(modes) != 1:
         raise RuntimeError("soft_rasterize_alpha_geometry: soft-max colour with UMR's own modes only")
     return _raster_forward(face_vertices, textures, image_size, background, near, far, fill_back, eps, sigma_val, dist_eps,
@@ -329,14 +334,17 @@ def soft_rasterize_alpha_geometry_backward_op(face_vertices: torch.Tensor, textu
     grad_textures = torch.zeros(N, F, TS, 3, device=dev, dtype=torch.float32)   # per view
     g = grad_image.to(torch.float32).contiguous()
     ws_bytes = L.umr_raster_workspace_bytes_for(N, F, int(image_size))
-    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    # lean: `soft_colors` carries the forward's workspace (its face records and bounding boxes are read, not rebuilt)
+    reuse = bool(lean) and soft_colors.dtype == torch.uint8 and soft_colors.numel() >= ws_bytes and soft_colors.is_contiguous()
+    ws = soft_colors if reuse else torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     sc = _scalars(image_size, near, far, fill_back, eps, sigma_val, dist_eps, gamma_val, modes)
     if getattr(_lib, "TAP", None) is not None:
         _lib.TAP("raster_backward_alpha_geometry", dict(face_vertices=fv, textures=tex, grad_image=g, lean=lean, image_size=int(image_size)))
     # lean: aggrs_info is the forward's packed saved state, soft_colors an empty placeholder
     rc = L.umr_raster_backward(ptr(fv), ptr(tex), None if lean else ptr(soft_colors), None, ptr(aggrs_info), ptr(grad_faces),
                                ptr(grad_textures), ptr(g),
-                               (1 if pool else 0) | BWD_ALPHA_GEOMETRY | (BWD_PACKED_STATE if lean else 0) | (G << 8), 1, 1, N, F, TS,
+                               (1 if pool else 0) | BWD_ALPHA_GEOMETRY | (BWD_PACKED_STATE if lean else 0) |
+                               (BWD_REUSE_WORKSPACE if reuse else 0) | (G << 8), 1, 1, N, F, TS,
                                *sc, ptr(ws), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "umr_raster_backward(alpha geometry)")
     if G > 1:

@@ -53,6 +53,82 @@ def wrap_ddp(module, device, world):
     return torch.nn.parallel.DistributedDataParallel(module, bucket_cap_mb=BUCKET_MB, broadcast_buffers=False)
 
 
+class BucketedGradSync:
+    """The gradient exchange of one data-parallel training step, written out: every parameter's `.grad` is a VIEW into one flat
+    fp32 buffer laid out in reverse parameter order (the order backward produces them); the buffer is cut into buckets of
+    `bucket_mb`; a post-accumulate hook per parameter counts its bucket down, and a bucket whose gradients are all in is
+    all-reduced at once -- asynchronously (RCCL runs it on the process group's own stream), in bucket order on every rank, while
+    backward goes on -- and `finish()` waits for all of them before the optimizer reads the gradients.
+
+    Why not torch's DistributedDataParallel here: this is the same schedule (64 MB buckets overlapped with backward, gradients
+    averaged over ranks) with no host-side reducer state, so the WHOLE step -- forward, backward, the bucket all-reduces, Adam --
+    captures into ONE HIP graph at every world size (bench.py: the N = 1 point of a scaling curve and the N > 1 points are then
+    measured the same way; under DDP the N > 1 step was eager and host-enqueue-bound).  wrap_ddp stays for callers that want DDP.
+
+    Use:   sync = BucketedGradSync(model.parameters(), world)
+           sync.begin(); (loss * sync.loss_scale).backward(); sync.finish(); opt.step()       # never opt.zero_grad(set_to_none=True)
+    loss_scale = 1 / world: the all-reduce SUMS, so pre-scaled gradients come out averaged (what DataParallel's gather + mean
+    and DDP both compute).  Parameters that received no gradient in a step contribute zeros."""
+
+    def __init__(self, params, world, bucket_mb=BUCKET_MB, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("BucketedGradSync: no trainable parameters")
+        self.world, self.group = max(1, int(world)), group
+        self.loss_scale = 1.0 / self.world
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        cap = max(1, int(bucket_mb * 1024 * 1024) // 4)
+        self.buckets, self._bucket_of, self._size = [], {}, []
+        off, start, count = 0, 0, 0
+        for p in reversed(self.params):
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("BucketedGradSync: fp32 parameters on one device only")
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += n
+            count += 1
+            if off - start >= cap:
+                self.buckets.append(self.flat[start:off]); self._size.append(count)
+                start, count = off, 0
+        if off > start:
+            self.buckets.append(self.flat[start:off]); self._size.append(count)
+        self._pending, self._next, self._works = list(self._size), 0, []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
+
+    def begin(self):
+        """Start of a step: zero every gradient (one fill of the flat buffer) and re-arm the buckets."""
+        self.flat.zero_()
+        self._pending, self._next, self._works = list(self._size), 0, []
+
+    def _launch(self):
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            if self.world > 1 or dist.is_initialized():
+                self._works.append(dist.all_reduce(self.buckets[self._next], group=self.group, async_op=True))
+            self._next += 1
+
+    def _ready(self, p):
+        self._pending[self._bucket_of[id(p)]] -= 1
+        self._launch()
+
+    def finish(self):
+        """After backward: launch the buckets that are still waiting (parameters without a gradient this step), in order, and
+        make the current stream wait for every all-reduce."""
+        for b in range(self._next, len(self.buckets)):
+            self._pending[b] = 0
+        self._launch()
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def shard(tensor, rank, world):
     """Contiguous batch shard of rank `rank` (images are independent in every kernel and loss).  The batch
     must split evenly: short or empty shards would give DDP uneven inputs (hang / crash in the bucketed all-reduce)."""
