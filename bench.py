@@ -447,6 +447,7 @@ def main(device=None, backend="nccl"):
     whole_graph = None
     eager_host_ms = None
     early_prof = None
+    graph_check = None
     if args.graph and use_model:
         # The WHOLE training step -- distance transform, MeshNet forward, every raster / loss kernel, backward, fused Adam with its
         # on-device learning-rate schedule -- captured once into one HIP graph and replayed: the eager step's host enqueue time
@@ -489,6 +490,13 @@ def main(device=None, backend="nccl"):
             torch.cuda.synchronize()
             if not math.isfinite(float(static_loss)):
                 raise RuntimeError("first replay of the captured step returned a non-finite loss")
+            # ... and a replay must BE the step: every gradient tensor of a replay against the eager step's from the same saved
+            # state (umr_amd/graph_check.py: captured memset nodes do not replay on this stack, and a library kernel that relies
+            # on one leaves garbage in the replayed step only)
+            from umr_amd.graph_check import replay_matches_eager
+            graph_check = replay_matches_eager(eager_step, whole_graph, static_loss, dev)
+            if not graph_check["ok"]:
+                raise RuntimeError("a replay of the captured step does not reproduce the eager step: %r" % (graph_check,))
 
             def step_fn():
                 whole_graph.replay()
@@ -722,6 +730,9 @@ def main(device=None, backend="nccl"):
                         "hip_graph": bool((args.graph and not use_model and world == 1) or whole_graph is not None),
                         "hip_graph_scope": ("whole training step (network + losses + Adam)" if whole_graph is not None else
                                             ("render-and-compare step" if (args.graph and not use_model and world == 1) else None)),
+                        # every gradient tensor of one replay against the eager step's from the same saved state (graph_check.py)
+                        "hip_graph_replay_vs_eager": ({k: graph_check[k] for k in ("ok", "tensors", "compared", "bad", "loss_replay", "loss_eager")}
+                                                      if graph_check else None),
                         "hot_path_loss_spread": loss_spread}, **rccl),
     }
     # ---- roofline -------------------------------------------------------------------------------------------------------------

@@ -305,9 +305,10 @@ def test_baseline_config1_shape_single_image(oracle_built):
 
 
 def test_one_rank_rccl_training_step():
-    """The data-parallel path on real RCCL with one rank: NCCL(=RCCL) process group on 127.0.0.1, MeshNet + discriminator
-    wrapped in DDP (64 MB buckets, no buffer broadcast), two full train_s1 steps; gradients are identical to the
-    un-wrapped model's (all-reduce over one rank = identity) and the optimiser moves the weights."""
+    """The data-parallel path on real RCCL with one rank: NCCL(=RCCL) process group on 127.0.0.1; the step's gradient exchange
+    in both forms -- parallel.BucketedGradSync (the default: gradients as views of one flat buffer, 64 MB buckets all-reduced from
+    the gradient hooks) and torch DDP (64 MB buckets, no buffer broadcast) --, one full train_s1 step each; gradients are identical
+    to the plain model's (all-reduce over one rank = identity) and the optimiser moves the weights."""
     import argparse
     import socket
     import torch.distributed as dist
@@ -322,9 +323,11 @@ def test_one_rank_rccl_training_step():
         args = argparse.Namespace(batch=4, image_size=64, subdivide=2, epoch=0)
         tv, faces = template(2)
         grads = {}
-        for wrapped in (True, False):
+        for wrapped in ("buckets", "ddp", False):
             torch.manual_seed(5)
-            step = build_training_step(tv, faces, args, dev, 2 if wrapped else 1)   # world 2 forces the DDP wrap
+            args.grad_sync = wrapped or "buckets"
+            step = build_training_step(tv, faces, args, dev, 2 if wrapped else 1)   # world 2: the data-parallel form
+            assert (step.sync is not None) == (wrapped == "buckets")
             step.model.eval()       # BatchNorm on running statistics: with 4 samples at 64x64 the batch statistics of the
                                     # 1x1 bottleneck amplify summation-order noise (float atomics) into O(1) differences
             before = [p.detach().clone() for p in step.model.parameters() if p.requires_grad]
@@ -338,9 +341,10 @@ def test_one_rank_rccl_training_step():
         t = torch.ones(4, device=dev)
         dist.all_reduce(t)
         assert float(t.sum()) == 4.0
-        assert grads[True].shape == grads[False].shape
-        rel = float((grads[True] - grads[False]).abs().max() / grads[False].abs().max())
-        assert rel < 1e-3, rel          # same seeds, same kernels; atomics in the projection scatter reorder a few sums
+        for form in ("buckets", "ddp"):
+            assert grads[form].shape == grads[False].shape
+            rel = float((grads[form] - grads[False]).abs().max() / grads[False].abs().max())
+            assert rel < 1e-3, (form, rel)          # same seeds, same kernels; atomics in the projection scatter reorder a few sums
     finally:
         dist.destroy_process_group()
 

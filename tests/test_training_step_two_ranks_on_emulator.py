@@ -1,5 +1,5 @@
 """CPU, world_size 2, gloo: bench.py's TIMED STEP itself -- umr_amd.model.build_training_step / build_training_step_s2: MeshNet
-forward, the whole render-and-compare path through the product's kernels, backward with DDP's bucketed all-reduce, Adam -- on
+forward, the whole render-and-compare path through the product's kernels, backward with the bucketed gradient all-reduce, Adam -- on
 two ranks, with the kernels running on the wave64 emulation of the library (tests/host_raster.py::emulated_product) instead of a
 GPU.  tests/test_parallel_gloo.py checks the data-parallel harness around a surrogate loss; this runs the real thing (toy
 size): different data per rank (seed 100 + rank, as in bench.py), identical replicas after every step, gradients that are the
@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, stage, q):
+def _worker(rank, world, port, stage, q, grad_sync="buckets"):
     import torch.distributed as dist
     from umr_amd import parallel
     from umr_amd.model import build_training_step, build_training_step_s2
@@ -33,7 +33,7 @@ def _worker(rank, world, port, stage, q):
     torch.set_num_threads(2)
     parallel.init_distributed("gloo")
     torch.manual_seed(0)                                   # identical initial replicas, as bench.py
-    args = types.SimpleNamespace(batch=2, image_size=64, subdivide=1, epoch=0, graph=0)
+    args = types.SimpleNamespace(batch=2, image_size=64, subdivide=1, epoch=0, graph=0, grad_sync=grad_sync)
     with HR.emulated_product():
         step = (build_training_step(None, None, args, "cpu", world) if stage == 1 else build_training_step_s2(args, "cpu", world))
         losses, sums = [], []
@@ -49,14 +49,16 @@ def _worker(rank, world, port, stage, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("stage", [1, 2])
-def test_bench_training_step_on_two_ranks(stage):
+@pytest.mark.parametrize("stage,grad_sync", [(1, "buckets"), (2, "buckets"), (1, "ddp")])
+def test_bench_training_step_on_two_ranks(stage, grad_sync):
+    """grad_sync: the step's gradient exchange -- parallel.BucketedGradSync (bench.py's default: flat gradient buffer, buckets
+    all-reduced from the gradient hooks) or torch's DistributedDataParallel."""
     HR.lib(HR.build())                                     # built once, before the ranks start
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, stage, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, stage, q, grad_sync)) for r in range(world)]
     for p in procs:
         p.start()
     import queue

@@ -1,5 +1,7 @@
-"""GPU box: rocprofv3 PMC passes (one counter group per run, --kernel-trace only) over tools/kernels.py, restricted to
-the counters `rocprofv3 -L` lists on this box, and a per-kernel summary.  usage: pmc_passes.py <outdir> [step_kernels args...]"""
+"""GPU box: rocprofv3 PMC passes (one counter group per run, --kernel-trace only) over tools/kernels.py -- or, with
+PMC_TARGET="tools/scene_times.py profiles/scenes/live_s1_a.npz --iters 3", over any other script of this tree --, restricted to
+the counters `rocprofv3 -L` lists on this box, and a per-kernel summary (incl. VALU busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x
+kernel cycles at 2.4 GHz), from the same pass's kernel trace).  usage: pmc_passes.py <outdir> [kernels.py args...]"""
 import collections
 import csv
 import glob
@@ -36,8 +38,10 @@ for g, names in GROUPS.items():
     if not ok:
         continue
     used[g] = ok
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ok + ["--output-format", "csv", "-d", os.path.join(out, g), "-o", "t", "--",
-           sys.executable, os.path.join(R, "tools/kernels.py")] + (extra or ["3"])
+    target = os.environ.get("PMC_TARGET", "").split()
+    tail = ([os.path.join(R, target[0])] + [os.path.join(R, a) if a.endswith(".npz") else a for a in target[1:]]) if target else \
+        ([os.path.join(R, "tools/kernels.py")] + (extra or ["3"]))
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ok + ["--output-format", "csv", "-d", os.path.join(out, g), "-o", "t", "--", sys.executable] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env)
     open(os.path.join(out, g + ".log"), "w").write(r.stdout[-4000:] + "\n---\n" + r.stderr[-4000:])
 d = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -46,7 +50,11 @@ for fn in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
         if "k_raster" in k or "k_face" in k or "k_superblock" in k:
             d[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-rep = {"counters_used": used, "kernels": {}}
+dur = collections.defaultdict(list)          # kernel durations of the sq2 pass (the one that holds SQ_ACTIVE_INST_VALU)
+for fn in glob.glob(out + "/sq2/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(fn)):
+        dur[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+rep = {"counters_used": used, "target": os.environ.get("PMC_TARGET", "tools/kernels.py"), "kernels": {}}
 for k, v in sorted(d.items()):
     c = {n: sum(x) / len(x) for n, x in v.items()}
     c["launches_seen"] = max(len(x) for x in v.values())
@@ -66,6 +74,10 @@ for k, v in sorted(d.items()):
         c["avg_smem_latency_quadcycles"] = round(c["SQ_INST_LEVEL_SMEM"] / c["SQ_INSTS_SMEM"], 1)
     if c.get("TCP_TCC_READ_REQ_sum") and c.get("TCP_TCC_READ_REQ_LATENCY_sum"):
         c["avg_l1_to_l2_read_latency_cycles"] = round(c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"], 1)
+    if dur.get(k) and c.get("SQ_ACTIVE_INST_VALU"):
+        ns = sum(dur[k]) / len(dur[k])
+        c["kernel_us_in_sq2_pass"] = round(ns / 1e3, 1)
+        c["valu_busy_frac"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * ns * 2.4), 3)
     rep["kernels"][k] = c
 json.dump(rep, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(rep)[:6000])

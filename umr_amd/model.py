@@ -61,8 +61,44 @@ def fc_stack(nc_inp, nc_out, nlayers, use_bn=True):
     return enc
 
 
+class _BiasAdd(torch.autograd.Function):
+    """y + bias over the channel axis, with the bias gradient summed in STAGES (over W, then H, then N)."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        ctx.mark_dirty(y)                              # y is the convolution's fresh output, which its backward does not read
+        return y.add_(bias.view(1, -1, 1, 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g.sum(3).sum(2).sum(0)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state_dict keys, same values) whose bias gradient over a LARGE output is not left to
+    the convolution's backward.  There it is one reduction of N x H x W values per channel, which ATen splits over several
+    workgroups that meet at a semaphore zeroed by a cudaMemsetAsync (ATen/native/cuda/Reduce.cuh: global_reduce).  On this
+    ROCm stack a memset node of a captured HIP graph does not run again on replay (the same defect the library's own zero-fills
+    met in round 2, umr_common.h: umr_k_zero), the semaphore keeps counting, no workgroup is ever 'last' and the bias gradient
+    of every replay is whatever the buffer held: measured at bench size, the texture decoder's 64x128 and 128x256 layers --
+    values up to 1e38 in a replayed step, eager steps correct (tests/test_gpu_round5.py::
+    test_whole_training_step_replays_from_a_hip_graph compares every gradient moment of a replay with the eager step's).
+    Summed in stages each reduction is short enough for one workgroup per output: no semaphore, no memset."""
+    STAGED_FROM = 16384          # N x H x W per channel from which the bias is added / reduced here
+
+    def forward(self, x):
+        if self.bias is not None and x.dim() == 4:
+            k, st, pd, dl = self.kernel_size, self.stride, self.padding, self.dilation
+            if isinstance(pd, tuple):       # output extent as F.conv2d computes it
+                ho = (x.shape[2] + 2 * pd[0] - dl[0] * (k[0] - 1) - 1) // st[0] + 1
+                wo = (x.shape[3] + 2 * pd[1] - dl[1] * (k[1] - 1) - 1) // st[1] + 1
+                if x.shape[0] * ho * wo >= self.STAGED_FROM:
+                    return _BiasAdd.apply(self._conv_forward(x, self.weight, None), self.bias)
+        return self._conv_forward(x, self.weight, self.bias)
+
+
 def conv2d(batch_norm, cin, cout, kernel_size=3, stride=1):
-    layers = [nn.Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True)]
+    layers = [Conv2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=True)]
     if batch_norm:
         layers.append(nn.BatchNorm2d(cout))
     layers.append(nn.LeakyReLU(0.2, inplace=True))
@@ -82,7 +118,7 @@ class Upsample2x(nn.Module):
 
 def upconv2d(cin, cout, mode='bilinear'):
     return nn.Sequential(Upsample2x(), nn.ReflectionPad2d(1),
-                         nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=0), nn.LeakyReLU(0.2, inplace=True))
+                         Conv2d(cin, cout, kernel_size=3, stride=1, padding=0), nn.LeakyReLU(0.2, inplace=True))
 
 
 def decoder2d(nlayers, nc_input, nc_final, nc_min=8, use_bn=True):
@@ -95,7 +131,7 @@ def decoder2d(nlayers, nc_input, nc_final, nc_min=8, use_bn=True):
         mods.append(upconv2d(nc_input, nc_output))
         nc_input = nc_output
         mods.append(conv2d(use_bn, nc_input, nc_output))
-    mods.append(nn.Conv2d(nc_output, nc_final, kernel_size=3, stride=1, padding=1, bias=True))
+    mods.append(Conv2d(nc_output, nc_final, kernel_size=3, stride=1, padding=1, bias=True))
     dec = nn.Sequential(*mods)
     net_init(dec)
     return dec
@@ -299,9 +335,9 @@ class Discriminator(nn.Module):
         super().__init__()
         self.lambda_ = lambda_
         fc_size = int(img_size // 16)
-        self.img_conv = nn.Conv2d(in_dim, 32, 3, 2, 1)
-        self.convs = nn.Sequential(nn.Conv2d(32, 64, 3, 2, 1), nn.ReLU(True), nn.Conv2d(64, 32, 3, 2, 1), nn.ReLU(True),
-                                   nn.Conv2d(32, 32, 3, 2, 1), nn.ReLU(True), nn.Conv2d(32, 1, 1, 1, 0))
+        self.img_conv = Conv2d(in_dim, 32, 3, 2, 1)
+        self.convs = nn.Sequential(Conv2d(32, 64, 3, 2, 1), nn.ReLU(True), Conv2d(64, 32, 3, 2, 1), nn.ReLU(True),
+                                   Conv2d(32, 32, 3, 2, 1), nn.ReLU(True), Conv2d(32, 1, 1, 1, 0))
         self.fc = nn.Linear(fc_size * fc_size, 1)
 
     def forward(self, imgs):
