@@ -88,7 +88,7 @@ int host_pairs(const float *faces, int n, const float *xp, const float *yp, int 
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, near_, far_, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, near_, far_, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         Face fc;
@@ -117,7 +117,7 @@ int host_texels(const float *faces, int n, const float *xp, const float *yp, int
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         Face fc;
@@ -147,7 +147,7 @@ int host_general_frag(const float *faces, int n, const float *xp, const float *y
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, g_thin_h);
     }
     RasterArgs A = {};
     A.threshold = threshold; A.nis = nis; A.thr = thr; A.dist_mode = dist_mode;
@@ -193,7 +193,7 @@ int host_tile_may_hit(const float *faces, int n, const float *tiles, int ntiles,
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         const float4 *q = (const float4 *)(rec + (size_t)i * REC + R_I0);
@@ -224,7 +224,7 @@ int host_cull_granularity(const float *faces, int n, int IS, float thr, float th
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, g_thin_h);
     }
     const bool pow2 = (IS & (IS - 1)) == 0;
     const float inv_is = 1.f / (float)IS, h = 0.5f * IS;
@@ -293,7 +293,7 @@ int host_replay_face(const float *faces, int n, int f, int IS, float thr, float 
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, near_, far_, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, near_, far_, g_thin_h);
     }
     const bool pow2 = (IS & (IS - 1)) == 0;
     const float inv_is = 1.f / (float)IS, h = 0.5f * IS, ig = 1.f / gamma, rr = 1.f / (far_ - near_);
@@ -365,7 +365,7 @@ int host_accurate_pairs(const float *faces, int n, const float *xp, const float 
     blockDim.x = 1;
     for (int i = 0; i < n; ++i) {
         blockIdx.x = (unsigned)i; threadIdx.x = 0;
-        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, nullptr, 0, g_thin_h);
+        face_setup_one(i, faces, nullptr, bbox, rec + (size_t)i * REC, thr, 1.f, 100.f, g_thin_h);
     }
     for (int i = 0; i < n; ++i) {
         Face fc;

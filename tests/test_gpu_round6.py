@@ -60,7 +60,7 @@ def _backward(variant, fvd, texd, st, g, IS):
 def test_split_faces_equal_the_unsplit_kernel_on_a_live_scene(variant):
     """The face-major backward on geometry a training step rendered (16 x 1280 faces at 512^2; faces of up to 1560 candidate
     sub-tiles where the median is 63): with k_face_order's default threshold the heavy faces are split into work items whose
-    partial sums the last arriving item adds in part order.  Against umr_debug_set("face_split", 0) -- one wave per face, round 5's
+    partial sums k_split_reduce adds in part order.  Against umr_debug_set("face_split", 0) -- one wave per face, round 5's
     kernel: faces of a single culling pass cannot split and come out bit-identical; split faces agree to summation order; two runs
     of the split kernel give the same bits (no float atomics, arrival order does not matter)."""
     from umr_amd import _lib

@@ -343,7 +343,7 @@ def _subtiles_under_bbox(faces, IS):
 @pytest.mark.parametrize("variant", ["one_pass", "one_pass_packed", "texel_only", "silhouette"])
 def test_split_faces_sum_to_the_unsplit_result(L, variant):
     """k_face_order splits a face whose estimated work exceeds umr_debug_set("face_split", T) into several work items, each a
-    share of the face's culling passes; the last item to arrive adds the parts' partial sums in part order.  An 80-face mesh at
+    share of the face's culling passes; k_split_reduce then adds the parts' partial sums in part order.  An 80-face mesh at
     IS = 256 (faces of ~300 sub-tiles = 5 culling passes) with T = 16: most faces split.  Against T = 0 (one wave per face):
     faces of a single culling pass cannot split and must come out bit-identical; split faces differ by summation order only;
     the split result repeats bit for bit."""

@@ -89,9 +89,11 @@ L.append("**%.0f images/s**, %.2f ms/step -- train_s1, bs 16, whole step (distan
          % (full["value"], full["ms_per_step"], c["hip_graph"], c.get("eager_host_enqueue_ms_per_step") or float("nan"),
             c["host_enqueue_ms_per_step"], c.get("hot_path_images_per_s") or float("nan"), c.get("hot_path_ms_per_step") or float("nan"),
             full["cpu_baseline"]["cores"], full["cpu_baseline"]["value"]))
-L.append("`roofline` (HIP events of the library around each raster main kernel, live training state of the profile pass -- the scene of "
-         "steps 41+ of THIS run's trajectory, +-40 %% from run to run; the fixed-scene table below is the comparable one):\n")
-L.append("| launch | avg us | algorithmic MB | % of 8 TB/s | PMC HBM MB | VALU wave-instr | lane use | VALU issue / peak | wave wait |\n|---|---|---|---|---|---|---|---|---|")
+L.append("`roofline` (library-owned HIP events around each raster main kernel).  `avg us` / `%% of 8 TB/s` are the line's DETERMINISTIC figures: "
+         "the kernel on the frozen captures of a training step's own geometry (%s; 20 launches each, mean over the scenes) -- they repeat "
+         "from run to run; `live us` is what THIS run's trajectory rendered at its profile pass (+-40 %% between runs of one build).  PMC "
+         "columns: the step's own launches (`profiles/traffic.json`).\n" % rf.get("source", "-"))
+L.append("| launch | avg us | live us | algorithmic MB | % of 8 TB/s | PMC HBM MB | VALU wave-instr | lane use | VALU issue / peak | VALU busy | wave wait |\n|---|---|---|---|---|---|---|---|---|---|---|")
 tk = {short(k): v for k, v in tr["kernels"].items()}
 
 
@@ -109,12 +111,33 @@ for name, key, kp in (("shared render's one-pass backward (packed state), N = 16
     k = rf if key is None else rf.get(key, {})
     t = pmc(kp); v = t.get("valu", {})
     if k.get("avg_us"):
-        L.append("| %s | %.1f | %.1f | %.1f | %s | %s | %s | %s | %s |" % (
-            name, k["avg_us"], k["alg_bytes_per_launch"] / 1e6, 100 * k["frac"],
+        L.append("| %s | %.1f | %s | %.1f | %.1f | %s | %s | %s | %s | %s | %s |" % (
+            name, k["avg_us"], "%.1f" % k["live"]["avg_us"] if k.get("live", {}).get("avg_us") else "-", k["alg_bytes_per_launch"] / 1e6, 100 * k["frac"],
             "%.0f" % (t["hbm_bytes_per_launch"] / 1e6) if t else "-", "%.1f M" % (v["issued_wave_instr"] / 1e6) if v else "-",
             "%.2f" % v["lane_use"] if v.get("lane_use") else "-", "%.3f" % v["frac_of_peak"] if v else "-",
+            "%.2f" % v["busy_frac"] if v.get("busy_frac") is not None else "-",
             "%.2f" % v["wave_wait_frac"] if v.get("wave_wait_frac") is not None else "-"))
 L.append("\nSummed raster main kernels: %.0f us per step (%s launches).\n" % (rf.get("raster_kernels_us_per_step", float("nan")), rf.get("raster_launches_per_step")))
+if rf.get("scenes"):
+    L.append("## Frozen scenes, kernel only (`roofline.scenes` of the line above; `tools/scene_times.py`)\n")
+    L.append(rf.get("scenes_note", "") + "\n")
+    for sn, d_ in rf["scenes"].items():
+        L.append("* %s: %s" % (sn, ", ".join("%s %.1f" % kv for kv in d_.items())))
+    L.append("")
+for sc_name in ("live_s1_a", "live_s1_b", "survey_8d"):
+    pj = os.path.join(FAST, "pmc_" + sc_name, "pmc_summary.json")
+    if os.path.exists(pj):
+        keep(pj, "pmc_%s.json" % sc_name)
+        pm = json.load(open(pj))
+        L.append("Counters of the raster kernels on the frozen scene %s (`profiles/%s_pmc_%s.json`, `tools/pmc_passes.py`, one group per run):\n" % (sc_name, tag, sc_name))
+        L.append("| kernel | us in the SQ pass | VALU wave-instr | VALU busy | wave wait | issue stall | L2 hit rate |\n|---|---|---|---|---|---|---|")
+        for kn, c_ in pm["kernels"].items():
+            if not kn.startswith("k_raster") or "SQ_INSTS_VALU" not in c_:
+                continue
+            g_ = lambda n, f="%.2f": (f % c_[n]) if c_.get(n) is not None else "-"
+            L.append("| `%s` | %s | %.1f M | %s | %s | %s | %s |" % (kn[:60], g_("kernel_us_in_sq2_pass", "%.1f"), c_["SQ_INSTS_VALU"] / 1e6, g_("valu_busy_frac"),
+                                                                g_("SQ_WAIT_ANY/WAVE_CYCLES"), g_("SQ_WAIT_INST_ANY/WAVE_CYCLES"), g_("tcc_hit_rate")))
+        L.append("")
 L.append("## Kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
 L.append("Command: `bench.py --steps 10 --warmup 3 --profile-steps 0 --graph 0` (eager: every kernel a dispatch of its own; 13 training steps "
          "from initialisation). `profiles/%s_bench_kernel_stats.csv` is rocprofv3's own table over the whole process -- its first steps hold "
@@ -140,7 +163,7 @@ if kern:
 L.append("## Other workloads (`tools/refresh_slow.sh`)\n")
 for name, what in (("bench_full_eager", "default workload, eager launches (`--graph 0`)"), ("bench_s2", "train_s2, bs 16, K = 8 (`--workload s2`; BASELINE configs[2] per-GPU shape)"),
                    ("bench_s2_cfg4", "configs[3] shape (`--workload s2 --image-size 512 --subdivide 4`: IS 1024, 5120 faces)"),
-                   ("bench_ddp1", "1-rank RCCL (`--force-ddp 1`, eager)"), ("bench_full_two_renders", "train_s1 with the reference's two renders (`--share-mask-render 0`)"),
+                   ("bench_ddp1", "1-rank RCCL (`--force-ddp 1`): the whole step incl. the bucket all-reduces from one HIP graph"), ("bench_full_two_renders", "train_s1 with the reference's two renders (`--share-mask-render 0`)"),
                    ("bench_s2_two_renders", "train_s2 with the reference's two renders")):
     d = slow.get(name)
     if not d:

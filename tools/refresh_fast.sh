@@ -16,6 +16,11 @@ python -c "from umr_amd import _lib; print(_lib.build_id())" > "$O/build_id.txt"
     --cpu-baseline 0 --hot-path-sub 0 --fixed-scene 0 > "$O/stats.log" 2>&1)
 tools/collect_traffic.sh "$O/traffic" > "$O/traffic.log" 2>&1
 cp "$O/traffic/traffic.json" profiles/traffic.json
+# counters of the raster kernels on the FROZEN scenes (deterministic; the passes above see the live step's lottery scene)
+for sc in live_s1_a survey_8d; do
+  if [ "$sc" = survey_8d ]; then T="tools/kernels.py 3"; else T="tools/scene_times.py profiles/scenes/$sc.npz --iters 3"; fi
+  PMC_TARGET="$T" PMC_GROUPS=sq1,sq2,tcc1 python tools/pmc_passes.py "$O/pmc_$sc" > "$O/pmc_$sc.log" 2>&1
+done
 python bench.py > "$O/bench_full.json" 2> "$O/bench_full.err"
 python bench.py --model 0 --cpu-baseline 0 --fixed-scene 0 > "$O/bench_hotpath_only.json" 2> "$O/bench_hot.err"
 python - "$O" <<'PY'

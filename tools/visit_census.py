@@ -22,10 +22,10 @@ STATIONS = ["live_face_lanes", "visited_face_lanes", "cull_candidates", "pass_ba
             "lanes_depth_in_range", "lanes_nonzero_weight", "lanes_not_dead_individually", "visits(wave)", "cull_passes(wave)"]
 
 INJECT = [
-    ("                if (ti < ntiles) {\n", "                if (ti < ntiles) { CNT(2);\n"),
+    ("                if (ti < tb_end) {\n", "                if (ti < tb_end) { CNT(2);\n"),
     ("                                        0.5f * (cyh - cyl), thr_cull);\n", "                                        0.5f * (cyh - cyl), thr_cull); if (want) CNT(3);\n"),
     ("                unsigned long long tm = __ballot(want);\n", "                unsigned long long tm = __ballot(want); if (want) CNT(4); if (lane == 0) CNT(13);\n"),
-    ("                    if (mine < 0) continue;\n", "                    CNT(5); if (lane == 0) CNT(12); if (mine < 0) continue; CNT(6);\n"),
+    ("                    if (mine < 0) continue;\n", "                    CNT(5); if (lane == 0) { CNT(12); CFACE(n, f); } if (mine < 0) continue; CNT(6);\n"),
     ("                        if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue;\n",
      "                        if (!dead) CNT(11); if ((RGB == 2 || !NEED_GF || AG) && __all(dead)) continue; CNT(7);\n"),
     ("                    if (!eval_pair(p, fc, xp, yp, c_thr2, c_nis, A.amb_thr)) continue;\n",
@@ -36,7 +36,8 @@ INJECT = [
     ("    if (live) {\n        // VGPR-resident operands", "    if (live) { CNT(0);\n        // VGPR-resident operands"),
     ("    if (FM_SKIP_EMPTY && FM_WAVES == 1 && !visited) return;\n", "    if (FM_SKIP_EMPTY && FM_WAVES == 1 && !visited) return; CNT(1);\n"),
 ]
-HEAD = ('#ifndef UMR_CENSUS\n#define UMR_CENSUS\nextern "C" { long g_census[16]; long g_nrec; unsigned long long g_rec[1 << 23]; }\n'
+HEAD = ('#ifndef UMR_CENSUS\n#define UMR_CENSUS\nextern "C" { long g_census[16]; long g_nrec; unsigned long long g_rec[1 << 23]; long g_facevis[1 << 16]; }\n'
+        '#define CFACE(n, f) __atomic_fetch_add(&g_facevis[((n) * 2048 + (f)) & 0xffff], 1L, __ATOMIC_RELAXED)\n'
         '#define CNT(i) __atomic_fetch_add(&g_census[i], 1L, __ATOMIC_RELAXED)\n'
         '#define CREC(n, f, pix) do { long i_ = __atomic_fetch_add(&g_nrec, 1L, __ATOMIC_RELAXED); if (i_ < (1 << 23)) g_rec[i_] = '
         '((unsigned long long)(n) << 48) | ((unsigned long long)(f) << 32) | (unsigned)(pix); } while (0)\n#endif\n')
@@ -62,7 +63,10 @@ def build():
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(argv[0]) if argv else 2
+    scene_file = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--scene=")), None)      # a frozen capture (profiles/scenes/*.npz)
+    meshes = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--meshes=")), None)         # "12,4": which of its views
     import host_raster as HR
     from helpers import scene
     from oracle import torch_ref as TR
@@ -73,9 +77,17 @@ def main():
         if hasattr(L, name):
             getattr(L, name).argtypes, getattr(L, name).restype = argtypes, restype
     census = (ctypes.c_long * 16).in_dll(L, "g_census")
+    facevis = (ctypes.c_long * (1 << 16)).in_dll(L, "g_facevis")
     verts, faces, cams, g = scene(32, 3, seed=0)
-    pv = TR.orthographic_proj_withz(verts[:n], cams[:n], offset_z=5.) * torch.tensor([1., -1., 1.])
-    fv = np.ascontiguousarray(TR.face_vertices(TR.look_at_ortho(pv), faces[:n]).numpy(), np.float32)
+    if scene_file:
+        z = np.load(scene_file)
+        pick = [int(m) for m in meshes.split(",")] if meshes else list(range(n))
+        fv = np.ascontiguousarray(z["fv_shared"][pick], np.float32)
+        n = len(pick)
+        print("scene %s, views %s" % (scene_file, pick))
+    else:
+        pv = TR.orthographic_proj_withz(verts[:n], cams[:n], offset_z=5.) * torch.tensor([1., -1., 1.])
+        fv = np.ascontiguousarray(TR.face_vertices(TR.look_at_ortho(pv), faces[:n]).numpy(), np.float32)
     IS, TS = 512, 36
     DEL = float(np.float32(np.log(1. / 1e-10 - 1.)))
     rng = np.random.default_rng(0)
@@ -107,6 +119,12 @@ def main():
         for i in range(16):
             census[i] = 0
         shapes()
+        # wave visits per face (work items of a split face add up to their face): what ONE wave per face would have to walk
+        fvis = np.frombuffer(facevis, dtype=np.int64, count=1 << 16).copy().reshape(32, 2048)[:n, :fv.shape[1]]
+        ctypes.memset(facevis, 0, ctypes.sizeof(facevis))
+        v = fvis.ravel()
+        print("  wave visits per face: mean %.1f  median %.0f  p99 %.0f  max %d; faces never visited %.0f %%; the 10 heaviest carry %.1f %% of all visits"
+              % (v.mean(), np.median(v), np.percentile(v, 99), v.max(), 100.0 * (v == 0).mean(), 100.0 * np.sort(v)[-10:].sum() / max(v.sum(), 1)))
         return c
 
     out = HR.forward(fv, tex, IS, pooled=True, dist_eps_log=DEL, L=L)

@@ -14,6 +14,12 @@
 // texel-only 14 266 -> 12 140, vertex + texel 17 520 -> 14 956.  Measured on MI355X (us, N = 16): silhouette (N = 32) 158 -> 136,
 // texel-only 134 -> 126.5 (only with FM_VREC 0: at the 72-VGPR budget its allocation swings between 126 and 141 with
 // incidental source changes), vertex + texel 213 -> 202 -- so only the silhouette variant and the one-pass kernel take it.
+// Work items (round 6).  With A.order set (k_face_order, raster_backward.h) a wave does not own a face but an ITEM of the launch's
+// list: a whole face, or -- for a face whose estimated work exceeds the split threshold -- part p of its n parts, a contiguous share
+// of the face's culling passes.  A part leaves its partial sums in a slab and k_split_reduce, the next launch, adds the parts up in
+// part order: on the geometry a training step really renders (profiles/scenes/) a handful of faces carry 20x the median work
+// and one wave per face ran for the whole launch (one-pass backward 268 / 207 us -> 107 / 109 us on the two frozen scenes,
+// unchanged 136 us on the regular SURVEY 8d scene).  The unsplit path is the old one, instruction for instruction in the visit.
 #ifndef UMR_MUL24
 #ifdef UMR_HOST_SHIM
 #define UMR_MUL24(a, b) ((a) * (b))
