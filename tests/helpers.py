@@ -37,7 +37,7 @@ def assert_close_frac(got, ref, atol, rtol=0.0, frac=0.999, max_outlier=None, na
 
 def _record(name, n, frac_ok, max_err, atol, rtol, need, max_outlier):
     """Measured parity figures, one JSON line per check: printed (pytest -s / failure reports) and appended to
-    gpurun_out/parity_measured.jsonl so the numbers behind every tolerance are on file (profiles/r02_parity_measured.jsonl)."""
+    gpurun_out/parity_measured.jsonl so the numbers behind every tolerance are on file (profiles/archive_r01_r03/r02_parity_measured.jsonl)."""
     import json
     import os
     rec = dict(check=name, test=os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], elements=int(n),

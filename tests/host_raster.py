@@ -16,7 +16,7 @@ SO = os.path.join(SRC_DIR, "libumr_host.so")
 TUS = ["raster", "geometry", "losses", "perceptual", "edt", "atlas", "regs", "eval"]     # umr_amd/build.py SOURCES
 
 NO_P2F, ALPHA_ONLY, FACE_ID_ONLY = 1, 2, 4      # UMR_RASTER_* (include/umr_hip.h)
-BWD_GRAD_POOLED, BWD_ALPHA_ONLY, BWD_ALPHA_GEOMETRY, BWD_PACKED_STATE = 1, 2, 4, 8          # UMR_BWD_*
+BWD_GRAD_POOLED, BWD_ALPHA_ONLY, BWD_ALPHA_GEOMETRY, BWD_PACKED_STATE, BWD_REUSE_WORKSPACE = 1, 2, 4, 8, 16          # UMR_BWD_*
 
 
 def available():
@@ -171,8 +171,9 @@ def forward(faces, textures, image_size, background=(0, 0, 0), near=1.0, far=100
 
 def backward(faces, textures, soft_colors, aggrs_info, grad_soft_colors, image_size, near=1.0, far=100.0, eps=1e-3,
              sigma_val=1e-5, dist_eps_log=None, gamma_val=1e-4, func_id_rgb=1, double_side=True, need_gf=True, need_gt=True,
-             grad_flags=0, tex_group=1, L=None, **modes):
-    """umr_raster_backward on host arrays -> (grad_faces | None, grad_textures | None)."""
+             grad_flags=0, tex_group=1, L=None, workspace=None, **modes):
+    """umr_raster_backward on host arrays -> (grad_faces | None, grad_textures | None).  workspace: the 'ws' of the forward call of
+    the same faces (for UMR_BWD_REUSE_WORKSPACE); default a fresh one."""
     L = L or lib()
     faces = np.ascontiguousarray(faces, np.float32).reshape(faces.shape[0], faces.shape[1], 9)
     N, F = faces.shape[:2]
@@ -185,7 +186,7 @@ def backward(faces, textures, soft_colors, aggrs_info, grad_soft_colors, image_s
     gf = np.zeros((N, F, 9), np.float32) if need_gf else None
     gt = np.zeros((N, F, TS, 3), np.float32) if need_gt else None
     wsb = L.umr_raster_workspace_bytes(N, F)
-    ws = np.zeros(wsb + 64, np.uint8)
+    ws = np.zeros(wsb + 64, np.uint8) if workspace is None else workspace
     scal = _scalars(near, far, eps, sigma_val, dist_eps_log, gamma_val, func_id_rgb, double_side, **modes)
     fl = int(grad_flags) | ((tex_group & 0xffff) << 8 if tex_group > 1 else 0)
     rc = L.umr_raster_backward(_p(faces), _p(tex), _p(sc), None, _p(ag), _p(gf), _p(gt), _p(g), fl, int(need_gf), int(need_gt),

@@ -65,7 +65,7 @@ def test_raster_cabi_vs_reference_golden(name):
     np.testing.assert_array_equal(t2n(o["faces_info"]), g["faces_info"])
     # 1e-4 = north_star render tolerance
     assert_close_frac(t2n(o["soft_colors"]), g["soft_colors"], atol=1e-4, frac=1.0, max_outlier=1e-5, name="soft_colors")   # measured on MI355X: max |err| 3.6e-7, every element within 1e-4
-    # Bounds below = ~10x what the MI355X measured (profiles/r03_parity_measured.jsonl), every element (frac = 1).
+    # Bounds below = ~10x what the MI355X measured (profiles/archive_r01_r03/r03_parity_measured.jsonl), every element (frac = 1).
     if int(g["func_id_rgb"]) == 1:
         # soft-max sum / max planes: measured max relative error 2.7e-7 (sum ~ 2e4)
         assert_close_frac(t2n(o["aggrs_info"]), g["aggrs_info"], atol=0, rtol=3e-6, frac=1.0, name="aggrs")
@@ -328,7 +328,7 @@ def test_train_s1_step_vs_oracle(oracle_built):
     for k in ("delta_v", "cam", "tex_flow"):
         r = out_c[k].grad.numpy()
         s = np.abs(r).max()
-        # measured (profiles/r03_parity_measured.jsonl): camera and texture-flow gradients agree in every element (1e-6 of scale);
+        # measured (profiles/archive_r01_r03/r03_parity_measured.jsonl): camera and texture-flow gradients agree in every element (1e-6 of scale);
         # 4 of the 972 vertex-gradient values differ by up to 1 % of scale -- the adversarial term's rotated camera, float64
         # numpy in the restatement (as in the reference's script), float32 on the device
         assert_close_frac(t2n(out_g[k].grad), r, atol=3e-4 * s, rtol=5e-3, frac=(0.995 if k == "delta_v" else 1.0),

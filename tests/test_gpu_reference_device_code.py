@@ -113,7 +113,7 @@ def test_product_vs_reference_device_code_full_size(ts, rgb):
 
 def test_fma_contraction_sensitivity_of_the_reference_text():
     """nvcc contracts a*b+c into FMA by default; the goldens (and the oracle) come from non-contracted builds.  The same
-    text built with contraction on: how far do its images move?  Reported in profiles/r02_parity_measured.jsonl; bounded by
+    text built with contraction on: how far do its images move?  Reported in profiles/archive_r01_r03/r02_parity_measured.jsonl; bounded by
     the north_star tolerance so the choice of contraction mode cannot hide a parity failure."""
     h = _lib("libsoftras_ref_gfx950_fma.so")
     g = load_golden("raster_softmax_ts36.npz")
@@ -127,7 +127,7 @@ def test_product_vs_fma_contracted_reference_at_full_size():
     CUDA render is only defined up to that.  The product (no contraction, like the goldens) against the SAME reference device
     text built with contraction ON (libsoftras_ref_gfx950_fma.so), 2 x 1280 faces x 512^2, TS = 36: the fraction of values
     within the north_star's 1e-4 for alpha, for alpha-weighted rgb (what every consumer composites) and for raw rgb -- whose
-    outliers outside the silhouette are ratios of weights ~1e-9.  Figures are recorded (profiles/r03_parity_measured.jsonl) and
+    outliers outside the silhouette are ratios of weights ~1e-9.  Figures are recorded (profiles/archive_r01_r03/r03_parity_measured.jsonl) and
     bounded at what was measured."""
     from oracle import torch_ref
     from umr_amd import functional as UF
@@ -149,7 +149,7 @@ def test_product_vs_fma_contracted_reference_at_full_size():
         err = np.abs(a.astype(np.float64) - b)
         res[name] = (float((err <= 1e-4).mean()), float(err.max()))
         _record(name, err.size, res[name][0], res[name][1], 1e-4, 0.0, 0.99, None)
-    # Measured on MI355X (profiles/r03_parity_measured.jsonl): alpha 99.61 % within 1e-4 (max 9.6e-3), alpha-weighted rgb 98.41 %
+    # Measured on MI355X (profiles/archive_r01_r03/r03_parity_measured.jsonl): alpha 99.61 % within 1e-4 (max 9.6e-3), alpha-weighted rgb 98.41 %
     # (max 0.14), raw rgb 97.87 % (max 0.54).  Contraction moves the reference's own soft fragments by its rounding noise (~1e-3
     # per face, tests/test_kernel_source_on_host.py) and its depth weights exp(zn / gamma), gamma = 1e-4, by 7e-4 per ulp of zn:
     # where two faces sit at nearly the same depth the winner changes.  "Within 1e-4 of the reference's CUDA render" is

@@ -499,8 +499,9 @@ def test_face_start_order_does_not_change_results():
         w = torch.rand(n, 4, IS, IS, generator=gen).to(DEV)
         wa = torch.rand(n, IS // 2 if IS % 2 == 0 else IS, IS // 2 if IS % 2 == 0 else IS, generator=gen).to(DEV)
         outs = []
-        for on in (2, 0):                                                    # 2: ordered start for every variant
+        for on in (1, 0):                                                    # 1: cost-ordered work-item lists (every variant)
             _lib.debug_set("face_order", on)
+            _lib.debug_set("face_split", 0)                                  # (order only: a split face sums in another order, round 6's tests)
             try:
                 res = []
                 fv = fv0.detach().clone().requires_grad_(True); tex = tex0.clone().requires_grad_(True)
@@ -518,6 +519,7 @@ def test_face_start_order_does_not_change_results():
                 outs.append(res)
             finally:
                 _lib.debug_set("face_order", 1)
+                _lib.debug_set("face_split", -1)
         for x, y in zip(outs[0], outs[1]):
             assert torch.isfinite(x).all() and float(x.abs().sum()) > 0
             assert torch.equal(x, y)

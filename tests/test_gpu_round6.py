@@ -46,6 +46,9 @@ def _backward(variant, fvd, texd, st, g, IS):
     elif variant == "texel_only":
         rc = L.umr_raster_backward(p(fvd), p(texd), p(st["sc"]), None, p(st["aggrs"]), None, p(gt), p(g), UMR_BWD_GRAD_POOLED,
                                    0, 1, N, F, TS, IS, *st["scal"], p(st["ws"]), st["wsb"], stream)
+    elif variant == "vertex_only":       # (train_s2's unseen-view / part renders: textures detached)
+        rc = L.umr_raster_backward(p(fvd), p(texd), p(st["sc"]), None, p(st["aggrs"]), p(gf), None, p(g), UMR_BWD_GRAD_POOLED,
+                                   1, 0, N, F, TS, IS, *st["scal"], p(st["ws"]), st["wsb"], stream)
     else:
         packed = variant == "one_pass_packed"
         rc = L.umr_raster_backward(p(fvd), p(texd), None if packed else p(st["sc"]), None, p(st["aggrs"]), p(gf), p(gt), p(g),
@@ -56,7 +59,7 @@ def _backward(variant, fvd, texd, st, g, IS):
     return gf, gt
 
 
-@pytest.mark.parametrize("variant", ["one_pass_packed", "one_pass", "texel_only", "silhouette"])
+@pytest.mark.parametrize("variant", ["one_pass_packed", "one_pass", "texel_only", "vertex_only", "silhouette"])
 def test_split_faces_equal_the_unsplit_kernel_on_a_live_scene(variant):
     """The face-major backward on geometry a training step rendered (16 x 1280 faces at 512^2; faces of up to 1560 candidate
     sub-tiles where the median is 63): with k_face_order's default threshold the heavy faces are split into work items whose
@@ -76,7 +79,6 @@ def test_split_faces_equal_the_unsplit_kernel_on_a_live_scene(variant):
     nt = _subtiles_under_bbox(fv.numpy(), IS)
     assert nt.max() > 1000 and np.median(nt) < 100
     try:
-        _lib.debug_set("face_order", 2)          # (the silhouette variant takes the item lists only with face_order 2)
         _lib.debug_set("face_split", 0)
         ref = _backward(variant, fvd, texd, st, g, IS)
         _lib.debug_set("face_split", -1)         # the default threshold
@@ -84,7 +86,6 @@ def test_split_faces_equal_the_unsplit_kernel_on_a_live_scene(variant):
         again = _backward(variant, fvd, texd, st, g, IS)
     finally:
         _lib.debug_set("face_split", -1)
-        _lib.debug_set("face_order", 1)
     single = torch.from_numpy(nt <= 64).to(DEV)
     changed = 0
     for a, b, c, name in zip(ref, got, again, ("grad_faces", "grad_textures")):
@@ -259,3 +260,32 @@ def test_replayed_step_matches_the_eager_step_at_bench_size(workload):
         print("[graph-check] this stack replays the reduction's memset node: the staged bias gradient is no longer needed")
     else:
         assert any("decoder" in n and n.endswith(".bias") for n, _ in rep["bad"]), rep
+
+
+def test_backward_reuses_the_forward_workspace():
+    """UMR_BWD_REUSE_WORKSPACE through the C ABI on the device: the one-pass backward handed the workspace its forward filled gives
+    the bits of the stateless call that rebuilds the face records (one small launch less per backward -- what the training steps'
+    shared render does: umr_amd/ops.py keeps the forward's workspace with the saved state)."""
+    from umr_amd import _lib
+    from tests.helpers import scene
+    from oracle import torch_ref
+    L, p = _lib.lib(), _lib.ptr
+    verts, faces, cams, gen = scene(2, 3, seed=12)
+    proj = torch_ref.orthographic_proj_withz(verts, cams, 5.) * torch.tensor([1., -1., 1.])
+    fvd = torch_ref.face_vertices(torch_ref.look_at_ortho(proj), faces).reshape(2, -1, 9).contiguous().to(DEV)
+    N, F, IS, TS = 2, fvd.shape[1], 256, 36
+    texd = torch.rand(N, F, TS, 3, generator=gen).to(DEV)
+    g = torch.randn(N, 4, IS // 2, IS // 2, generator=gen).to(DEV)
+    st = _forward_cabi(fvd, texd, IS, True, packed=True)
+    out = []
+    for reuse in (False, True):
+        gf, gt = torch.zeros(N, F, 9, device=DEV), torch.zeros(N, F, TS, 3, device=DEV)
+        ws = st["ws"] if reuse else torch.empty_like(st["ws"])
+        rc = L.umr_raster_backward(p(fvd), p(texd), None, None, p(st["aggrs"]), p(gf), p(gt), p(g),
+                                   UMR_BWD_GRAD_POOLED | UMR_BWD_ALPHA_GEOMETRY | UMR_BWD_PACKED_STATE | (16 if reuse else 0),
+                                   1, 1, N, F, TS, IS, *st["scal"], p(ws), st["wsb"], _lib.stream_ptr(torch.device(DEV)))
+        assert rc == 0
+        torch.cuda.synchronize()
+        out.append((gf, gt))
+    assert float(out[0][0].abs().max()) > 0 and float(out[0][1].abs().max()) > 0
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])

@@ -273,7 +273,7 @@ def test_default_build_takes_the_references_decisions_on_fuzzed_scenes(L, oracle
     degenerate faces), a few scenes each: with the default switches ("exact_edges" = 1, thin faces and the noise-widened cull,
     HISTORY.md 4.1 / 4.4) the emulated kernels take every discrete decision as the reference does -- no pixel with a missing or
     extra face, alpha within a few ulp of the oracle's (1e-6), no colour value off by 1e-4, every gradient (full, texel-only,
-    silhouette backward) within 1e-5 of the scene's largest.  (3 600 scenes of the same generator: profiles/r03_emulator_fuzz.json.)"""
+    silhouette backward) within 1e-5 of the scene's largest.  (3 600 scenes of the same generator: profiles/archive_r01_r03/r03_emulator_fuzz.json.)"""
     import os
     import sys
     sys.path.insert(0, os.path.join(HR.ROOT, "tools"))
@@ -340,7 +340,7 @@ def _subtiles_under_bbox(faces, IS):
     return np.where((px0 <= px1) & (py0 <= py1), ((px1 // 4) - (px0 // 4) + 1) * ((py1 // 4) - (py0 // 4) + 1), 0)
 
 
-@pytest.mark.parametrize("variant", ["one_pass", "one_pass_packed", "texel_only", "silhouette"])
+@pytest.mark.parametrize("variant", ["one_pass", "one_pass_packed", "texel_only", "vertex_only", "silhouette"])
 def test_split_faces_sum_to_the_unsplit_result(L, variant):
     """k_face_order splits a face whose estimated work exceeds umr_debug_set("face_split", T) into several work items, each a
     share of the face's culling passes; k_split_reduce then adds the parts' partial sums in part order.  An 80-face mesh at
@@ -360,6 +360,8 @@ def test_split_faces_sum_to_the_unsplit_result(L, variant):
     def run():
         if variant == "texel_only":
             return HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, need_gf=False, grad_flags=HR.BWD_GRAD_POOLED, L=L, **cfg)
+        if variant == "vertex_only":
+            return HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, need_gt=False, grad_flags=HR.BWD_GRAD_POOLED, L=L, **cfg)
         if variant == "silhouette":
             return HR.backward(faces, None, np.ascontiguousarray(o["soft_colors"][:, 3]), None, np.ascontiguousarray(gp[:, 3]), IS,
                                need_gt=False, grad_flags=HR.BWD_ALPHA_ONLY | HR.BWD_GRAD_POOLED, L=L, **cfg)
@@ -368,7 +370,6 @@ def test_split_faces_sum_to_the_unsplit_result(L, variant):
             return HR.backward(faces, tex, None, st, gp, IS, grad_flags=HR.BWD_GRAD_POOLED | HR.BWD_ALPHA_GEOMETRY | HR.BWD_PACKED_STATE, L=L, **cfg)
         return HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, grad_flags=HR.BWD_GRAD_POOLED | HR.BWD_ALPHA_GEOMETRY, L=L, **cfg)
 
-    L.umr_debug_set(b"face_order", 2)          # (the silhouette variant takes the item lists only with face_order 2)
     try:
         L.umr_debug_set(b"face_split", 0)
         ref = run()
@@ -376,7 +377,6 @@ def test_split_faces_sum_to_the_unsplit_result(L, variant):
         got, again = run(), run()
     finally:
         L.umr_debug_set(b"face_split", -1)
-        L.umr_debug_set(b"face_order", 1)
     single_pass = _subtiles_under_bbox(faces, IS) <= 64
     assert single_pass.any() and (~single_pass).sum() > F // 2
     differs = 0
@@ -389,3 +389,28 @@ def test_split_faces_sum_to_the_unsplit_result(L, variant):
         assert_close_frac(b, a, atol=2e-6 * s, rtol=1e-5, frac=1.0, name="host split vs unsplit (%s)" % variant)
         differs += int((a != b).any(axis=tuple(range(2, a.ndim))).sum())
     assert differs > 0, "no face was split: the test exercises nothing"
+
+
+def test_backward_reads_the_forwards_workspace_when_told_to(L):
+    """UMR_BWD_REUSE_WORKSPACE: handed the workspace its forward call filled, the backward skips k_face_setup and reads those face
+    records and bounding boxes -- same bits out as the stateless call that rebuilds them, for the one-pass kernel (what the training
+    steps' shared render does) and the texel-only variant; a workspace that was NOT filled by a forward gives something else (the flag
+    is taken at its word), so the equality is not vacuous."""
+    import torch
+    IS, TS = 128, 9
+    faces, gen = _scene_faces(2, 2, seed=5)
+    F = faces.shape[1]
+    tex = torch.rand(2, F, TS, 3, generator=gen).numpy()
+    gp = torch.randn(2, 4, IS // 2, IS // 2, generator=gen).numpy()
+    cfg = dict(CFG, func_id_rgb=1)
+    o = HR.forward(faces, tex, IS, pooled=True, L=L, **cfg)
+    for flags, kw in ((HR.BWD_GRAD_POOLED | HR.BWD_ALPHA_GEOMETRY, {}), (HR.BWD_GRAD_POOLED, dict(need_gf=False))):
+        ref = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, grad_flags=flags, L=L, **cfg, **kw)
+        got = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, grad_flags=flags | HR.BWD_REUSE_WORKSPACE, workspace=o["ws"],
+                          L=L, **cfg, **kw)
+        for a, b in zip(ref, got):
+            if a is not None:
+                np.testing.assert_array_equal(a, b)
+        stale = HR.backward(faces, tex, o["soft_colors"], o["aggrs_info"], gp, IS, grad_flags=flags | HR.BWD_REUSE_WORKSPACE,
+                            workspace=np.zeros_like(o["ws"]), L=L, **cfg, **kw)
+        assert any(a is not None and not np.array_equal(a, b) for a, b in zip(ref, stale))

@@ -132,10 +132,10 @@ for sc_name in ("live_s1_a", "live_s1_b", "survey_8d"):
         L.append("Counters of the raster kernels on the frozen scene %s (`profiles/%s_pmc_%s.json`, `tools/pmc_passes.py`, one group per run):\n" % (sc_name, tag, sc_name))
         L.append("| kernel | us in the SQ pass | VALU wave-instr | VALU busy | wave wait | issue stall | L2 hit rate |\n|---|---|---|---|---|---|---|")
         for kn, c_ in pm["kernels"].items():
-            if not kn.startswith("k_raster") or "SQ_INSTS_VALU" not in c_:
+            if "k_raster" not in kn or "SQ_INSTS_VALU" not in c_:
                 continue
             g_ = lambda n, f="%.2f": (f % c_[n]) if c_.get(n) is not None else "-"
-            L.append("| `%s` | %s | %.1f M | %s | %s | %s | %s |" % (kn[:60], g_("kernel_us_in_sq2_pass", "%.1f"), c_["SQ_INSTS_VALU"] / 1e6, g_("valu_busy_frac"),
+            L.append("| `%s` | %s | %.1f M | %s | %s | %s | %s |" % (kn.replace("void ", "")[:60], g_("kernel_us_in_sq2_pass", "%.1f"), c_["SQ_INSTS_VALU"] / 1e6, g_("valu_busy_frac"),
                                                                 g_("SQ_WAIT_ANY/WAVE_CYCLES"), g_("SQ_WAIT_INST_ANY/WAVE_CYCLES"), g_("tcc_hit_rate")))
         L.append("")
 L.append("## Kernel trace (`rocprofv3 --kernel-trace --stats`)\n")

@@ -66,6 +66,8 @@ size_t ws_order_bytes(int N, int F) {
     }
     return worst;
 }
+int g_block_order = 1;           // umr_debug_set("block_order", 0 | 1): the forward starts its 16x16 workgroup blocks in descending order of the face
+                                 // count of their super-block (k_block_order) instead of row by row
 int g_fm_runs = 0;               // umr_debug_set("fm_runs", r): runs of faces per XCD and mesh (fm_owned_face) for every face-major launch; 0 = automatic
 int g_fm_rotate = -1;            // umr_debug_set("fm_rotate", 0 | 1): mesh m's runs go to XCD (x + m) % 8 instead of x (item lists only); -1 = automatic
 int g_split_budget_div = 16;     // umr_debug_set("face_split_budget", d >= 4): a list may hold gsz / d + 16 extra items (<= the gsz / 4 + 16 the workspace
@@ -78,9 +80,8 @@ int g_xcd_remap = 2;             // umr_debug_set("xcd_remap", v): work mapping 
                                  // blockIdx order (12-25 % slower: one mesh's records then live in all eight L2s)
 int g_face_order_group = 0;      // umr_debug_set("face_order_group", G): meshes per start-order group (0 = automatic)
 int g_face_order = 1;            // umr_debug_set("face_order", v): 0 = every face-major backward starts one wave per face in index order,
-                                 // 1 = work-item lists (k_face_order: heavy faces split) -- in cost order, heavy items first, for the light
-                                 // variants (texel gradients only, one pass, silhouette), in index order for the others --, 2 = cost
-                                 // order for all variants
+                                 // 1 = work-item lists in cost order (k_face_order: heavy faces split, heavy items first), 3 = work-item
+                                 // lists in index order (A/B)
 float g_thin_face_h = THIN_FACE_H;   // umr_debug_set("thin_face_h_1e6", h * 1e6): faces with a height below h screen units evaluate
                                      // inside pixels the reference's way (k_face_setup, bit 4 of the record's flags)
 bool g_exact_edges = true;           // umr_debug_set("exact_edges", 0 | 1): eval_pair's amb_thr = 20 sigma (see there).  On by default:
@@ -175,6 +176,7 @@ int umr_debug_set(const char *key, int value) {
     if (std::string(key) == "face_order") { g_face_order = value; return UMR_OK; }
     if (std::string(key) == "exact_edges") { g_exact_edges = value != 0; return UMR_OK; }
     if (std::string(key) == "thin_face_h_1e6") { g_thin_face_h = value < 0 ? THIN_FACE_H : 1e-6f * (float)value; return UMR_OK; }
+    if (std::string(key) == "block_order") { g_block_order = value != 0; return UMR_OK; }
     if (std::string(key) == "fm_runs") { g_fm_runs = std::max(0, value); return UMR_OK; }
     if (std::string(key) == "fm_rotate") { g_fm_rotate = value < 0 ? -1 : (value != 0); return UMR_OK; }
     if (std::string(key) == "face_split_budget") { g_split_budget_div = std::max(4, value); return UMR_OK; }
@@ -289,6 +291,19 @@ int umr_raster_forward_vis(const float *faces, const float *textures, float *fac
                                                       sqrtf(A.threshold), near_, far_, g_thin_face_h);
     setup_bins(A, workspace, N, F, image_size, st);
     const int blocks = N * A.tiles_x * A.tiles_y;
+    // start the heavy workgroup blocks first (k_block_order): the list lives in the workspace's work-item region, which belongs to
+    // the backward call that follows (a backward that reuses this workspace reads the records and boxes only)
+    if (g_block_order && !general && A.sb_count && A.no_xcd_remap == 2 && A.tiles_y % 8 == 0 && A.tiles_x <= 256 && A.tiles_y <= 256) {
+        const int per_mesh = (A.tiles_y >> 3) * A.tiles_x;
+        const int G = std::max(1, std::min(std::min(N, 65535), BLOCK_ORDER_MAX_ENTRIES / per_mesh));
+        const int groups = (N + G - 1) / G;
+        if (per_mesh <= BLOCK_ORDER_MAX_ENTRIES && (size_t)groups * 8 * G * per_mesh * sizeof(int) <= ws_order_bytes(N, F)) {
+            int *border = (int *)((char *)workspace + ws_order_offset(N, F, image_size));
+            UMR_LAUNCH(k_block_order, dim3(8, groups), BLOCK_ORDER_THREADS, 0, st, A.sb_count, border, N, A.tiles_x, A.tiles_y, A.sb_size, A.sb_nx,
+                       A.sb_slots, G);
+            A.block_order = border; A.block_group = G;
+        }
+    }
     {
         // algorithmic bytes of one forward launch: 24 IS^2 + F (36 + 12 TS + 16) per mesh
         // (silhouette-only launches are accounted separately, id 2: 4 IS^2 + 36 F)
@@ -388,14 +403,12 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
     // "bwd_pixel_major", or TS beyond the LDS accumulators) would send the rgb gradient into grad_faces: rejected, nothing
     // enqueued (soft_rasterize_cuda.cpp:122-129 raises on what it cannot do, it never returns other data)
     if (alpha_geom && !face_major) return UMR_ERR_ARG;
-    // Work-item lists in cost order (k_face_order).  Measured on MI355X, us per launch at N = 16 / 128 (F = 1280, IS = 512), index
-    // order -> ordered in groups of 16 | 8 meshes, regular SURVEY 8d scene (round 3): texel gradients only 137.6 -> 122.3 | 129.7 and
-    // 814 -> 838 | 798; vertex + texel gradients 205 -> 263 | 232 and 1325 -> 1900 | 1587 (its waves read 28 B of state per pixel:
-    // with 16 meshes' heavy faces in flight an XCD's 4 MB L2 no longer holds their state); silhouette unchanged there, but on the
-    // frozen captures of a training step's own geometry (round 6, profiles/scenes) 96.7 -> 73.6 and 83.6 -> 71.4.  So: the light
-    // variants, one group when the launch has <= 16 meshes, groups of 8 otherwise.
+    // Work-item lists in cost order (k_face_order), every variant.  Round 3 (one wave per face, regular SURVEY 8d scene) had found the
+    // cost order slower for the variants that read 28 B of state per pixel (205 -> 263 us) and kept them in index order; with heavy
+    // faces split (round 6) it wins there too: vertex-gradient backward 160 / 176 -> 135 / 139 us on the frozen training scenes,
+    // 187 -> 182 on the 8d scene (profiles/r06_scene_ab_block_order.jsonl).  One group when the launch has <= 16 meshes, groups of 8 otherwise.
     const int order_mode = alpha_only ? 2 : (((!need_grad_faces || alpha_geom) && func_id_rgb == 1) ? 1 : 0);
-    const bool sorted_items = g_face_order == 2 || order_mode != 0;
+    const bool sorted_items = g_face_order != 3;
     const bool ordered = face_major && g_face_order >= 1 && FM_WAVES == 1 &&
                          F % 8 == 0 && F <= 0xffff && F / 8 <= ORDER_MAX_ENTRIES;
     int G = order_group_for(N, F);

@@ -145,9 +145,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_raster_backward(const RasterArg
 //      each a contiguous share of the face's culling passes.  T = the smallest of T0 x {1, 1.25, 1.5, 2, 3, 4, 8, 16} whose extra
 //      items fit the list's budget X (so the launch grid and the slab pool have fixed sizes);
 //   3. sorts the ITEMS by descending work (counting sort, 1024 buckets; a part's key = the face's estimate / parts), so the
-//      heavy items of all meshes of the group start first and the launch drains on cheap ones -- or, for the variants that
-//      prefer their faces' index order (`sorted` 0), keeps that order with the parts of a split face side by side; the list is
-//      padded with 0xffffffff to its fixed length;
+//      heavy items of all meshes of the group start first and the launch drains on cheap ones (`sorted` 0, an A/B switch, keeps
+//      the index order with the parts of a split face side by side); the list is padded with 0xffffffff to its fixed length;
 //   4. lists the split faces (split[list][0] = their number, then {item word, first slab} each) for k_split_reduce, which runs
 //      after the main kernel and adds each split face's partial sums in part order.
 // Neither order nor split changes WHICH pairs contribute, and a split face's sum is formed in a fixed order: results do not
@@ -264,8 +263,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
         int np = 1;
         if (level < SPLIT_LEVELS) { const int T = split_threshold(O.T0, level); np = min(max((nt + T - 1) / T, 1), lim); }
         const int nt_order = (s_key[e] & 0x8000) ? nt >> 3 : nt;
-        // sorted: heavy items first (a part's key = its share of the face's estimate); else INDEX order, bucket by bucket (the
-        // variants whose waves read 28 B of state per pixel want their faces' spatial order more than a balanced drain)
+        // sorted: heavy items first (a part's key = its share of the face's estimate); else INDEX order, bucket by bucket (A/B)
         const int key = O.sorted ? min((nt_order + np - 1) / np, ORDER_KEYS - 1) : ORDER_KEYS - 1 - (int)(((long long)e * ORDER_KEYS) / E);
         s_key[e] = (unsigned short)key;
         s_np[e] = (unsigned char)np;

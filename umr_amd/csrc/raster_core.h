@@ -107,6 +107,11 @@ struct RasterArgs {
     float *vis;         // k_raster_forward<1, .., VIS>: hard z-buffer planes [N,2,IS,IS] = (nearest depth, its face id | -1),
                         // written next to the soft-max render of the same faces (umr_raster_forward_vis)
     int no_xcd_remap;   // A/B switch (umr_debug_set("xcd_remap", 0)): pixel-major work items in plain blockIdx order
+    // forward: start order of the 16x16-pixel workgroup blocks (k_block_order).  block_order[(g * 8 + xcd) * block_group * per_mesh + i]
+    // = (mesh - g * block_group) << 16 | block row << 8 | block column of the i-th workgroup XCD `xcd` starts within mesh group g
+    // (per_mesh = tiles_y / 8 * tiles_x: XCD x keeps block rows x, x + 8, ... of every mesh); NULL = row by row, mesh by mesh.
+    const int *block_order;
+    int block_group;
     int bg_arg;       // background passed by value: soft_colors arrives uninitialised
     float bg0, bg1, bg2;
     // UMR_RASTER_PACKED_STATE / UMR_BWD_PACKED_STATE: the soft-max render's saved state as ONE tiled buffer instead of the planes
@@ -691,7 +696,14 @@ struct Tile {
 __device__ __forceinline__ void tile_setup(Tile &t, const RasterArgs &A) {
     const int total = A.N * A.tiles_x * A.tiles_y;
     int bx, by;
-    if (A.no_xcd_remap == 2 && A.tiles_y % 8 == 0) {
+    if (A.block_order) {          // (k_block_order: only with the row-interleaved mapping, tiles_y % 8 == 0)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gsz = A.block_group * (A.tiles_y >> 3) * A.tiles_x;
+        const int g = slot / gsz;
+        const int e = A.block_order[((size_t)g * 8 + xcd) * gsz + slot % gsz];
+        t.n = g * A.block_group + (e >> 16);
+        by = (e >> 8) & 255;
+        bx = e & 255;
+    } else if (A.no_xcd_remap == 2 && A.tiles_y % 8 == 0) {
         // XCD x (= blockIdx % 8) takes block rows x, x + 8, x + 16, ... of EVERY mesh: the dense middle rows of each mesh are
         // spread over all eight XCDs (balance at small N) while horizontally adjacent blocks -- which share most of their
         // faces' records -- stay in one L2
@@ -814,6 +826,57 @@ __global__ __launch_bounds__(256) void k_superblock_bin(const float4 *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) sb_count[n * gridDim.x + sb] = count;
+}
+
+// Start order of the forward's workgroup blocks.  A 16x16 block's work is its visits, and those follow the number of faces
+// over it: on a regular mesh blocks differ ~3x, on the half-trained meshes a training step renders (profiles/scenes/) a few
+// blocks sit under hundreds of stacked faces and, started late, are the launch's tail (VALU busy 0.72 against 0.82 on the regular
+// scene).  Per XCD -- which keeps its block rows x, x + 8, ... of every mesh: the records' L2 locality -- and per group of G meshes
+// the blocks are sorted by DESCENDING face count of their 64x64 super-block (k_superblock_bin's sb_count; counting sort, 1024
+// buckets): heavy blocks start first, the launch drains on empty ones.  The order changes no result (a block's pixels are its own).
+#define BLOCK_ORDER_KEYS 1024
+#define BLOCK_ORDER_MAX_ENTRIES 16384
+#define BLOCK_ORDER_THREADS 1024
+__global__ __launch_bounds__(BLOCK_ORDER_THREADS) void k_block_order(const int *__restrict__ sb_count, int *__restrict__ order, int N,
+                                                                      int tiles_x, int tiles_y, int sb_size, int sb_nx, int sb_slots, int G) {
+    __shared__ int s_hist[BLOCK_ORDER_KEYS];
+    __shared__ int s_wsum[BLOCK_ORDER_THREADS / 64];
+    __shared__ unsigned short s_key[BLOCK_ORDER_MAX_ENTRIES];
+    const int xcd = blockIdx.x, g = blockIdx.y, per_mesh = (tiles_y >> 3) * tiles_x;
+    const int m0 = g * G, gl = min(G, N - m0), E = gl * per_mesh;
+    for (int k = threadIdx.x; k < BLOCK_ORDER_KEYS; k += BLOCK_ORDER_THREADS) s_hist[k] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += BLOCK_ORDER_THREADS) {
+        const int ml = e / per_mesh, rem = e - ml * per_mesh;
+        const int by = (rem / tiles_x) * 8 + xcd, bx = rem % tiles_x;
+        const int sb = ((by * BLK_H) / sb_size) * sb_nx + (bx * BLK_W) / sb_size;
+        const int key = min(sb_count[(m0 + ml) * sb_slots + sb], BLOCK_ORDER_KEYS - 1);
+        s_key[e] = (unsigned short)key;
+        atomicAdd(&s_hist[key], 1);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kb = BLOCK_ORDER_KEYS - 1 - (int)threadIdx.x;      // exclusive prefix over DESCENDING keys: thread t owns key 1023 - t
+    const int mine = s_hist[kb];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    __syncthreads();
+    s_hist[kb] = base;
+    __syncthreads();
+    int *out = order + ((size_t)g * 8 + xcd) * ((size_t)G * per_mesh);
+    for (int e = threadIdx.x; e < E; e += BLOCK_ORDER_THREADS) {
+        const int ml = e / per_mesh, rem = e - ml * per_mesh;
+        const int pos = atomicAdd(&s_hist[s_key[e]], 1);
+        out[pos] = (ml << 16) | (((rem / tiles_x) * 8 + xcd) << 8) | (rem % tiles_x);
+    }
 }
 
 }  // namespace
