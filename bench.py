@@ -459,11 +459,11 @@ def main(device=None, backend="nccl"):
         side.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(side):
-                n_w = max(3, args.warmup)
-                for i_ in range(n_w):
-                    if i_ == n_w - 3:                    # what the eager step costs the HOST (enqueue only), over the last three
-                        torch.cuda.synchronize()         # warm-up steps: profiling off, queue empty at the start
-                        t_e = time.perf_counter()
+                for _ in range(max(3, args.warmup)):
+                    eager_step()
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()                # what the eager step costs the HOST (enqueue only): three more steps after
+                for _ in range(3):                       # the warm-up (first-use solver searches are behind us), profiling off
                     eager_step()
                 eager_host_ms = 1e3 * (time.perf_counter() - t_e) / 3
                 torch.cuda.synchronize()

@@ -494,7 +494,7 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         R.split = split_list; R.slab = slab; R.grad_faces = grad_faces; R.grad_textures = grad_textures;
         R.F = F; R.TS = TS; R.G = G; R.X = OL.extra; R.slab_stride = A.slab_stride;
         R.need_gf = need_grad_faces; R.need_gt = need_grad_textures;
-        UMR_LAUNCH(k_split_reduce, dim3(SPLIT_REDUCE_BLOCKS, OL.groups * 8), 64, 0, st, R);
+        UMR_LAUNCH(k_split_reduce, OL.groups * 8, SPLIT_REDUCE_WAVES * 64, 0, st, R);
     }
     return umr_launch_status();
 }

@@ -310,17 +310,18 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
 
 // Second half of a split face (k_face_order): one wave per split face adds the partial sums its items left in their slabs, in
 // part order, and adds the total to the face's gradient -- the launch boundary is what orders the items' stores before these
-// loads.  Grid (SPLIT_REDUCE_BLOCKS, lists): block (b, l) takes entries b, b + SPLIT_REDUCE_BLOCKS, ... of list l.
-#define SPLIT_REDUCE_BLOCKS 32
+// loads.  One workgroup of SPLIT_REDUCE_WAVES waves per list: wave w takes entries w, w + SPLIT_REDUCE_WAVES, ... (a launch
+// without split faces -- the common case on regular meshes -- is `lists` workgroups that read one word and exit).
+#define SPLIT_REDUCE_WAVES 4
 struct SplitReduceArgs {
     const uint2 *split; const float *slab; float *grad_faces; float *grad_textures;
     int F, TS, G, X, slab_stride, need_gf, need_gt;
 };
-__global__ __launch_bounds__(64) void k_split_reduce(const SplitReduceArgs R) {
-    const int list = blockIdx.y, g = list >> 3, lane = threadIdx.x;
+__global__ __launch_bounds__(SPLIT_REDUCE_WAVES * 64) void k_split_reduce(const SplitReduceArgs R) {
+    const int list = blockIdx.x, g = list >> 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint2 *sp = R.split + (size_t)list * (R.X + 1);
     const int count = (int)sp[0].x;
-    for (int i = blockIdx.x; i < count; i += SPLIT_REDUCE_BLOCKS) {
+    for (int i = wave; i < count; i += SPLIT_REDUCE_WAVES) {
         const uint2 e = sp[1 + i];
         const int nparts = (int)((e.x >> 21) & 31u) + 1, f = (int)(e.x & 0xffffu), n = g * R.G + (int)((e.x >> 16) & 31u);
         const float *s0 = R.slab + (size_t)e.y * R.slab_stride;

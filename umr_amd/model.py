@@ -61,22 +61,30 @@ def fc_stack(nc_inp, nc_out, nlayers, use_bn=True):
     return enc
 
 
-class _BiasAdd(torch.autograd.Function):
-    """y + bias over the channel axis, with the bias gradient summed in STAGES (over W, then H, then N)."""
+class _ConvStagedBiasGrad(torch.autograd.Function):
+    """F.conv2d whose backward takes the input / weight gradients from the library's convolution backward and sums the BIAS
+    gradient itself, in stages (over W, then H, then N)."""
 
     @staticmethod
-    def forward(ctx, y, bias):
-        ctx.mark_dirty(y)                              # y is the convolution's fresh output, which its backward does not read
-        return y.add_(bias.view(1, -1, 1, 1))
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, dilation, groups)
+        return F.conv2d(x, weight, bias, stride, padding, dilation, groups)
 
     @staticmethod
     def backward(ctx, g):
-        return g, g.sum(3).sum(2).sum(0)
+        x, weight = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.cfg
+        g = g.contiguous()
+        gi, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), list(dilation), False, [0, 0], groups,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        gb = g.sum(3).sum(2).sum(0) if ctx.needs_input_grad[2] else None
+        return gi, gw, gb, None, None, None, None
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters, same state_dict keys, same values) whose bias gradient over a LARGE output is not left to
-    the convolution's backward.  There it is one reduction of N x H x W values per channel, which ATen splits over several
+    """nn.Conv2d (same parameters, same state_dict keys, same forward values) whose bias gradient over a LARGE output is not left
+    to the convolution's backward.  There it is one reduction of N x H x W values per channel, which ATen splits over several
     workgroups that meet at a semaphore zeroed by a cudaMemsetAsync (ATen/native/cuda/Reduce.cuh: global_reduce).  On this
     ROCm stack a memset node of a captured HIP graph does not run again on replay (the same defect the library's own zero-fills
     met in round 2, umr_common.h: umr_k_zero), the semaphore keeps counting, no workgroup is ever 'last' and the bias gradient
@@ -84,16 +92,15 @@ class Conv2d(nn.Conv2d):
     values up to 1e38 in a replayed step, eager steps correct (tests/test_gpu_round5.py::
     test_whole_training_step_replays_from_a_hip_graph compares every gradient moment of a replay with the eager step's).
     Summed in stages each reduction is short enough for one workgroup per output: no semaphore, no memset."""
-    STAGED_FROM = 16384          # N x H x W per channel from which the bias is added / reduced here
+    STAGED_FROM = 16384          # N x H x W per channel from which the bias gradient is summed here
 
     def forward(self, x):
-        if self.bias is not None and x.dim() == 4:
+        if self.bias is not None and x.dim() == 4 and isinstance(self.padding, tuple) and self.padding_mode == "zeros":
             k, st, pd, dl = self.kernel_size, self.stride, self.padding, self.dilation
-            if isinstance(pd, tuple):       # output extent as F.conv2d computes it
-                ho = (x.shape[2] + 2 * pd[0] - dl[0] * (k[0] - 1) - 1) // st[0] + 1
-                wo = (x.shape[3] + 2 * pd[1] - dl[1] * (k[1] - 1) - 1) // st[1] + 1
-                if x.shape[0] * ho * wo >= self.STAGED_FROM:
-                    return _BiasAdd.apply(self._conv_forward(x, self.weight, None), self.bias)
+            ho = (x.shape[2] + 2 * pd[0] - dl[0] * (k[0] - 1) - 1) // st[0] + 1      # output extent as F.conv2d computes it
+            wo = (x.shape[3] + 2 * pd[1] - dl[1] * (k[1] - 1) - 1) // st[1] + 1
+            if x.shape[0] * ho * wo >= self.STAGED_FROM:
+                return _ConvStagedBiasGrad.apply(x, self.weight, self.bias, st, pd, dl, self.groups)
         return self._conv_forward(x, self.weight, self.bias)
 
 
