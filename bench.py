@@ -482,6 +482,13 @@ def main(device=None, backend="nccl"):
                 # (with a process group: its watchdog thread polls events of earlier collectives -- only THIS thread's calls
                 # belong to the capture)
                 mode = {"capture_error_mode": "thread_local"} if (world > 1 or args.force_ddp) else {}
+                if mode:
+                    # ... and let the watchdog retire the warm-up's (completed) collectives first: it polls the end event of every
+                    # work still on its list every 100 ms, HIP refuses a query on an event whose STREAM is capturing -- the process
+                    # group's own stream joins the capture with the first bucket -- even when the event was recorded before the
+                    # capture began (hipErrorCapturedEvent), and the watchdog then takes the process down (seen once in three runs)
+                    torch.cuda.synchronize()
+                    time.sleep(1.0)
                 with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(whole_graph, stream=side, **mode):
                     static_loss = eager_step()
             torch.cuda.current_stream().wait_stream(side)

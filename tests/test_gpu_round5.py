@@ -276,6 +276,9 @@ def replay_equals_eager(step, dev, tag, graph_kwargs=None, bn_eval=True):
     with torch.cuda.stream(side):
         warm = [float(step()) for _ in range(4)]
         torch.cuda.synchronize()
+        if graph_kwargs:            # (a process group is up: let its watchdog retire the warm-up's collectives before its stream captures,
+            import time             # bench.py has the story)
+            time.sleep(1.0)
         g = torch.cuda.CUDAGraph()
         with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g, stream=side, **(graph_kwargs or {})):
             static_loss = step()

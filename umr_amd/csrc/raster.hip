@@ -46,7 +46,7 @@ size_t ws_sblist_bytes(int N, int F, int slots) { return (size_t)N * slots * sb_
 // "face_order_group" debug switch can only shrink G).
 int order_extra(int gsz) { return gsz / 4 + 16; }
 int order_group_for(int N, int F) { return std::max(1, std::min(N <= 16 ? 16 : 8, ORDER_MAX_ENTRIES / std::max(1, F / 8))); }
-struct OrderLayout { int G, groups, stride, extra, slabs_per_list; size_t order_bytes, ctr_bytes, slab_bytes; };
+struct OrderLayout { int G, groups, stride, extra, slabs_per_list; size_t order_bytes, ctr_bytes, slab_bytes, est_bytes; };
 OrderLayout order_layout(int N, int F, int G) {
     OrderLayout L;
     L.G = G; L.groups = (N + G - 1) / G;
@@ -56,13 +56,14 @@ OrderLayout order_layout(int N, int F, int G) {
     L.order_bytes = (lists * L.stride * sizeof(uint2) + 255) & ~(size_t)255;
     L.ctr_bytes = (lists * (L.extra + 1) * sizeof(uint2) + 255) & ~(size_t)255;          // the split-face lists (k_split_reduce)
     L.slab_bytes = lists * L.slabs_per_list * SPLIT_UNIT * sizeof(float);
+    L.est_bytes = ((size_t)N * F * sizeof(unsigned) + 255) & ~(size_t)255;                 // k_face_estimate -> k_face_order
     return L;
 }
 size_t ws_order_bytes(int N, int F) {
     size_t worst = 0;
     for (int G = 1; G <= order_group_for(N, F); ++G) {
         const OrderLayout L = order_layout(N, F, G);
-        worst = std::max(worst, L.order_bytes + L.ctr_bytes + L.slab_bytes);
+        worst = std::max(worst, L.order_bytes + L.ctr_bytes + L.slab_bytes + L.est_bytes);
     }
     return worst;
 }
@@ -450,6 +451,8 @@ int umr_raster_backward(const float *faces, const float *textures, const float *
         O.X = extra_run / units;                       // extra items this launch's lists may hold (its parts take `units` slab units each)
         O.slabs_per_list = OL.slabs_per_list / units;
         O.T0 = g_face_split;
+        O.est = (unsigned *)(op + OL.order_bytes + OL.ctr_bytes + OL.slab_bytes);
+        UMR_LAUNCH(k_face_estimate, (total + 255) / 256, 256, 0, st, O);
         UMR_LAUNCH(k_face_order, dim3(8, OL.groups), ORDER_THREADS, 0, st, O);
         A.order = order; A.order_group = G; A.order_stride = stride_run;
         A.slab = slab; A.slab_stride = units * SPLIT_UNIT;

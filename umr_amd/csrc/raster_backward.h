@@ -160,17 +160,80 @@ __device__ __forceinline__ int split_threshold(int T0, int k) {
     const int num[SPLIT_LEVELS] = {4, 5, 6, 8, 12, 16, 32, 64};
     return max((max(T0, 1) * num[k]) >> 2, 1);
 }
+// parts of a face of estimate nt at threshold T: ceil(nt / T) in [1, lim], in float arithmetic (exact for the quotients <= 32 that
+// matter; an integer division is ~40 instructions and the level search makes eight per face).  Every pass of k_face_order calls
+// THIS function, so the item count and the lists agree.
+__device__ __forceinline__ int split_parts(int nt, int T, int lim) {
+    return min(max((int)ceilf((float)nt / (float)T), 1), lim);
+}
 #define SPLIT_UNIT 128          // floats per slab unit (a part of the BASELINE variants -- 9 + 3 x 36 sums -- takes one)
 #ifndef SPLIT_T0
-#define SPLIT_T0 128            // estimated work (sub-tiles) one item may carry before its face is split
-#endif
+#define SPLIT_T0 192            // estimated work (sub-tiles) one item may carry before its face is split: 64 ... 192 time the same on the
+#endif                          // frozen training scenes (107 / 108 us), 256 costs 8 - 12 %; the larger, the fewer faces of a regular mesh split
 struct OrderArgs {
     const float4 *bbox; const float *rec; uint2 *order; uint2 *split;   // split: [lists][X + 1]
+    unsigned *est;                            // [N * F] k_face_estimate -> k_face_order
     const float *alpha;                       // silhouette launch: the alpha plane [N, IS, IS]
     const float *state, *aggrs;               // colour launches: the packed saved state, or aggrs_info [N, 2, IS, IS]
     float far_, r_range, inv_gamma;
     int N, F, IS, G, mode, sorted, run_split, rotate, stride, X, X_alloc, slabs_per_list, units_per_part, T0;   // X <= X_alloc: this launch's budget of extra items
 };
+// Step 1 of k_face_order's list, one thread per (mesh, face) over the whole chip (inside k_face_order -- one 1 024-thread workgroup
+// per XCD -- it was 20 of that kernel's 29 us at N = 16): est[n * F + f] = estimate (15 bits) | start order at an eighth << 15 |
+// most parts the face can have << 16.
+__global__ __launch_bounds__(256) void k_face_estimate(const OrderArgs O) {
+    const int i = blockIdx.x * 256 + (int)threadIdx.x, F = O.F, IS = O.IS;
+    if (i >= O.N * F) return;
+    const size_t fi = (size_t)i;
+    const size_t n_ = fi / F;
+    const float h = 0.5f * IS;
+    // work estimate: 4x4 sub-tiles under the dilated bbox (the window the wave will walk; NaN bounds: the whole image)
+    const float4 bb = O.bbox[fi];
+    int raw = 0x7fff;
+    if (bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w) {
+        const int px0 = max((int)floorf(bb.x * h + h - 0.5f) - 1, 0), px1 = min((int)ceilf(bb.y * h + h - 0.5f) + 1, IS - 1);
+        const int py0 = max((int)floorf(bb.z * h + h - 0.5f) - 1, 0), py1 = min((int)ceilf(bb.w * h + h - 0.5f) + 1, IS - 1);
+        raw = (px0 <= px1 && py0 <= py1) ? min(((px1 >> 2) - (px0 >> 2) + 1) * ((py1 >> 2) - (py0 >> 2) + 1), 0x7fff) : 0;
+    }
+    const unsigned c = (__float_as_int(O.rec[fi * REC + R_FLAGS]) & 32) ? 0x8000u : 0u;      // front-facing (k_face_setup)
+    int nt = raw;
+    bool order_eighth = false;
+    // Faces the state cull will (mostly) remove, judged at the face's corners and centroid with the kernels' own tests:
+    //  * silhouette launch (mode 2): alpha == 1.0f at all five -- g (1 - alpha) = 0 there;
+    //  * colour launches (mode 1), back faces only: the face is depth-dead at all five -- even its nearest depth lies >= 89
+    //    gamma behind the pixel's soft-max maximum, i.e. a nearer face covers it and its weight is 0.0f.
+    // A back face that sticks OUT of the silhouette (a spike of a half-trained mesh) is its own nearest surface: it is
+    // walked in full.  (Round 5 discounted every back face; on the captured training scenes such faces were the launch's tail.)
+    if (nt > 0 && (O.mode == 2 || (O.mode == 1 && !(c & 0x8000u))) && (O.alpha || O.state || O.aggrs)) {
+        const float *r = O.rec + fi * REC;
+        const float cx[4] = {r[R_X0], r[R_X1], r[R_X2], (r[R_X0] + r[R_X1] + r[R_X2]) * (1.f / 3.f)};
+        const float cy[4] = {r[R_Y0], r[R_Y1], r[R_Y2], (r[R_Y0] + r[R_Y1] + r[R_Y2]) * (1.f / 3.f)};
+        const float zq = (O.far_ - fminf(fminf(r[R_Z0], r[R_Z1]), r[R_Z2])) * O.r_range;
+        bool removed = true;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int xi = min(max((int)(cx[c4] * h + h), 0), IS - 1), row = IS - 1 - min(max((int)(cy[c4] * h + h), 0), IS - 1);
+            const size_t pn = (size_t)row * IS + xi;
+            if (O.mode == 2) removed &= O.alpha[n_ * IS * IS + pn] == 1.f;
+            else {
+                // the pixel's soft-max maximum: packed state, [16 + 4 (y & 3) + (x & 3)] of its 4x4 tile's record, or plane 1 of aggrs_info
+                const float smax = O.state ? O.state[(n_ * (IS >> 2) * (IS >> 2) + (size_t)(row >> 2) * (IS >> 2) + (xi >> 2)) * STATE_REC +
+                                                     STATE_O_MAX + (row & 3) * 4 + (xi & 3)]
+                                           : O.aggrs[(n_ * 2 + 1) * IS * IS + pn];
+                removed &= (zq - smax) * O.inv_gamma < -89.f;
+            }
+        }
+        if (removed) nt >>= 3;
+        // (a back face that is NOT removed at all five probes: split by its full estimate -- it may be a spike --, but started
+        // where round 5's rule puts it, an eighth: on regular meshes such faces sit near the silhouette's rim and the quad-level
+        // state cull still removes most of them; measured on the SURVEY 8d scene, one-pass backward: 142 -> 137 us)
+        else if (O.mode == 1) order_eighth = true;
+    }
+    // a face cannot have more parts than culling passes (64 candidate sub-tiles each)
+    const int lim = max(1, min(SPLIT_MAX_PARTS, (raw + 63) >> 6));
+    O.est[fi] = (unsigned)nt | (order_eighth ? 0x8000u : 0u) | ((unsigned)lim << 16);
+}
+
 __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O) {
     __shared__ int s_hist[ORDER_KEYS];
     __shared__ int s_wsum[ORDER_THREADS / 64];
@@ -178,70 +241,23 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
     __shared__ unsigned char s_np[ORDER_MAX_ENTRIES];
     __shared__ int s_ex[SPLIT_LEVELS];
     __shared__ int s_slab, s_level, s_nsplit;
-    const int xcd = blockIdx.x, g = blockIdx.y, F = O.F, IS = O.IS, per = F >> 3;
+    const int xcd = blockIdx.x, g = blockIdx.y, F = O.F, per = F >> 3;
     const int m0 = g * O.G, gl = min(O.G, O.N - m0), E = gl * per;
     for (int k = threadIdx.x; k < ORDER_KEYS; k += ORDER_THREADS) s_hist[k] = 0;
     if (threadIdx.x < SPLIT_LEVELS) s_ex[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_slab = 0; s_nsplit = 0; }
     __syncthreads();
-    const float h = 0.5f * IS;
     int ex[SPLIT_LEVELS];
 #pragma unroll
     for (int k = 0; k < SPLIT_LEVELS; ++k) ex[k] = 0;
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
         const int ml = e / per, f = fm_owned_face((xcd + (m0 + ml) * O.rotate) & 7, e % per, per, O.run_split);
-        const size_t fi = (size_t)(m0 + ml) * F + f;
-        // work estimate: 4x4 sub-tiles under the dilated bbox (the window the wave will walk; NaN bounds: the whole image)
-        const float4 bb = O.bbox[fi];
-        int raw = 0x7fff;
-        if (bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w) {
-            const int px0 = max((int)floorf(bb.x * h + h - 0.5f) - 1, 0), px1 = min((int)ceilf(bb.y * h + h - 0.5f) + 1, IS - 1);
-            const int py0 = max((int)floorf(bb.z * h + h - 0.5f) - 1, 0), py1 = min((int)ceilf(bb.w * h + h - 0.5f) + 1, IS - 1);
-            raw = (px0 <= px1 && py0 <= py1) ? min(((px1 >> 2) - (px0 >> 2) + 1) * ((py1 >> 2) - (py0 >> 2) + 1), 0x7fff) : 0;
-        }
-        const unsigned c = (__float_as_int(O.rec[fi * REC + R_FLAGS]) & 32) ? 0x8000u : 0u;      // front-facing (k_face_setup)
-        int nt = raw;
-        bool order_eighth = false;
-        // Faces the state cull will (mostly) remove, judged at the face's corners and centroid with the kernels' own tests:
-        //  * silhouette launch (mode 2): alpha == 1.0f at all five -- g (1 - alpha) = 0 there;
-        //  * colour launches (mode 1), back faces only: the face is depth-dead at all five -- even its nearest depth lies >= 89
-        //    gamma behind the pixel's soft-max maximum, i.e. a nearer face covers it and its weight is 0.0f.
-        // A back face that sticks OUT of the silhouette (a spike of a half-trained mesh) is its own nearest surface: it is
-        // walked in full.  (Round 5 discounted every back face; on the captured training scenes such faces were the launch's tail.)
-        if (nt > 0 && (O.mode == 2 || (O.mode == 1 && !(c & 0x8000u))) && (O.alpha || O.state || O.aggrs)) {
-            const float *r = O.rec + fi * REC;
-            const float cx[4] = {r[R_X0], r[R_X1], r[R_X2], (r[R_X0] + r[R_X1] + r[R_X2]) * (1.f / 3.f)};
-            const float cy[4] = {r[R_Y0], r[R_Y1], r[R_Y2], (r[R_Y0] + r[R_Y1] + r[R_Y2]) * (1.f / 3.f)};
-            const float zq = (O.far_ - fminf(fminf(r[R_Z0], r[R_Z1]), r[R_Z2])) * O.r_range;
-            bool removed = true;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const int xi = min(max((int)(cx[c4] * h + h), 0), IS - 1), row = IS - 1 - min(max((int)(cy[c4] * h + h), 0), IS - 1);
-                const size_t n_ = (size_t)(m0 + ml), pn = (size_t)row * IS + xi;
-                if (O.mode == 2) removed &= O.alpha[n_ * IS * IS + pn] == 1.f;
-                else {
-                    // the pixel's soft-max maximum: packed state, [16 + 4 (y & 3) + (x & 3)] of its 4x4 tile's record, or plane 1 of aggrs_info
-                    const float smax = O.state ? O.state[(n_ * (IS >> 2) * (IS >> 2) + (size_t)(row >> 2) * (IS >> 2) + (xi >> 2)) * STATE_REC +
-                                                         STATE_O_MAX + (row & 3) * 4 + (xi & 3)]
-                                               : O.aggrs[(n_ * 2 + 1) * IS * IS + pn];
-                    removed &= (zq - smax) * O.inv_gamma < -89.f;
-                }
-            }
-            if (removed) nt >>= 3;
-            // (a back face that is NOT removed at all five probes: split by its full estimate -- it may be a spike --, but started
-            // where round 5's rule puts it, an eighth: on regular meshes such faces sit near the silhouette's rim and the quad-level
-            // state cull still removes most of them; measured on the SURVEY 8d scene, one-pass backward: 142 -> 137 us)
-            else if (O.mode == 1) order_eighth = true;
-        }
-        // a face cannot have more parts than culling passes (64 candidate sub-tiles each)
-        const int lim = max(1, min(SPLIT_MAX_PARTS, (raw + 63) >> 6));
-        s_key[e] = (unsigned short)(nt | (order_eighth ? 0x8000 : 0));
+        const unsigned v = O.est[(size_t)(m0 + ml) * F + f];      // k_face_estimate: estimate (15 bits) | start at an eighth << 15 | most parts << 16
+        const int nt = (int)(v & 0x7fffu), lim = (int)(v >> 16);
+        s_key[e] = (unsigned short)(v & 0xffffu);
         s_np[e] = (unsigned char)lim;
 #pragma unroll
-        for (int k = 0; k < SPLIT_LEVELS; ++k) {
-            const int T = split_threshold(O.T0, k);
-            ex[k] += min(max((nt + T - 1) / T, 1), lim) - 1;
-        }
+        for (int k = 0; k < SPLIT_LEVELS; ++k) ex[k] += split_parts(nt, split_threshold(O.T0, k), lim) - 1;
     }
 #pragma unroll
     for (int k = 0; k < SPLIT_LEVELS; ++k) {
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
     for (int e = threadIdx.x; e < E; e += ORDER_THREADS) {
         const int nt = s_key[e] & 0x7fff, lim = s_np[e];
         int np = 1;
-        if (level < SPLIT_LEVELS) { const int T = split_threshold(O.T0, level); np = min(max((nt + T - 1) / T, 1), lim); }
+        if (level < SPLIT_LEVELS) np = split_parts(nt, split_threshold(O.T0, level), lim);
         const int nt_order = (s_key[e] & 0x8000) ? nt >> 3 : nt;
         // sorted: heavy items first (a part's key = its share of the face's estimate); else INDEX order, bucket by bucket (A/B)
         const int key = O.sorted ? min((nt_order + np - 1) / np, ORDER_KEYS - 1) : ORDER_KEYS - 1 - (int)(((long long)e * ORDER_KEYS) / E);
@@ -310,9 +326,11 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_face_order(const OrderArgs O)
 
 // Second half of a split face (k_face_order): one wave per split face adds the partial sums its items left in their slabs, in
 // part order, and adds the total to the face's gradient -- the launch boundary is what orders the items' stores before these
-// loads.  One workgroup of SPLIT_REDUCE_WAVES waves per list: wave w takes entries w, w + SPLIT_REDUCE_WAVES, ... (a launch
-// without split faces -- the common case on regular meshes -- is `lists` workgroups that read one word and exit).
-#define SPLIT_REDUCE_WAVES 4
+// loads.  ONE workgroup of SPLIT_REDUCE_WAVES waves per list; wave w takes entries w, w + SPLIT_REDUCE_WAVES, ...  (What the shape
+// costs, measured: 32 one-wave workgroups per list 12 us whether or not anything was split -- 0.8 ms per train_s2 step with its
+// 11 x 128 lists; one 4-wave workgroup per list 3 us empty but 44 us on a captured training scene with ~100 split faces per list:
+// a face is a chain of ~5 dependent memory round trips.)
+#define SPLIT_REDUCE_WAVES 16
 struct SplitReduceArgs {
     const uint2 *split; const float *slab; float *grad_faces; float *grad_textures;
     int F, TS, G, X, slab_stride, need_gf, need_gt;
@@ -325,13 +343,9 @@ __global__ __launch_bounds__(SPLIT_REDUCE_WAVES * 64) void k_split_reduce(const 
         const uint2 e = sp[1 + i];
         const int nparts = (int)((e.x >> 21) & 31u) + 1, f = (int)(e.x & 0xffffu), n = g * R.G + (int)((e.x >> 16) & 31u);
         const float *s0 = R.slab + (size_t)e.y * R.slab_stride;
-        unsigned mask = 0u;
-        for (int q = 0; q < nparts; ++q) mask |= s0[(size_t)q * R.slab_stride + 9] != 0.f ? 1u << q : 0u;
-        if (!mask) continue;
         if (R.need_gf && lane < 9) {
             float acc = 0.f;
-            for (int q = 0; q < nparts; ++q)
-                if ((mask >> q) & 1u) acc += s0[(size_t)q * R.slab_stride + lane];
+            for (int q = 0; q < nparts; ++q) acc += s0[(size_t)q * R.slab_stride + lane];
             UMR_TRAP_AT(umr_bad(acc), 4, ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
             R.grad_faces[((size_t)n * R.F + f) * 9 + lane] += acc;
         }
@@ -339,8 +353,7 @@ __global__ __launch_bounds__(SPLIT_REDUCE_WAVES * 64) void k_split_reduce(const 
             float *dst = R.grad_textures + ((size_t)n * R.F + f) * R.TS * 3;
             for (int j = lane; j < R.TS * 3; j += 64) {
                 float acc = 0.f;
-                for (int q = 0; q < nparts; ++q)
-                    if ((mask >> q) & 1u) acc += s0[(size_t)q * R.slab_stride + 16 + j];
+                for (int q = 0; q < nparts; ++q) acc += s0[(size_t)q * R.slab_stride + 16 + j];
                 UMR_TRAP_AT(umr_bad(acc), 5, ((unsigned)(n & 127) << 16) | ((unsigned)f & 0xffffu));
                 dst[j] += acc;
             }

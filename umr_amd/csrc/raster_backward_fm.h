@@ -577,8 +577,8 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
         item = (unsigned)__builtin_amdgcn_readfirstlane((int)A.order[((size_t)((blockIdx.x >> 3) / A.order_stride) * 8 + (blockIdx.x & 7)) * A.order_stride +
                                                                      (blockIdx.x >> 3) % A.order_stride].x);
     if (FM_WAVES == 1 && (item >> 21)) {
-        // One part of a split face: leave this item's partial sums in its slab (vertex gradients at [0, 9), "visited a pixel" at
-        // [9], texel gradients from [16]).  k_split_reduce -- the next launch on the stream -- adds a face's parts in part order
+        // One part of a split face: leave this item's partial sums in its slab (vertex gradients at [0, 9), texel gradients
+        // from [16]).  k_split_reduce -- the next launch on the stream -- adds a face's parts in part order
         // and stores: the sum a face gets is a function of its parts' sums and their fixed order alone.  (An in-kernel hand-over
         // to the last arriving item was measured first: its device-scope fences write back / invalidate the XCD's L2 and cost
         // 3x the kernel's time.)
@@ -587,8 +587,10 @@ __global__ __launch_bounds__(FM_WAVES * 64) BWD_WPE_ATTR void FM_KERNEL_NAME(con
         const unsigned slab0 = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)A.order[((size_t)(slot_ / A.order_stride) * 8 + xcd_) * A.order_stride + slot_ % A.order_stride].y);
         float *sl = A.slab + (size_t)(slab0 + (unsigned)part) * A.slab_stride;
-        if (lane == 9) sl[9] = visited ? 1.f : 0.f;
-        if (!visited) return;
+        if (!visited) {        // nothing under this part: its sums are zeros (k_split_reduce adds every part, no flags to fetch first)
+            for (int j = lane; j < 16 + (NEED_GT ? TS * 3 : 0); j += 64) sl[j] = 0.f;
+            return;
+        }
         if (NEED_GF) {
             float mine = 0.f;
 #pragma unroll

@@ -96,7 +96,7 @@ struct RasterArgs {
     const uint2 *order;
     int order_group, order_stride;
     int fm_blocks;                  // workgroups of the face-major launch: N x F, or the lists' total length
-    float *slab;                    // [slabs][slab_stride]: vertex gradients at [0, 9), visited flag at [9], texel gradients at [16, 16 + 3 TS)
+    float *slab;                    // [slabs][slab_stride]: vertex gradients at [0, 9), texel gradients at [16, 16 + 3 TS)
     int slab_stride;
     int fm_split;      // runs of faces per XCD and mesh in the face-major backward (fm_owned_face); 0 / 1 = one
     int tex_group;    // K >= 1: mesh n samples textures[n / K] (K views share one texture set)
