@@ -124,6 +124,16 @@ if rf.get("scenes"):
     for sn, d_ in rf["scenes"].items():
         L.append("* %s: %s" % (sn, ", ".join("%s %.1f" % kv for kv in d_.items())))
     L.append("")
+ss = os.path.join(FAST, "scene_stats", "t_kernel_stats.csv")
+if os.path.exists(ss):
+    keep(ss, "frozen_scenes_kernel_stats.csv")
+    L.append("rocprofv3 `--kernel-trace --stats` of `tools/scene_times.py live_s1_a.npz live_s1_b.npz` (`profiles/%s_frozen_scenes_kernel_stats.csv`; "
+             "2 warm-up + 20 timed launches per scene) -- the averages `roofline.avg_us` has to agree with:\n" % tag)
+    L.append("| kernel | calls | average us |\n|---|---|---|")
+    for r_ in csv.DictReader(open(ss)):
+        if "k_raster" in r_["Name"]:
+            L.append("| `%s` | %s | %.1f |" % (r_["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:70], r_["Calls"], float(r_["AverageNs"]) / 1e3))
+    L.append("")
 for sc_name in ("live_s1_a", "live_s1_b", "survey_8d"):
     pj = os.path.join(FAST, "pmc_" + sc_name, "pmc_summary.json")
     if os.path.exists(pj):

@@ -16,6 +16,9 @@ python -c "from umr_amd import _lib; print(_lib.build_id())" > "$O/build_id.txt"
     --cpu-baseline 0 --hot-path-sub 0 --fixed-scene 0 > "$O/stats.log" 2>&1)
 tools/collect_traffic.sh "$O/traffic" > "$O/traffic.log" 2>&1
 cp "$O/traffic/traffic.json" profiles/traffic.json
+# rocprofv3's own per-kernel averages over the FROZEN training scenes: the durations bench.py's roofline.{avg_us, frac} are built from
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/scene_stats" -o t -- python "$R/tools/scene_times.py" "$R/profiles/scenes/live_s1_a.npz" \
+    "$R/profiles/scenes/live_s1_b.npz" > "$O/scene_stats.log" 2>&1)
 # counters of the raster kernels on the FROZEN scenes (deterministic; the passes above see the live step's lottery scene)
 for sc in live_s1_a survey_8d; do
   if [ "$sc" = survey_8d ]; then T="tools/kernels.py 3"; else T="tools/scene_times.py profiles/scenes/$sc.npz --iters 3"; fi
