@@ -43,7 +43,10 @@ const char *umr_build_id(void);
 int umr_profile_enable(int on);
 /* A/B switches for benchmarking kernel variants ("bwd_pixel_major": 1 selects the tile-binned
  * pixel-major backward with global atomics instead of the default face-major one; "superblock_bins",
- * "xcd_remap", "face_order", "face_order_group": see raster.hip), and two switches that trade time for
+ * "xcd_remap", "face_order" (0 one wave per face in index order, 1 work-item lists in cost order), "face_order_group",
+ * "face_split" (estimated work -- 4x4 sub-tiles -- beyond which a face is split into several work items; 0 never,
+ * negative = default 192), "face_split_budget", "fm_runs", "fm_rotate", "block_order" (0: the forward starts its
+ * workgroup blocks row by row instead of heavy blocks first): see raster.hip), and two switches that trade time for
  * exactness (HISTORY.md 4.4).  Inside a triangle the reference keeps the edge line with the smallest COMPUTED
  * distance (:78-107); the kernels pick it by its true distance unless the face is thin.
  *   "exact_edges" (default 1): inside pixels whose SECOND nearest edge line is closer than sqrt(20 sigma) evaluate
@@ -138,8 +141,8 @@ int umr_profile_collect(int which, double *total_ms, long *launches, double *tot
                                    and scalars filled, untouched since: its face records and bounding boxes are read, not rebuilt
                                    (one small launch less per backward; the ABI stays stateless without the flag) */
 
-/* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins, the backward's
- * start order).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst
+/* Bytes of caller-provided scratch one raster call needs (bounding boxes, face records, per-mesh coarse bins; the forward's block
+ * start order; the backward's work-item lists, work estimates, split-face lists and the slabs of the split faces' partial sums).  umr_raster_workspace_bytes(N, F) is valid for EVERY image size (coarse bins sized for their 256-slot worst
  * case: 1 MB per mesh at F >= 1024); umr_raster_workspace_bytes_for(N, F, image_size) is the exact amount for that size (64 slots
  * per mesh up to 512^2: a quarter of it) -- a caller that knows the size it is about to render may allocate this instead. */
 size_t umr_raster_workspace_bytes(int N, int F);

@@ -300,7 +300,7 @@ def test_emulated_library_exports_the_whole_c_abi(L):
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.umr_version() == b"umr_hip 0.6 gfx950" and L.umr_build_id() == b"host-emulation"
+    assert L.umr_version() == b"umr_hip 0.7 gfx950" and L.umr_build_id() == b"host-emulation"
 
 
 def test_exactness_switches_change_what_they_say(L, oracle_built):

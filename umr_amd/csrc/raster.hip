@@ -162,7 +162,7 @@ extern "C" int umr_debug_trap(int reset, unsigned long long *when) {
 
 extern "C" {
 
-const char *umr_version(void) { return "umr_hip 0.6 gfx950"; }
+const char *umr_version(void) { return "umr_hip 0.7 gfx950"; }
 
 #ifndef UMR_SRC_HASH
 #define UMR_SRC_HASH "unknown"
