@@ -289,3 +289,53 @@ def test_backward_reuses_the_forward_workspace():
         out.append((gf, gt))
     assert float(out[0][0].abs().max()) > 0 and float(out[0][1].abs().max()) > 0
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def _two_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from umr_amd.model import build_training_step
+    from umr_amd.synthetic import template
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device(DEV)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # (one GPU on the box: RCCL refuses two ranks on a device)
+    try:
+        torch.manual_seed(0)                                           # identical initial replicas, as bench.py
+        args = types.SimpleNamespace(batch=2, image_size=64, subdivide=2, epoch=0, graph=0, share_mask_render=1)
+        tv, faces = template(2)
+        step = build_training_step(tv, faces, args, dev, world)        # per-rank data: seed 100 + rank
+        assert step.sync is not None
+        losses, sums = [], []
+        for _ in range(3):
+            losses.append(float(step()))
+            torch.cuda.synchronize()
+            sums.append(float(sum(p.detach().double().sum() for p in step.model.parameters() if p.requires_grad)))
+        g = step.sync.flat.double()
+        q.put((rank, losses, sums, float(g.sum()), float(g.abs().sum())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_exchange_gradients():
+    """The data-parallel step at WORLD SIZE 2 on the device: two processes share the box's one GPU, device tensors, the real kernels;
+    the gradient exchange (parallel.BucketedGradSync: hooks fire on the autograd thread, buckets all-reduced asynchronously while
+    backward runs, finish() before Adam) goes over gloo because RCCL does not take two ranks on one device -- the schedule, the
+    hooks and the stream ordering are the N > 1 path's, only the transport differs.  Different data per rank, three steps: the
+    ranks hold the same averaged gradient to the last bit and identical replicas after every step."""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    (_, l0, s0, g0, a0), (_, l1, s1, g1, a1) = res
+    assert all(math.isfinite(v) for v in l0 + l1) and l0 != l1          # finite, and the ranks really see different shards
+    assert a0 > 0 and g0 == g1 and a0 == a1, (g0, g1, a0, a1)          # the same all-reduced gradient on both ranks
+    assert s0 == s1 and s0[0] != s0[1], (s0, s1)                       # identical replicas after every step, and they move
