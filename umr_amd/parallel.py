@@ -66,7 +66,8 @@ class BucketedGradSync:
     measured the same way; under DDP the N > 1 step was eager and host-enqueue-bound).  wrap_ddp stays for callers that want DDP.
 
     Use:   sync = BucketedGradSync(model.parameters(), world)
-           sync.begin(); (loss * sync.loss_scale).backward(); sync.finish(); opt.step()       # never opt.zero_grad(set_to_none=True)
+           sync.begin(); (loss * sync.loss_scale).backward(); sync.finish(); opt.step()       # never opt.zero_grad(set_to_none=True);
+                                                                                              # ONE backward per begin() / finish()
     loss_scale = 1 / world: the all-reduce SUMS, so pre-scaled gradients come out averaged (what DataParallel's gather + mean
     and DDP both compute).  Parameters that received no gradient in a step contribute zeros."""
 
@@ -110,7 +111,11 @@ class BucketedGradSync:
             self._next += 1
 
     def _ready(self, p):
-        self._pending[self._bucket_of[id(p)]] -= 1
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] < 0:        # a second backward since begin(): the bucket has already been exchanged with partial sums
+            raise RuntimeError("BucketedGradSync: a parameter's gradient arrived twice in one step -- one backward() per "
+                               "begin() / finish() (accumulate over micro-batches in the loss, or call begin() again)")
         self._launch()
 
     def finish(self):
